@@ -1,0 +1,160 @@
+/*
+ * motifs_hip.h — C ABI of libmotifs_hip.so (MI355X / gfx950).
+ *
+ * This is the drop-in boundary for the motif-scanning hot path of MOTIFs.jl
+ * (SURVEY.md §8b).  The reference has no FFI of its own: the entry points
+ * below replace ordinary Julia call sites, each cited as
+ * `path:line` relative to the reference checkout.  Julia binds them with
+ * `ccall` (see INTEGRATION.md and julia/MotifsHIP.jl); tests and bench.py
+ * bind the same symbols with ctypes.
+ *
+ * Conventions
+ *   - every function returns an int status (MOTIFS_OK == 0); the text of the
+ *     last failure on the calling thread is motifs_last_error();
+ *   - no C++ exception, torch type or library-allocated buffer crosses the ABI;
+ *   - host buffers are owned by the caller and only read/written during the
+ *     call; `*_dev` entry points take device pointers (hipMalloc'ed or
+ *     torch-allocated) and enqueue on the context's stream without
+ *     synchronising;
+ *   - array layouts are the reference's: column-major, 1-based indices inside
+ *     records.
+ */
+#ifndef MOTIFS_HIP_H
+#define MOTIFS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MOTIFS_ABI_VERSION 1
+
+enum motifs_status {
+    MOTIFS_OK = 0,
+    MOTIFS_ERR_INVALID = 1,      /* bad argument (shape, null pointer, range)            */
+    MOTIFS_ERR_HIP = 2,          /* a HIP runtime call failed                            */
+    MOTIFS_ERR_NO_DEVICE = 3,    /* no gfx950 device visible: there is NO CPU fallback   */
+    MOTIFS_ERR_BUFFER_TOO_SMALL = 4, /* *n_out holds the required record count           */
+    MOTIFS_ERR_NOT_ONEHOT = 5,   /* a data column is not exactly one-hot / all-zero      */
+    MOTIFS_ERR_NONFINITE = 6,    /* PWM bank holds NaN/Inf (reference semantics differ)  */
+    MOTIFS_ERR_UNSUPPORTED = 7   /* e.g. maxlen > MOTIFS_SCAN_MAX_LEN                    */
+};
+
+/* Encodings accepted for a sequence matrix. */
+enum motifs_data_kind {
+    MOTIFS_DATA_CODES_U8 = 0,   /* N rows of L bytes, 0..3 = A,C,G,T, 4 = all-zero column   */
+    MOTIFS_DATA_ONEHOT_F32 = 1, /* reference `data.data_matrix` (4L,1,N) Float32,           */
+                                /* loadfasta/helpers.jl:110-139, fasta.jl:78-81             */
+    MOTIFS_DATA_ONEHOT_F16 = 2  /* what _h3_1_alignment.jl:74 uploads                       */
+};
+
+/* Order of hit records. */
+enum motifs_hit_order {
+    /* exactly the reference's: per 5000-sequence batch, `findall` column-major
+     * over (k, n, l): k fastest, then n, then l (_h3_1_alignment.jl:71-84).   */
+    MOTIFS_ORDER_REFERENCE = 0
+};
+
+#define MOTIFS_SCAN_MAX_LEN 32          /* longest PWM supported by the scan kernels */
+#define MOTIFS_SCAN_BATCH 5000          /* batch_size_greedy, _h3_1_alignment.jl:12  */
+
+typedef struct motifs_ctx motifs_ctx;   /* opaque: device id, stream, workspaces */
+
+/* One hit = the reference's record_t NTuple{3,UInt32} (_h3_1_alignment.jl:10):
+ * (m, n, l) = (PWM index, global sequence index, start position), all 1-based. */
+typedef struct motifs_hit {
+    uint32_t m;
+    uint32_t n;
+    uint32_t l;
+} motifs_hit;
+
+/* ---- context ------------------------------------------------------------ */
+
+int motifs_abi_version(void);
+const char* motifs_last_error(void);
+
+/* Fails with MOTIFS_ERR_NO_DEVICE when no GPU is visible. */
+int motifs_ctx_create(int device, motifs_ctx** out);
+void motifs_ctx_destroy(motifs_ctx* ctx);
+/* Use an existing hipStream_t (e.g. torch's current stream); NULL = own stream. */
+int motifs_ctx_set_stream(motifs_ctx* ctx, void* hip_stream);
+int motifs_ctx_synchronize(motifs_ctx* ctx);
+/* Per-kernel device time, measured with HIP events on the context stream
+ * around every launch of that kernel (each timed launch synchronises, so leave
+ * timing off outside measurements).  `slot` is a motifs_kernel_slot; *ms is the
+ * total since the last reset and *launches the number of timed launches. */
+enum motifs_kernel_slot {
+    MOTIFS_KS_ENCODE = 0,
+    MOTIFS_KS_SCAN_DENSE = 1,
+    MOTIFS_KS_SCAN_COUNT = 2,
+    MOTIFS_KS_SCAN_OFFSETS = 3,
+    MOTIFS_KS_SCAN_FILL = 4
+};
+int motifs_ctx_enable_timing(motifs_ctx* ctx, int on);
+int motifs_ctx_reset_timing(motifs_ctx* ctx);
+int motifs_ctx_kernel_ms(motifs_ctx* ctx, int slot, double* ms, int64_t* launches);
+
+/* ---- sequence encoding (input side of every kernel) ----------------------- */
+
+/* Bytes needed for the internal code matrix of N sequences of length L
+ * (rows padded to a multiple of 4 bytes + a guard). */
+size_t motifs_codes_bytes(int64_t N, int L);
+/* Row pitch in bytes of that matrix. */
+int motifs_codes_pitch(int L);
+/* Convert a device-resident matrix of `kind` into the internal code matrix.
+ * `bad_flag_dev` (int32 on device, may be NULL) is set non-zero if a column is
+ * neither one-hot nor all-zero. */
+int motifs_encode_dev(motifs_ctx* ctx, const void* data_dev, int kind, int64_t N, int L,
+                      uint8_t* codes_dev, int32_t* bad_flag_dev);
+
+/* ---- PWM scan: a17 greedy_search! --------------------------------------- */
+
+/* Replaces the kernel launch at _h3_1_alignment.jl:76-80.
+ * pwms_fp16: (K,4,maxlen) column-major IEEE binary16 bits, zero-padded beyond
+ *            lens[k] (host pointer; _h3_1_alignment.jl:66-69);
+ * codes_dev: internal code matrix of N sequences (motifs_encode_dev);
+ * scores_dev: (K, N, ld_l) column-major fp16, ld_l >= L - min(lens) + 1.
+ *            Entries with l <= L-lens[k]+1 get max(score,0); entries beyond, up
+ *            to ld_l, get +0 (the reference pre-zeroes the tensor, :75, with
+ *            ld_l = 4L).
+ * Score = sequential fp16 sum over ind = 1..lens[k] of
+ *         pwms[k, base(l+ind-1), ind], one rounding per add (:26-31). */
+int motifs_pwm_scan_dense_dev(motifs_ctx* ctx, const uint16_t* pwms_fp16, const int64_t* lens,
+                              int K, int maxlen, const uint8_t* codes_dev, int64_t N, int L,
+                              uint16_t* scores_dev, int64_t ld_l);
+
+/* ---- PWM scan: a18 get_pos_scores_arr ------------------------------------ */
+
+/* Replaces get_pos_scores_arr (_h3_1_alignment.jl:57-87) for one strand:
+ * scan + threshold (> 0) + ordered compaction, all on the device.
+ * hits_dev / hit_scores_dev: device buffers of `cap` records (may be NULL with
+ *            cap == 0: count only);
+ * n_out:     host; total number of hits (also when the buffer is too small);
+ * per_pwm_counts_dev: optional K int64 on device, hit count per PWM (the
+ *            histogram all-reduced across GPUs);
+ * n0:        global index of the first sequence minus one (records carry
+ *            n + n0, _h3_1_alignment.jl:83), so shards can be concatenated;
+ * batch:     sequences per ordering batch (MOTIFS_SCAN_BATCH for the
+ *            reference's order).
+ * `rc` != 0 scans with reverse(pwm) in both dims (:68-69); pass the forward
+ * bank, the library builds the reverse one. */
+int motifs_pwm_scan_hits_dev(motifs_ctx* ctx, const uint16_t* pwms_fp16, const int64_t* lens,
+                             int K, int maxlen, const uint8_t* codes_dev, int64_t N, int L, int rc,
+                             int64_t n0, int batch, motifs_hit* hits_dev, uint16_t* hit_scores_dev,
+                             int64_t cap, int64_t* n_out, int64_t* per_pwm_counts_dev);
+
+/* Host-buffer form of the same call: what Julia's `ccall` binds.  `data` is a
+ * host matrix of `kind`; hits / hit_scores / per_pwm_counts are host buffers.
+ * hits == NULL or cap too small: returns MOTIFS_ERR_BUFFER_TOO_SMALL (or
+ * MOTIFS_OK when hits == NULL && cap == 0) with *n_out = required count. */
+int motifs_pwm_scan(motifs_ctx* ctx, const uint16_t* pwms_fp16, const int64_t* lens, int K,
+                    int maxlen, const void* data, int kind, int64_t N, int L, int rc,
+                    motifs_hit* hits, uint16_t* hit_scores, int64_t cap, int64_t* n_out,
+                    int64_t* per_pwm_counts);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOTIFS_HIP_H */

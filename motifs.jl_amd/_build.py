@@ -1,0 +1,55 @@
+"""Build libmotifs_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "_obj")
+LIB = os.path.join(HERE, "libmotifs_hip.so")
+
+COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+# per-file extra flags
+EXTRA = {
+    # The scan kernel's 4-way scalar branch per base must survive code generation:
+    # LLVM structurizes even uniform control flow by default, which turns the
+    # rotating accumulators into a v_mov per add (2x the VALU work).
+    "scan_kernels.hip": ["-mllvm", "-structurizecfg-skip-uniform-regions"],
+}
+
+
+def _newer(src_paths, out):
+    if not os.path.exists(out):
+        return True
+    t = os.path.getmtime(out)
+    return any(os.path.getmtime(p) > t for p in src_paths)
+
+
+def build(verbose=True, force=False):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    os.makedirs(OBJ, exist_ok=True)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers.append(os.path.join(HERE, "..", "include", "motifs_hip.h"))
+    objs = []
+    for f in sorted(os.listdir(CSRC)):
+        if not f.endswith(".hip"):
+            continue
+        src = os.path.join(CSRC, f)
+        obj = os.path.join(OBJ, f[:-4] + ".o")
+        objs.append(obj)
+        if force or _newer([src] + headers, obj):
+            cmd = [hipcc] + COMMON + EXTRA.get(f, []) + ["-c", src, "-o", obj]
+            if verbose:
+                print("[build]", " ".join(cmd), file=sys.stderr, flush=True)
+            subprocess.check_call(cmd)
+    if force or _newer(objs, LIB):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print("[build]", " ".join(cmd), file=sys.stderr, flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

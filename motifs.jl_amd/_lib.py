@@ -1,0 +1,196 @@
+"""ctypes binding of include/motifs_hip.h.
+
+Loading is lazy so that CPU-only tests can import the package; any attempt to
+create a context without the shared library or without a gfx950 GPU raises —
+there is no CPU fallback behind this module.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmotifs_hip.so")
+
+OK, ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_BUFFER_TOO_SMALL, ERR_NOT_ONEHOT, ERR_NONFINITE, ERR_UNSUPPORTED = range(8)
+DATA_CODES_U8, DATA_ONEHOT_F32, DATA_ONEHOT_F16 = 0, 1, 2
+KS_ENCODE, KS_SCAN_DENSE, KS_SCAN_COUNT, KS_SCAN_OFFSETS, KS_SCAN_FILL = range(5)
+SCAN_BATCH = 5000
+SCAN_MAX_LEN = 32
+
+HIT_DTYPE = np.dtype([("m", "<u4"), ("n", "<u4"), ("l", "<u4")])
+
+
+class MotifsError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libmotifs_hip status {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+_p = C.c_void_p
+_i64 = C.c_int64
+_int = C.c_int
+
+# name -> (restype, argtypes); mirrors include/motifs_hip.h declaration by declaration
+SIGNATURES = {
+    "motifs_abi_version": (_int, []),
+    "motifs_last_error": (C.c_char_p, []),
+    "motifs_ctx_create": (_int, [_int, C.POINTER(_p)]),
+    "motifs_ctx_destroy": (None, [_p]),
+    "motifs_ctx_set_stream": (_int, [_p, _p]),
+    "motifs_ctx_synchronize": (_int, [_p]),
+    "motifs_ctx_enable_timing": (_int, [_p, _int]),
+    "motifs_ctx_reset_timing": (_int, [_p]),
+    "motifs_ctx_kernel_ms": (_int, [_p, _int, C.POINTER(C.c_double), C.POINTER(_i64)]),
+    "motifs_codes_bytes": (C.c_size_t, [_i64, _int]),
+    "motifs_codes_pitch": (_int, [_int]),
+    "motifs_encode_dev": (_int, [_p, _p, _int, _i64, _int, _p, _p]),
+    "motifs_pwm_scan_dense_dev": (_int, [_p, _p, _p, _int, _int, _p, _i64, _int, _p, _i64]),
+    "motifs_pwm_scan_hits_dev": (
+        _int,
+        [_p, _p, _p, _int, _int, _p, _i64, _int, _int, _i64, _int, _p, _p, _i64, C.POINTER(_i64), _p],
+    ),
+    "motifs_pwm_scan": (
+        _int,
+        [_p, _p, _p, _int, _int, _p, _int, _i64, _int, _int, _p, _p, _i64, C.POINTER(_i64), _p],
+    ),
+}
+
+
+def lib():
+    """The loaded shared library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MotifsError(
+                ERR_NO_DEVICE,
+                f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(there is no CPU fallback)",
+            )
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(code):
+    if code != OK:
+        raise MotifsError(code, lib().motifs_last_error().decode())
+
+
+def _np_ptr(a):
+    return a.ctypes.data_as(_p) if a is not None else None
+
+
+class Context:
+    """Owns a motifs_ctx (device, stream, workspaces)."""
+
+    def __init__(self, device=0, stream=None):
+        self._h = _p()
+        check(lib().motifs_ctx_create(int(device), C.byref(self._h)))
+        self.device = int(device)
+        if stream is not None:
+            self.set_stream(stream)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().motifs_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, hip_stream_ptr):
+        check(lib().motifs_ctx_set_stream(self._h, _p(hip_stream_ptr)))
+
+    def synchronize(self):
+        check(lib().motifs_ctx_synchronize(self._h))
+
+    def enable_timing(self, on=True):
+        check(lib().motifs_ctx_enable_timing(self._h, int(bool(on))))
+
+    def reset_timing(self):
+        check(lib().motifs_ctx_reset_timing(self._h))
+
+    def kernel_ms(self, slot):
+        ms, n = C.c_double(0), _i64(0)
+        check(lib().motifs_ctx_kernel_ms(self._h, int(slot), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    # ---- sequence encoding ----
+    @staticmethod
+    def codes_bytes(N, L):
+        return lib().motifs_codes_bytes(int(N), int(L))
+
+    @staticmethod
+    def codes_pitch(L):
+        return lib().motifs_codes_pitch(int(L))
+
+    def encode_dev(self, data_ptr, kind, N, L, codes_ptr, bad_flag_ptr=None):
+        check(lib().motifs_encode_dev(self._h, _p(data_ptr), int(kind), int(N), int(L), _p(codes_ptr), _p(bad_flag_ptr)))
+
+    # ---- scan ----
+    def pwm_scan_dense_dev(self, pwms, lens, codes_ptr, N, L, scores_ptr, ld_l):
+        pwms, lens, K, maxlen = _bank(pwms, lens)
+        check(
+            lib().motifs_pwm_scan_dense_dev(
+                self._h, _np_ptr(pwms), _np_ptr(lens), K, maxlen, _p(codes_ptr), int(N), int(L), _p(scores_ptr), int(ld_l)
+            )
+        )
+
+    def pwm_scan_hits_dev(self, pwms, lens, codes_ptr, N, L, rc, hits_ptr, scores_ptr, cap, n0=0, batch=SCAN_BATCH,
+                          counts_ptr=None, allow_small=False):
+        """Returns the total number of hits; raises on a too-small buffer unless allow_small."""
+        pwms, lens, K, maxlen = _bank(pwms, lens)
+        n_out = _i64(0)
+        code = lib().motifs_pwm_scan_hits_dev(
+            self._h, _np_ptr(pwms), _np_ptr(lens), K, maxlen, _p(codes_ptr), int(N), int(L), int(bool(rc)), int(n0),
+            int(batch), _p(hits_ptr), _p(scores_ptr), int(cap), C.byref(n_out), _p(counts_ptr),
+        )
+        if code == ERR_BUFFER_TOO_SMALL and allow_small:
+            return n_out.value
+        check(code)
+        return n_out.value
+
+    def pwm_scan(self, pwms, lens, data, kind, N, L, rc, cap=None, want_counts=False):
+        """Host-buffer scan (the entry Julia's ccall binds).  cap=None sizes the
+        buffers with a count-only first call."""
+        pwms, lens, K, maxlen = _bank(pwms, lens)
+        data = np.ascontiguousarray(data)
+        n_out = _i64(0)
+        counts = np.zeros(K, dtype=np.int64) if want_counts else None
+        if cap is None:
+            code = lib().motifs_pwm_scan(self._h, _np_ptr(pwms), _np_ptr(lens), K, maxlen, _np_ptr(data), int(kind),
+                                         int(N), int(L), int(bool(rc)), None, None, 0, C.byref(n_out), None)
+            check(code)
+            cap = n_out.value
+        hits = np.zeros(max(cap, 1), dtype=HIT_DTYPE)
+        scores = np.zeros(max(cap, 1), dtype=np.uint16)
+        code = lib().motifs_pwm_scan(self._h, _np_ptr(pwms), _np_ptr(lens), K, maxlen, _np_ptr(data), int(kind), int(N),
+                                     int(L), int(bool(rc)), _np_ptr(hits) if cap > 0 else None,
+                                     _np_ptr(scores) if cap > 0 else None, int(cap), C.byref(n_out), _np_ptr(counts))
+        check(code)
+        n = n_out.value
+        out = (hits[:n], scores[:n].view(np.float16))
+        return out + (counts,) if want_counts else out
+
+
+def _bank(pwms, lens):
+    """pwms: uint16/float16 array with Julia layout (K,4,maxlen) column-major,
+    i.e. numpy shape (maxlen, 4, K) C-order."""
+    pwms = np.ascontiguousarray(pwms)
+    if pwms.dtype == np.float16:
+        pwms = pwms.view(np.uint16)
+    assert pwms.dtype == np.uint16 and pwms.ndim == 3 and pwms.shape[1] == 4, pwms.shape
+    lens = np.ascontiguousarray(lens, dtype=np.int64)
+    maxlen, _, K = pwms.shape
+    assert lens.shape == (K,)
+    return pwms, lens, K, maxlen

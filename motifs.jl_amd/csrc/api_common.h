@@ -1,0 +1,124 @@
+// api_common.h — context object and error plumbing shared by the C-ABI files.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/motifs_hip.h"
+
+namespace motifs {
+
+void set_error(const char* fmt, ...);
+
+// A grow-only device buffer (never shrinks; freed with the context).
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) return e;
+        cap = want;
+        return hipSuccess;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+enum KernelSlot {
+    KS_ENCODE = 0,
+    KS_SCAN_DENSE = 1,
+    KS_SCAN_COUNT = 2,
+    KS_SCAN_OFFSETS = 3,
+    KS_SCAN_FILL = 4,
+    KS_COUNT_
+};
+
+}  // namespace motifs
+
+struct motifs_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    bool timing = false;
+    // timing: event pairs are recorded around launches without synchronising and
+    // resolved when the totals are read (motifs_ctx_kernel_ms)
+    struct TimedSpan {
+        int slot;
+        hipEvent_t e0, e1;
+    };
+    std::vector<TimedSpan> pending;
+    std::vector<hipEvent_t> free_events;
+    double kernel_ms[motifs::KS_COUNT_] = {0};
+    int64_t kernel_launches[motifs::KS_COUNT_] = {0};
+    // scan workspaces
+    motifs::DevBuf tab, lim, cnt, off, tilesum, small, codes, hits_tmp, scores_tmp, pwmcnt, data_tmp;
+    void* pinned = nullptr;  // small pinned host block for totals / flags
+};
+
+#define MOTIFS_HIP_CHECK(expr)                                                                   \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess) {                                                                  \
+            motifs::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return MOTIFS_ERR_HIP;                                                               \
+        }                                                                                        \
+    } while (0)
+
+namespace motifs {
+
+// RAII timer around a group of launches on the context stream.  Records two
+// events on the stream the kernels run on; nothing waits until the totals are read.
+struct KernelTimer {
+    motifs_ctx* c;
+    int slot;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    static hipEvent_t get(motifs_ctx* c) {
+        if (!c->free_events.empty()) {
+            hipEvent_t e = c->free_events.back();
+            c->free_events.pop_back();
+            return e;
+        }
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+    KernelTimer(motifs_ctx* ctx, int s) : c(ctx), slot(s) {
+        if (c->timing) {
+            e0 = get(c);
+            e1 = get(c);
+            (void)hipEventRecord(e0, c->stream);
+        }
+    }
+    ~KernelTimer() {
+        if (c->timing && e0 && e1) {
+            (void)hipEventRecord(e1, c->stream);
+            c->pending.push_back({slot, e0, e1});
+        }
+    }
+};
+
+inline void resolve_timing(motifs_ctx* c) {
+    for (auto& sp : c->pending) {
+        (void)hipEventSynchronize(sp.e1);
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, sp.e0, sp.e1) == hipSuccess) {
+            c->kernel_ms[sp.slot] += ms;
+            c->kernel_launches[sp.slot] += 1;
+        }
+        c->free_events.push_back(sp.e0);
+        c->free_events.push_back(sp.e1);
+    }
+    c->pending.clear();
+}
+
+}  // namespace motifs

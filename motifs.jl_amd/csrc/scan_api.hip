@@ -1,0 +1,439 @@
+// scan_api.hip — C-ABI entry points of the PWM scan (include/motifs_hip.h).
+//
+// Host side of what `get_pos_scores_arr` does around the kernel
+// (src/inference/_h3_1_alignment.jl:57-87): build the (optionally reversed)
+// padded PWM bank (:66-69), walk the sequences, collect `(m, n, l)` records and
+// fp16 scores (:82-84).  Everything numeric runs on the device; there is no CPU
+// fallback (a missing GPU is MOTIFS_ERR_NO_DEVICE).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "api_common.h"
+#include "scan_kernels.h"
+
+namespace motifs {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+struct PackedBank {
+    std::vector<uint32_t> tab;
+    std::vector<int32_t> lim;
+    int KP = 0, nch = 0, lenp = 0, minlen = 0, maxlen_true = 0;
+};
+
+// Build the lane-major packed bank.  `rc` applies reverse(pwm) in both dims per
+// motif (_h3_1_alignment.jl:68) before the zero padding of :66.
+static int pack_bank(const uint16_t* pwms, const int64_t* lens, int K, int maxlen, int rc, int L, PackedBank& out) {
+    if (!pwms || !lens || K <= 0 || maxlen <= 0) {
+        set_error("pwm bank: null pointer or K/maxlen <= 0 (K=%d maxlen=%d)", K, maxlen);
+        return MOTIFS_ERR_INVALID;
+    }
+    if (maxlen > MOTIFS_SCAN_MAX_LEN) {
+        set_error("pwm bank: maxlen %d > MOTIFS_SCAN_MAX_LEN %d", maxlen, MOTIFS_SCAN_MAX_LEN);
+        return MOTIFS_ERR_UNSUPPORTED;
+    }
+    int minlen = maxlen, maxtrue = 0;
+    for (int k = 0; k < K; k++) {
+        if (lens[k] < 1 || lens[k] > maxlen) {
+            set_error("pwm bank: lens[%d] = %lld outside 1..maxlen=%d", k, (long long)lens[k], maxlen);
+            return MOTIFS_ERR_INVALID;
+        }
+        minlen = std::min<int>(minlen, (int)lens[k]);
+        maxtrue = std::max<int>(maxtrue, (int)lens[k]);
+    }
+    out.lenp = scan_len_padded(maxtrue);
+    out.minlen = minlen;
+    out.maxlen_true = maxtrue;
+    const int pairs = (K + 1) / 2;
+    out.nch = (pairs + 63) / 64;
+    out.KP = out.nch * 64;
+    out.tab.assign((size_t)out.lenp * 4 * out.KP, 0u);
+    out.lim.assign((size_t)2 * out.KP, -1);
+    for (int k = 0; k < K; k++) {
+        const int len = (int)lens[k];
+        const int kp = k >> 1, hi = k & 1;
+        out.lim[k] = L - len;  // < 0: no valid start; the kernel compares l <= lim
+        for (int ind = 0; ind < len; ind++)
+            for (int b = 0; b < 4; b++) {
+                const int sb = rc ? 3 - b : b, si = rc ? len - 1 - ind : ind;
+                const uint16_t w = pwms[k + (size_t)K * (sb + 4 * si)];
+                if ((w & 0x7c00u) == 0x7c00u) {
+                    set_error("pwm bank: entry (k=%d, a=%d, ind=%d) is Inf/NaN", k + 1, sb + 1, si + 1);
+                    return MOTIFS_ERR_NONFINITE;
+                }
+                uint32_t& cell = out.tab[(size_t)(ind * 4 + b) * out.KP + kp];
+                cell |= hi ? (uint32_t)w << 16 : (uint32_t)w;
+            }
+    }
+    return MOTIFS_OK;
+}
+
+static int pick_spw(int64_t N, int nch) {
+    const int64_t items = N * nch;
+    int64_t spw = items / 16384;  // aim for >= 16k waves in flight over the launch
+    if (spw < 1) spw = 1;
+    if (spw > 16) spw = 16;
+    return (int)spw;
+}
+
+static int upload_bank(motifs_ctx* c, const PackedBank& bank) {
+    MOTIFS_HIP_CHECK(c->tab.reserve(bank.tab.size() * 4));
+    MOTIFS_HIP_CHECK(c->lim.reserve(bank.lim.size() * 4));
+    MOTIFS_HIP_CHECK(hipMemcpyAsync(c->tab.p, bank.tab.data(), bank.tab.size() * 4, hipMemcpyHostToDevice, c->stream));
+    MOTIFS_HIP_CHECK(hipMemcpyAsync(c->lim.p, bank.lim.data(), bank.lim.size() * 4, hipMemcpyHostToDevice, c->stream));
+    // the vectors die with the caller's frame: make sure the copies are done
+    MOTIFS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return MOTIFS_OK;
+}
+
+}  // namespace motifs
+
+using namespace motifs;
+
+extern "C" {
+
+int motifs_abi_version(void) { return MOTIFS_ABI_VERSION; }
+const char* motifs_last_error(void) { return motifs::g_err; }
+
+int motifs_ctx_create(int device, motifs_ctx** out) {
+    if (!out) {
+        set_error("motifs_ctx_create: out is NULL");
+        return MOTIFS_ERR_INVALID;
+    }
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        set_error("no HIP device visible (%s); libmotifs_hip has no CPU fallback",
+                  e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+        return MOTIFS_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= ndev) {
+        set_error("device %d out of range (0..%d)", device, ndev - 1);
+        return MOTIFS_ERR_INVALID;
+    }
+    MOTIFS_HIP_CHECK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    MOTIFS_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error("device %d is %s; this library carries gfx950 code only", device, prop.gcnArchName);
+        return MOTIFS_ERR_NO_DEVICE;
+    }
+    motifs_ctx* c = new motifs_ctx();
+    c->device = device;
+    MOTIFS_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->own_stream = true;
+    MOTIFS_HIP_CHECK(hipHostMalloc(&c->pinned, 256, hipHostMallocDefault));
+    *out = c;
+    return MOTIFS_OK;
+}
+
+void motifs_ctx_destroy(motifs_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (DevBuf* b : {&c->tab, &c->lim, &c->cnt, &c->off, &c->tilesum, &c->small, &c->codes, &c->hits_tmp,
+                      &c->scores_tmp, &c->pwmcnt, &c->data_tmp})
+        b->release();
+    if (c->pinned) (void)hipHostFree(c->pinned);
+    resolve_timing(c);
+    for (hipEvent_t e : c->free_events) (void)hipEventDestroy(e);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int motifs_ctx_set_stream(motifs_ctx* c, void* hip_stream) {
+    if (!c) return MOTIFS_ERR_INVALID;
+    MOTIFS_HIP_CHECK(hipSetDevice(c->device));
+    MOTIFS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    if (hip_stream) {
+        c->stream = (hipStream_t)hip_stream;
+        c->own_stream = false;
+    } else {
+        MOTIFS_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->own_stream = true;
+    }
+    return MOTIFS_OK;
+}
+
+int motifs_ctx_synchronize(motifs_ctx* c) {
+    if (!c) return MOTIFS_ERR_INVALID;
+    MOTIFS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return MOTIFS_OK;
+}
+
+int motifs_ctx_enable_timing(motifs_ctx* c, int on) {
+    if (!c) return MOTIFS_ERR_INVALID;
+    c->timing = on != 0;
+    return MOTIFS_OK;
+}
+
+int motifs_ctx_reset_timing(motifs_ctx* c) {
+    if (!c) return MOTIFS_ERR_INVALID;
+    resolve_timing(c);
+    for (int i = 0; i < KS_COUNT_; i++) {
+        c->kernel_ms[i] = 0;
+        c->kernel_launches[i] = 0;
+    }
+    return MOTIFS_OK;
+}
+
+int motifs_ctx_kernel_ms(motifs_ctx* c, int slot, double* ms, int64_t* launches) {
+    if (!c || slot < 0 || slot >= KS_COUNT_) {
+        set_error("motifs_ctx_kernel_ms: bad slot %d", slot);
+        return MOTIFS_ERR_INVALID;
+    }
+    resolve_timing(c);
+    if (ms) *ms = c->kernel_ms[slot];
+    if (launches) *launches = c->kernel_launches[slot];
+    return MOTIFS_OK;
+}
+
+int motifs_codes_pitch(int L) { return (L + 3) & ~3; }
+size_t motifs_codes_bytes(int64_t N, int L) { return (size_t)N * motifs_codes_pitch(L) + 2 * MOTIFS_SCAN_MAX_LEN + 64; }
+
+int motifs_encode_dev(motifs_ctx* c, const void* data_dev, int kind, int64_t N, int L, uint8_t* codes_dev,
+                      int32_t* bad_flag_dev) {
+    if (!c || (N > 0 && (!data_dev || !codes_dev)) || N < 0 || L <= 0 || kind < 0 || kind > 2) {
+        set_error("motifs_encode_dev: bad argument (N=%lld L=%d kind=%d)", (long long)N, L, kind);
+        return MOTIFS_ERR_INVALID;
+    }
+    MOTIFS_HIP_CHECK(hipSetDevice(c->device));
+    KernelTimer t(c, KS_ENCODE);
+    MOTIFS_HIP_CHECK(launch_encode(kind, data_dev, N, L, motifs_codes_pitch(L), codes_dev, bad_flag_dev, c->stream));
+    return MOTIFS_OK;
+}
+
+int motifs_pwm_scan_dense_dev(motifs_ctx* c, const uint16_t* pwms_fp16, const int64_t* lens, int K, int maxlen,
+                              const uint8_t* codes_dev, int64_t N, int L, uint16_t* scores_dev, int64_t ld_l) {
+    if (!c || N < 0 || L <= 0 || (N > 0 && (!codes_dev || !scores_dev))) {
+        set_error("motifs_pwm_scan_dense_dev: bad argument");
+        return MOTIFS_ERR_INVALID;
+    }
+    PackedBank bank;
+    int rcode = pack_bank(pwms_fp16, lens, K, maxlen, 0, L, bank);
+    if (rcode) return rcode;
+    const int Lout = L - bank.minlen + 1;
+    if (ld_l < std::max(Lout, 0)) {
+        set_error("motifs_pwm_scan_dense_dev: ld_l=%lld < L-minlen+1=%d", (long long)ld_l, Lout);
+        return MOTIFS_ERR_INVALID;
+    }
+    if (N == 0) return MOTIFS_OK;
+    MOTIFS_HIP_CHECK(hipSetDevice(c->device));
+    rcode = upload_bank(c, bank);
+    if (rcode) return rcode;
+    const int lo = std::max(Lout, 0);
+    if (ld_l > lo)  // the l-planes no window reaches (the reference pre-zeroes the tensor, :75)
+        MOTIFS_HIP_CHECK(hipMemsetAsync(scores_dev + (size_t)K * N * lo, 0, (size_t)K * N * (ld_l - lo) * 2, c->stream));
+    if (Lout <= 0) return MOTIFS_OK;
+    ScanArgs a{};
+    a.tab = (const uint32_t*)c->tab.p;
+    a.lim = (const int32_t*)c->lim.p;
+    a.codes = codes_dev;
+    a.d.N = N;
+    a.d.L = L;
+    a.d.pitch = motifs_codes_pitch(L);
+    a.d.K = K;
+    a.d.KP = bank.KP;
+    a.d.nch = bank.nch;
+    a.d.Lout = Lout;
+    a.d.LoutP = (Lout + 63) & ~63;
+    a.d.lim_min = L - bank.maxlen_true;
+    a.d.spw = pick_spw(N, bank.nch);
+    a.d.k_even = (K % 2 == 0);
+    a.d.batch = MOTIFS_SCAN_BATCH;
+    a.scores = scores_dev;
+    KernelTimer t(c, KS_SCAN_DENSE);
+    MOTIFS_HIP_CHECK(launch_scan(MODE_DENSE, bank.lenp, a, c->stream));
+    return MOTIFS_OK;
+}
+
+int motifs_pwm_scan_hits_dev(motifs_ctx* c, const uint16_t* pwms_fp16, const int64_t* lens, int K, int maxlen,
+                             const uint8_t* codes_dev, int64_t N, int L, int rc, int64_t n0, int batch,
+                             motifs_hit* hits_dev, uint16_t* hit_scores_dev, int64_t cap, int64_t* n_out,
+                             int64_t* per_pwm_counts_dev) {
+    if (!c || !n_out || N < 0 || L <= 0 || batch <= 0 || cap < 0 || (N > 0 && !codes_dev) ||
+        (cap > 0 && (!hits_dev || !hit_scores_dev)) || n0 < 0 || n0 + N > 0xffffffffll) {
+        set_error("motifs_pwm_scan_hits_dev: bad argument (N=%lld L=%d batch=%d cap=%lld n0=%lld)", (long long)N, L,
+                  batch, (long long)cap, (long long)n0);
+        return MOTIFS_ERR_INVALID;
+    }
+    *n_out = 0;
+    PackedBank bank;
+    int rcode = pack_bank(pwms_fp16, lens, K, maxlen, rc, L, bank);
+    if (rcode) return rcode;
+    MOTIFS_HIP_CHECK(hipSetDevice(c->device));
+    if (per_pwm_counts_dev) MOTIFS_HIP_CHECK(hipMemsetAsync(per_pwm_counts_dev, 0, (size_t)K * 8, c->stream));
+    const int Lout = L - bank.minlen + 1;
+    if (N == 0 || Lout <= 0) return MOTIFS_OK;
+    rcode = upload_bank(c, bank);
+    if (rcode) return rcode;
+
+    const int LoutP = (Lout + 63) & ~63;
+    // super-batch: as many ordering batches as fit a ~6 GiB count/offset workspace
+    const size_t per_seq = (size_t)bank.nch * LoutP * 6;
+    int64_t sb = (int64_t)((6ull << 30) / per_seq);
+    sb = std::max<int64_t>(batch, sb / batch * batch);
+    sb = std::min<int64_t>(sb, (N + batch - 1) / batch * batch);
+    const int tiles = (batch + OFFS_TILE - 1) / OFFS_TILE;
+    const int nbatch_max = (int)(sb / batch);
+
+    MOTIFS_HIP_CHECK(c->cnt.reserve((size_t)sb * bank.nch * LoutP * 2));
+    MOTIFS_HIP_CHECK(c->off.reserve((size_t)sb * bank.nch * LoutP * 4));
+    MOTIFS_HIP_CHECK(c->tilesum.reserve((size_t)nbatch_max * Lout * tiles * 4));
+    MOTIFS_HIP_CHECK(c->small.reserve((size_t)nbatch_max * 8 + 64));
+    MOTIFS_HIP_CHECK(c->pwmcnt.reserve((size_t)2 * bank.KP * 8));
+    if (per_pwm_counts_dev) MOTIFS_HIP_CHECK(hipMemsetAsync(c->pwmcnt.p, 0, (size_t)2 * bank.KP * 8, c->stream));
+
+    int64_t* batch_base = (int64_t*)c->small.p;
+    int64_t* total_dev = batch_base + nbatch_max;
+    int32_t* overflow_dev = (int32_t*)(total_dev + 1);
+    int64_t* h_total = (int64_t*)c->pinned;
+    int32_t* h_overflow = (int32_t*)(h_total + 1);
+
+    int64_t emitted = 0;
+    bool too_small = false;
+    for (int64_t s0 = 0; s0 < N; s0 += sb) {
+        const int64_t ns = std::min<int64_t>(sb, N - s0);
+        ScanArgs a{};
+        a.tab = (const uint32_t*)c->tab.p;
+        a.lim = (const int32_t*)c->lim.p;
+        a.codes = codes_dev + (size_t)s0 * motifs_codes_pitch(L);
+        a.d.N = ns;
+        a.d.L = L;
+        a.d.pitch = motifs_codes_pitch(L);
+        a.d.K = K;
+        a.d.KP = bank.KP;
+        a.d.nch = bank.nch;
+        a.d.Lout = Lout;
+        a.d.LoutP = LoutP;
+        a.d.lim_min = L - bank.maxlen_true;
+        a.d.spw = pick_spw(ns, bank.nch);
+        a.d.k_even = (K % 2 == 0);
+        a.d.batch = batch;
+        a.d.n0 = n0 + s0;
+        a.cnt = (uint16_t*)c->cnt.p;
+        a.off = (const uint32_t*)c->off.p;
+        a.batch_base = batch_base;
+        a.hits = (HitRec*)hits_dev;
+        a.hit_scores = hit_scores_dev;
+        a.pwm_counts = per_pwm_counts_dev ? (int64_t*)c->pwmcnt.p : nullptr;
+        {
+            KernelTimer t(c, KS_SCAN_COUNT);
+            MOTIFS_HIP_CHECK(launch_scan(MODE_COUNT, bank.lenp, a, c->stream));
+        }
+        OffsArgs o{};
+        o.cnt = a.cnt;
+        o.off = (uint32_t*)c->off.p;
+        o.tilesum = (uint32_t*)c->tilesum.p;
+        o.batch_base = batch_base;
+        o.total = total_dev;
+        o.overflow = overflow_dev;
+        o.N = ns;
+        o.base0 = emitted;
+        o.Lout = Lout;
+        o.LoutP = LoutP;
+        o.nch = bank.nch;
+        o.batch = batch;
+        o.tiles = tiles;
+        o.nbatch = (int)((ns + batch - 1) / batch);
+        MOTIFS_HIP_CHECK(hipMemsetAsync(overflow_dev, 0, 4, c->stream));
+        {
+            KernelTimer t(c, KS_SCAN_OFFSETS);
+            MOTIFS_HIP_CHECK(launch_offsets(o, c->stream));
+        }
+        MOTIFS_HIP_CHECK(hipMemcpyAsync(h_total, total_dev, 12, hipMemcpyDeviceToHost, c->stream));
+        MOTIFS_HIP_CHECK(hipStreamSynchronize(c->stream));
+        if (*h_overflow) {
+            set_error("more than 2^32 hits inside one %d-sequence batch", batch);
+            return MOTIFS_ERR_UNSUPPORTED;
+        }
+        const int64_t sb_total = *h_total;
+        if (emitted + sb_total > cap) too_small = true;
+        if (!too_small && sb_total > 0) {
+            KernelTimer t(c, KS_SCAN_FILL);
+            MOTIFS_HIP_CHECK(launch_scan(MODE_FILL, bank.lenp, a, c->stream));
+        }
+        emitted += sb_total;
+    }
+    *n_out = emitted;
+    if (per_pwm_counts_dev)
+        MOTIFS_HIP_CHECK(hipMemcpyAsync(per_pwm_counts_dev, c->pwmcnt.p, (size_t)K * 8, hipMemcpyDeviceToDevice, c->stream));
+    if (too_small && !(cap == 0 && hits_dev == nullptr)) {
+        set_error("hit buffer too small: need %lld records, cap %lld", (long long)emitted, (long long)cap);
+        return MOTIFS_ERR_BUFFER_TOO_SMALL;
+    }
+    return MOTIFS_OK;
+}
+
+int motifs_pwm_scan(motifs_ctx* c, const uint16_t* pwms_fp16, const int64_t* lens, int K, int maxlen, const void* data,
+                    int kind, int64_t N, int L, int rc, motifs_hit* hits, uint16_t* hit_scores, int64_t cap,
+                    int64_t* n_out, int64_t* per_pwm_counts) {
+    if (!c || !n_out || N < 0 || L <= 0 || kind < 0 || kind > 2 || (N > 0 && !data) || cap < 0 ||
+        (cap > 0 && (!hits || !hit_scores))) {
+        set_error("motifs_pwm_scan: bad argument");
+        return MOTIFS_ERR_INVALID;
+    }
+    MOTIFS_HIP_CHECK(hipSetDevice(c->device));
+    const size_t elt = kind == MOTIFS_DATA_ONEHOT_F32 ? 16 : kind == MOTIFS_DATA_ONEHOT_F16 ? 8 : 1;
+    MOTIFS_HIP_CHECK(c->codes.reserve(motifs_codes_bytes(N, L)));
+    int32_t* bad_dev = nullptr;
+    MOTIFS_HIP_CHECK(c->small.reserve(4096));
+    // encode in slabs so the staging buffer stays bounded (<= 1 GiB)
+    const int64_t slab = std::max<int64_t>(1, (int64_t)((1ull << 30) / ((size_t)L * elt)));
+    MOTIFS_HIP_CHECK(c->data_tmp.reserve((size_t)std::min<int64_t>(slab, std::max<int64_t>(N, 1)) * L * elt + 64));
+    bad_dev = (int32_t*)((char*)c->small.p + 2048);
+    MOTIFS_HIP_CHECK(hipMemsetAsync(bad_dev, 0, 4, c->stream));
+    const int pitch = motifs_codes_pitch(L);
+    for (int64_t s0 = 0; s0 < N; s0 += slab) {
+        const int64_t ns = std::min<int64_t>(slab, N - s0);
+        MOTIFS_HIP_CHECK(hipMemcpyAsync(c->data_tmp.p, (const char*)data + (size_t)s0 * L * elt, (size_t)ns * L * elt,
+                                        hipMemcpyHostToDevice, c->stream));
+        int r = motifs_encode_dev(c, c->data_tmp.p, kind, ns, L, (uint8_t*)c->codes.p + (size_t)s0 * pitch, bad_dev);
+        if (r) return r;
+        MOTIFS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    }
+    int32_t* h_bad = (int32_t*)((char*)c->pinned + 64);
+    MOTIFS_HIP_CHECK(hipMemcpyAsync(h_bad, bad_dev, 4, hipMemcpyDeviceToHost, c->stream));
+    MOTIFS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (*h_bad) {
+        set_error("data matrix has a column that is neither one-hot nor all-zero");
+        return MOTIFS_ERR_NOT_ONEHOT;
+    }
+    if (cap > 0) {
+        MOTIFS_HIP_CHECK(c->hits_tmp.reserve((size_t)cap * sizeof(motifs_hit)));
+        MOTIFS_HIP_CHECK(c->scores_tmp.reserve((size_t)cap * 2));
+    }
+    int64_t* counts_dev = nullptr;
+    if (per_pwm_counts) {
+        // second half of `small` is free above the batch table only for small nbatch; use a dedicated block
+        MOTIFS_HIP_CHECK(c->data_tmp.reserve((size_t)K * 8));
+        counts_dev = (int64_t*)c->data_tmp.p;
+    }
+    int r = motifs_pwm_scan_hits_dev(c, pwms_fp16, lens, K, maxlen, (const uint8_t*)c->codes.p, N, L, rc, 0,
+                                     MOTIFS_SCAN_BATCH, cap > 0 ? (motifs_hit*)c->hits_tmp.p : nullptr,
+                                     cap > 0 ? (uint16_t*)c->scores_tmp.p : nullptr, cap, n_out, counts_dev);
+    if (per_pwm_counts && (r == MOTIFS_OK || r == MOTIFS_ERR_BUFFER_TOO_SMALL))
+        MOTIFS_HIP_CHECK(hipMemcpyAsync(per_pwm_counts, counts_dev, (size_t)K * 8, hipMemcpyDeviceToHost, c->stream));
+    if (r == MOTIFS_OK && cap > 0 && *n_out > 0) {
+        MOTIFS_HIP_CHECK(hipMemcpyAsync(hits, c->hits_tmp.p, (size_t)*n_out * sizeof(motifs_hit), hipMemcpyDeviceToHost, c->stream));
+        MOTIFS_HIP_CHECK(hipMemcpyAsync(hit_scores, c->scores_tmp.p, (size_t)*n_out * 2, hipMemcpyDeviceToHost, c->stream));
+    }
+    MOTIFS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return r;
+}
+
+}  // extern "C"

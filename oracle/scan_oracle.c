@@ -1,0 +1,227 @@
+/*
+ * scan_oracle.c — CPU restatement of MOTIFs.jl's PWM log-odds scan.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product:
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * build, load or call it, and only as the checker.
+ *
+ * PARITY UNPINNED: the reference ships no tests, fixtures or golden vectors
+ * (test/runtests.jl:4-6 is an empty testset) and Julia is not installed in
+ * the build container, so this restatement could not be checked against the
+ * reference's own outputs.  It is pinned instead by hand-computed known-answer
+ * cases and identities (tests/test_oracle_scan.py).
+ *
+ * What it restates (paths relative to the reference checkout):
+ *   src/inference/_h3_1_alignment.jl:18-36   greedy_search!   -> oracle_greedy_search
+ *   src/inference/_h3_1_alignment.jl:57-87   get_pos_scores_arr -> oracle_get_pos_scores_arr
+ *   src/inference/_0_const.jl:1              float_type_retrieval = Float16
+ *
+ * Arithmetic: IEEE binary16 with round-to-nearest-even after EVERY multiply
+ * and EVERY add, accumulated in the output array exactly as the reference
+ * kernel does (`pos_scores[k,n,l] += pwms[k,a,ind]*data[(i-1)*4+a,n]`, :29).
+ * Products and sums of two binary16 values are formed in binary32 (both are
+ * exact or differ from the exact result by less than a quarter binary16 ulp in
+ * binary32, so the single rounding to binary16 that follows is the correctly
+ * rounded binary16 result) and rounded back with f32_to_f16 below.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+static inline float f16_to_f32(uint16_t h) {
+    uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    uint32_t exp = (h >> 10) & 0x1fu;
+    uint32_t man = h & 0x3ffu;
+    uint32_t bits;
+    if (exp == 0) {
+        if (man == 0) {
+            bits = sign;
+        } else { /* subnormal: normalise */
+            int e = -1;
+            do {
+                e++;
+                man <<= 1;
+            } while (!(man & 0x400u));
+            bits = sign | (uint32_t)(127 - 15 - e) << 23 | (man & 0x3ffu) << 13;
+        }
+    } else if (exp == 31) {
+        bits = sign | 0x7f800000u | man << 13;
+    } else {
+        bits = sign | (exp + 127 - 15) << 23 | man << 13;
+    }
+    float f;
+    memcpy(&f, &bits, 4);
+    return f;
+}
+
+/* binary32 -> binary16, round to nearest even, IEEE overflow to inf. */
+static inline uint16_t f32_to_f16(float f) {
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    uint16_t sign = (uint16_t)((x >> 16) & 0x8000u);
+    uint32_t ax = x & 0x7fffffffu;
+    if (ax >= 0x7f800000u) { /* inf / nan */
+        return (uint16_t)(sign | 0x7c00u | (ax > 0x7f800000u ? 0x200u | ((ax >> 13) & 0x3ffu) : 0));
+    }
+    if (ax >= 0x477ff000u) { /* >= 65520 rounds to inf */
+        return (uint16_t)(sign | 0x7c00u);
+    }
+    if (ax < 0x38800000u) { /* below smallest normal half: subnormal or zero */
+        if (ax < 0x33000000u) return sign; /* < 2^-25 rounds to zero (2^-25 itself ties to even = 0) */
+        uint32_t e = ax >> 23;             /* biased exponent, 102..112 */
+        uint32_t man = (ax & 0x7fffffu) | 0x800000u;
+        uint32_t shift = 126 - e;          /* 14..24 */
+        uint32_t q = man >> shift;
+        uint32_t rem = man & ((1u << shift) - 1u);
+        uint32_t half = 1u << (shift - 1);
+        if (rem > half || (rem == half && (q & 1u))) q++;
+        return (uint16_t)(sign | q);
+    }
+    uint32_t e = (ax >> 23) - 112; /* 1..30 */
+    uint32_t man = ax & 0x7fffffu;
+    uint32_t q = (e << 10) | (man >> 13);
+    uint32_t rem = man & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (q & 1u))) q++; /* may carry into exponent: correct */
+    return (uint16_t)(sign | q);
+}
+
+static inline uint16_t h_mul(uint16_t a, uint16_t b) { return f32_to_f16(f16_to_f32(a) * f16_to_f32(b)); }
+static inline uint16_t h_add(uint16_t a, uint16_t b) { return f32_to_f16(f16_to_f32(a) + f16_to_f32(b)); }
+
+uint16_t oracle_f32_to_f16(float f) { return f32_to_f16(f); }
+float oracle_f16_to_f32(uint16_t h) { return f16_to_f32(h); }
+uint16_t oracle_h_add(uint16_t a, uint16_t b) { return h_add(a, b); }
+
+/*
+ * greedy_search!  (_h3_1_alignment.jl:18-36), one CPU loop iteration per GPU thread.
+ *   pwms       (K,4,maxlen) col-major fp16            — `pwms[k,a,ind]`
+ *   data       (L4, N) col-major fp16 one-hot         — `data_dat_gpu[(i-1)*4+a, n]`
+ *   lens       (K) Int64
+ *   pos_scores (K, N, L4) col-major fp16, PRE-ZEROED by the caller (:75)
+ * Indices k,n,l,ind,a below are the reference's 1-based ones.
+ */
+void oracle_greedy_search(const uint16_t* pwms, const uint16_t* data, const int64_t* lens, int K,
+                          int maxlen, int64_t N, int L4, uint16_t* pos_scores) {
+    (void)maxlen;
+    const int L_div_4 = L4 / 4;
+#pragma omp parallel for schedule(static)
+    for (int64_t n = 1; n <= N; n++) {
+        for (int l = 1; l <= L4; l++) { /* grid covers the whole third dim (:76, _0_const.jl:41) */
+            for (int k = 1; k <= K; k++) {
+                if (!(l <= L_div_4 - lens[k - 1] + 1)) continue; /* :25 */
+                uint16_t* out = &pos_scores[(k - 1) + (int64_t)K * ((n - 1) + N * (int64_t)(l - 1))];
+                int ind = 0;
+                for (int i = l; i <= l + lens[k - 1] - 1; i++) { /* :26 enumerate(l:l+lens[k]-1) */
+                    ind++;
+                    for (int a = 1; a <= 4; a++) { /* :28 */
+                        uint16_t w = pwms[(k - 1) + K * ((a - 1) + 4 * (ind - 1))];
+                        uint16_t d = data[((i - 1) * 4 + a - 1) + (int64_t)L4 * (n - 1)];
+                        *out = h_add(*out, h_mul(w, d)); /* :29 */
+                    }
+                }
+                /* :33  pos_scores > 0f0 ? pos_scores : 0f0  (NaN -> 0) */
+                *out = (f16_to_f32(*out) > 0.0f) ? *out : (uint16_t)0;
+            }
+        }
+    }
+}
+
+typedef struct {
+    uint32_t m, n, l;
+} oracle_hit;
+
+/*
+ * get_pos_scores_arr (_h3_1_alignment.jl:57-87) for one strand.
+ *   pwms_in  (K,4,maxlen) col-major fp16 = the forward bank built at :66-69 with rc=false
+ *            (zero-padded `ms.pwms[i]`); with rc != 0 this routine applies
+ *            `reverse(ms.pwms[i])` (both dims) per motif before padding, as :68 does.
+ *   data_f32 (L4, N) col-major Float32 one-hot = data.data_matrix[:,1,:]
+ * Output records in the reference's order: batches of 5000 sequences (:71), inside a batch
+ * `findall(pos_scores_arr .> 0)` (:82) walks the (K, nb, L4) array column-major.
+ * Returns the number of hits; writes at most `cap` of them.
+ */
+int64_t oracle_get_pos_scores_arr(const uint16_t* pwms_in, const int64_t* lens, int K, int maxlen,
+                                  const float* data_f32, int64_t N, int L4, int rc, int batch_size,
+                                  oracle_hit* found, uint16_t* score_record, int64_t cap) {
+    uint16_t* pwms = (uint16_t*)calloc((size_t)K * 4 * maxlen, 2);
+    for (int k = 0; k < K; k++) {
+        int len = (int)lens[k];
+        for (int ind = 0; ind < len; ind++)
+            for (int a = 0; a < 4; a++) {
+                /* reverse(pwm): element (a, ind) <- (4-1-a, len-1-ind) */
+                int sa = rc ? 3 - a : a, si = rc ? len - 1 - ind : ind;
+                pwms[k + K * (a + 4 * ind)] = pwms_in[k + K * (sa + 4 * si)];
+            }
+    }
+    int64_t nfound = 0;
+    for (int64_t n0 = 1; n0 <= N; n0 += batch_size) { /* :71 */
+        int64_t nend = n0 + batch_size - 1 < N ? n0 + batch_size - 1 : N;
+        int64_t nb = nend - n0 + 1;
+        /* :74 float_type_retrieval.(data_matrix[:,1,n:nend]) */
+        uint16_t* data16 = (uint16_t*)malloc((size_t)L4 * nb * 2);
+        for (int64_t i = 0; i < (int64_t)L4 * nb; i++)
+            data16[i] = f32_to_f16(data_f32[(int64_t)L4 * (n0 - 1) + i]);
+        uint16_t* pos_scores = (uint16_t*)calloc((size_t)K * nb * L4, 2); /* :75 */
+        oracle_greedy_search(pwms, data16, lens, K, maxlen, nb, L4, pos_scores);
+        /* :82-84 findall(.> 0) in column-major order; n -> n + n0 - 1 */
+        for (int l = 1; l <= L4; l++)
+            for (int64_t n = 1; n <= nb; n++)
+                for (int k = 1; k <= K; k++) {
+                    uint16_t s = pos_scores[(k - 1) + (int64_t)K * ((n - 1) + nb * (int64_t)(l - 1))];
+                    if (f16_to_f32(s) > 0.0f) {
+                        if (nfound < cap) {
+                            found[nfound].m = (uint32_t)k;
+                            found[nfound].n = (uint32_t)(n + n0 - 1);
+                            found[nfound].l = (uint32_t)l;
+                            score_record[nfound] = s;
+                        }
+                        nfound++;
+                    }
+                }
+        free(pos_scores);
+        free(data16);
+    }
+    free(pwms);
+    return nfound;
+}
+
+/*
+ * Same function as oracle_greedy_search computed the cheap way (gather of the
+ * one selected weight per position, no dense L4 third dimension): used as the
+ * "optimised CPU" leg of bench.py's cpu_baseline and to cross-check the literal
+ * loop.  codes: (N rows of L bytes) 0..3, 4 = all-zero column.
+ * scores: (K, N, Lout) col-major, Lout = L - minlen + 1.
+ */
+void oracle_scan_gather(const uint16_t* pwms, const int64_t* lens, int K, const uint8_t* codes,
+                        int64_t N, int L, int Lout, uint16_t* scores) {
+#pragma omp parallel for schedule(static)
+    for (int64_t n = 0; n < N; n++) {
+        const uint8_t* s = codes + n * L;
+        for (int l = 0; l < Lout; l++)
+            for (int k = 0; k < K; k++) {
+                int len = (int)lens[k];
+                uint16_t acc = 0;
+                if (l <= L - len) {
+                    for (int ind = 0; ind < len; ind++) {
+                        int b = s[l + ind];
+                        if (b < 4) acc = h_add(acc, pwms[k + K * (b + 4 * ind)]);
+                    }
+                    if (!(f16_to_f32(acc) > 0.0f)) acc = 0;
+                }
+                scores[k + (int64_t)K * (n + N * (int64_t)l)] = acc;
+            }
+    }
+}
+
+int oracle_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

@@ -1,0 +1,212 @@
+"""Parity tests proper: the HIP scan, called through the C ABI, against the CPU oracle.
+Integer hit records and fp16 scores must be bit-exact (BASELINE.json north_star)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import scan_oracle as so
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    return torch
+
+
+def dev_scan_hits(torch, ctx, pkg, bank, lens, codes, rc, batch, n0=0, want_counts=False):
+    """Device-resident path: encode -> count -> offsets -> fill."""
+    L = codes.shape[1]
+    N = codes.shape[0]
+    lib = pkg._lib
+    raw = torch.from_numpy(np.ascontiguousarray(codes)).cuda()
+    dcodes = torch.zeros(lib.Context.codes_bytes(N, L), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    ctx.encode_dev(raw.data_ptr(), lib.DATA_CODES_U8, N, L, dcodes.data_ptr())
+    counts = torch.zeros(bank.shape[2], dtype=torch.int64, device="cuda") if want_counts else None
+    n = ctx.pwm_scan_hits_dev(bank, lens, dcodes.data_ptr(), N, L, rc, None, None, 0, n0=n0, batch=batch)
+    hits = torch.zeros((max(n, 1), 3), dtype=torch.int32, device="cuda")
+    sc = torch.zeros(max(n, 1), dtype=torch.int16, device="cuda")
+    n2 = ctx.pwm_scan_hits_dev(bank, lens, dcodes.data_ptr(), N, L, rc, hits.data_ptr(), sc.data_ptr(), n, n0=n0,
+                               batch=batch, counts_ptr=counts.data_ptr() if want_counts else None)
+    ctx.synchronize()
+    assert n2 == n
+    h = hits[:n].cpu().numpy().astype(np.uint32)
+    s = sc[:n].cpu().numpy().view(np.uint16)
+    if want_counts:
+        return h, s, counts.cpu().numpy()
+    return h, s
+
+
+def oracle_hits(pkg, bank, lens, codes, rc, batch):
+    f, s = so.get_pos_scores_arr(bank, lens, pkg.synth.codes_to_onehot(codes), rc=rc, batch_size=batch)
+    return np.stack([f["m"], f["n"], f["l"]], axis=1).astype(np.uint32), s.view(np.uint16)
+
+
+def test_golden_fixture(torch_cuda, ctx, pkg):
+    g = np.load(os.path.join(HERE, "golden", "scan_small.npz"))
+    for rc in (0, 1):
+        h, s = dev_scan_hits(torch_cuda, ctx, pkg, g["bank"], g["lens"], g["codes"], rc, int(g["batch"]))
+        assert np.array_equal(h, g[f"found_rc{rc}"])
+        assert np.array_equal(s, g[f"score_rc{rc}"])
+
+
+CASES = [
+    # N, L, K, len_lo, len_hi, batch, alpha
+    (50, 100, 32, 8, 8, 5000, 0.4),        # cfg-1 shape
+    (33, 47, 7, 3, 7, 10, 0.6),            # odd K, L % 4 != 0, LEN=8 template with short PWMs
+    (70, 61, 131, 9, 12, 32, 0.5),         # 66 pairs -> two chunks, LEN=12
+    (40, 90, 20, 13, 16, 17, 0.5),         # LEN=16
+    (30, 75, 9, 17, 20, 8, 0.5),           # LEN=20
+    (25, 70, 6, 21, 24, 25, 0.6),          # LEN=24
+    (21, 80, 5, 25, 32, 5, 0.7),           # LEN=32
+    (10, 12, 4, 12, 12, 3, 0.9),           # a single window per sequence
+    (300, 40, 260, 6, 10, 64, 0.4),        # three chunks
+]
+
+
+@pytest.mark.parametrize("N,L,K,lo,hi,batch,alpha", CASES)
+@pytest.mark.parametrize("rc", [False, True])
+def test_hits_match_oracle(torch_cuda, ctx, pkg, N, L, K, lo, hi, batch, alpha, rc):
+    sy = pkg.synth
+    codes = sy.gen_codes(N, L, 100 + N + K, n_plant=2, k=min(8, L))
+    codes[N // 2, L // 3] = 4                      # an all-zero column
+    pwms, lens = sy.gen_pwm_bank(K, 200 + K, len_lo=lo, len_hi=hi, alpha=alpha)
+    bank = sy.pad_bank(pwms, lens)
+    h, s, counts = dev_scan_hits(torch_cuda, ctx, pkg, bank, lens, codes, rc, batch, want_counts=True)
+    oh, os_ = oracle_hits(pkg, bank, lens, codes, rc, batch)
+    assert len(oh) > 0
+    assert np.array_equal(h, oh), "hit records (m,n,l) or their order differ"
+    assert np.array_equal(s, os_), "fp16 scores differ"
+    assert np.array_equal(counts, np.bincount(oh[:, 0] - 1, minlength=K))
+
+
+def test_pwm_longer_than_sequence_and_empty(torch_cuda, ctx, pkg):
+    sy = pkg.synth
+    codes = sy.gen_codes(5, 10, 1)
+    pwms, lens = sy.gen_pwm_bank(3, 2, len_lo=11, len_hi=12)
+    bank = sy.pad_bank(pwms, lens)
+    h, s = dev_scan_hits(torch_cuda, ctx, pkg, bank, lens, codes, False, 5000)
+    assert len(h) == 0
+    # one PWM fits, the others do not
+    pwms2, lens2 = sy.gen_pwm_bank(3, 3, len_lo=4, len_hi=4, alpha=0.9)
+    pw = [pwms[0], pwms2[1], pwms[2]]
+    ln = np.array([lens[0], 4, lens[2]])
+    bank = sy.pad_bank(pw, ln)
+    h, s = dev_scan_hits(torch_cuda, ctx, pkg, bank, ln, codes, False, 5000)
+    oh, os_ = oracle_hits(pkg, bank, ln, codes, False, 5000)
+    assert np.array_equal(h, oh) and np.array_equal(s, os_) and set(h[:, 0]) <= {2}
+
+
+def test_dense_matches_greedy_search_layout(torch_cuda, ctx, pkg):
+    """a17 drop-in: the (K, nb, 4L) tensor of _h3_1_alignment.jl:75-80, zeros included."""
+    torch = torch_cuda
+    sy = pkg.synth
+    for (N, L, K, lo, hi) in [(19, 50, 10, 6, 12), (8, 33, 7, 5, 9), (12, 64, 140, 12, 12)]:
+        codes = sy.gen_codes(N, L, 9 + K)
+        pwms, lens = sy.gen_pwm_bank(K, 10 + K, len_lo=lo, len_hi=hi, alpha=0.6)
+        bank = sy.pad_bank(pwms, lens)
+        want = so.greedy_search(bank, lens, sy.codes_to_onehot(codes).astype(np.float16))  # (4L, N, K)
+        raw = torch.from_numpy(codes).cuda()
+        dcodes = torch.zeros(pkg._lib.Context.codes_bytes(N, L), dtype=torch.uint8, device="cuda")
+        out = torch.full((4 * L, N, K), 0x7BFF, dtype=torch.int16, device="cuda")  # poison: must be overwritten
+        torch.cuda.synchronize()
+        ctx.encode_dev(raw.data_ptr(), pkg._lib.DATA_CODES_U8, N, L, dcodes.data_ptr())
+        ctx.pwm_scan_dense_dev(bank, lens, dcodes.data_ptr(), N, L, out.data_ptr(), 4 * L)
+        ctx.synchronize()
+        got = out.cpu().numpy().view(np.uint16)
+        assert np.array_equal(got, want.view(np.uint16))
+
+
+def test_host_entry_and_mirror(torch_cuda, ctx, pkg):
+    """motifs_pwm_scan (host buffers, f32 one-hot) + gpu_scan dict build (:38-52, :89-99)."""
+    sy, sc = pkg.synth, pkg.scan
+    N, L, K = 5200, 24, 12                        # crosses the 5000-sequence batch boundary (:71)
+    codes = sy.gen_codes(N, L, 77, n_plant=2, k=8)
+    pwms, lens = sy.gen_pwm_bank(K, 78, len_lo=6, len_hi=8, alpha=0.35)
+    bank = sy.pad_bank(pwms, lens)
+    onehot = sy.codes_to_onehot(codes)
+    data = sc.FastaData(onehot.reshape(N, 1, 4 * L))
+    ms = sc.Motifs(pwms, lens)
+    for rc in (False, True):
+        found, score = sc.get_pos_scores_arr(ms, data, rc=rc, ctx=ctx)
+        of, os_ = so.get_pos_scores_arr(bank, lens, onehot, rc=rc)
+        assert np.array_equal(found, of) and np.array_equal(score.view(np.uint16), os_.view(np.uint16))
+        assert found["n"].max() > 5000
+    sc.scan_w_gpu(ms, data, ctx=ctx)
+    # per (m, n): forward hits in ascending l, then reverse-strand hits in ascending l
+    m0 = next(i for i, d in enumerate(ms.positions) if d)
+    n0 = next(iter(ms.positions[m0]))
+    pos, comp = ms.positions[m0][n0], ms.use_comp[m0][n0]
+    fwd = [p for p, c in zip(pos, comp) if not c]
+    rev = [p for p, c in zip(pos, comp) if c]
+    assert pos == fwd + rev and fwd == sorted(fwd) and rev == sorted(rev)
+    total = sum(len(v) for d in ms.positions for v in d.values())
+    assert total == sum(len(so.get_pos_scores_arr(bank, lens, onehot, rc=r)[0]) for r in (False, True))
+
+
+def test_f16_input_and_errors(torch_cuda, ctx, pkg):
+    sy, lib = pkg.synth, pkg._lib
+    codes = sy.gen_codes(20, 30, 5)
+    pwms, lens = sy.gen_pwm_bank(6, 6, len_lo=5, len_hi=8, alpha=0.6)
+    bank = sy.pad_bank(pwms, lens)
+    onehot = sy.codes_to_onehot(codes)
+    a = ctx.pwm_scan(bank, lens, onehot.astype(np.float16), lib.DATA_ONEHOT_F16, 20, 30, False)
+    b = ctx.pwm_scan(bank, lens, onehot, lib.DATA_ONEHOT_F32, 20, 30, False)
+    c = ctx.pwm_scan(bank, lens, codes, lib.DATA_CODES_U8, 20, 30, False)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(c[0], b[0]) and len(a[0]) > 0
+    bad = onehot.copy()
+    bad[3, 5] = 0.5
+    with pytest.raises(lib.MotifsError) as e:
+        ctx.pwm_scan(bank, lens, bad, lib.DATA_ONEHOT_F32, 20, 30, False)
+    assert e.value.code == lib.ERR_NOT_ONEHOT
+    nb = bank.copy()
+    nb[0, 0, 0] = np.inf
+    with pytest.raises(lib.MotifsError) as e:
+        ctx.pwm_scan(nb, lens, onehot, lib.DATA_ONEHOT_F32, 20, 30, False)
+    assert e.value.code == lib.ERR_NONFINITE
+    with pytest.raises(lib.MotifsError) as e:
+        ctx.pwm_scan(bank, lens, onehot, lib.DATA_ONEHOT_F32, 20, 30, False, cap=max(len(b[0]) - 1, 1))
+    assert e.value.code == lib.ERR_BUFFER_TOO_SMALL
+    big = np.zeros((33, 4, 2), dtype=np.float16)
+    with pytest.raises(lib.MotifsError) as e:
+        ctx.pwm_scan(big, np.array([33, 33]), onehot, lib.DATA_ONEHOT_F32, 20, 30, False)
+    assert e.value.code == lib.ERR_UNSUPPORTED
+
+
+def test_full_size_properties(torch_cuda, ctx, pkg):
+    """BASELINE configs[1] size (100k x 200 bp, 200 PWMs of length 12): the oracle cannot finish this
+    in seconds, so check size-independent properties + an oracle comparison on sampled sequences."""
+    torch = torch_cuda
+    sy, lib = pkg.synth, pkg._lib
+    N, L, K = 100_000, 200, 200
+    codes = sy.gen_codes(N, L, sy.SEED_BASE + 2, n_plant=5, k=12)
+    pwms, lens = sy.gen_pwm_bank(K, sy.SEED_BASE + 2, alpha=0.3)
+    bank = sy.pad_bank(pwms, lens)
+    h, s, counts = dev_scan_hits(torch, ctx, pkg, bank, lens, codes, False, lib.SCAN_BATCH, want_counts=True)
+    n = len(h)
+    assert n > 1_000_000
+    # (1) histogram == record counts
+    assert np.array_equal(counts, np.bincount(h[:, 0] - 1, minlength=K))
+    # (2) reference order: (batch, l, n, m) strictly increasing
+    key = (((h[:, 1].astype(np.int64) - 1) // lib.SCAN_BATCH) * 1000 + h[:, 2]) * (N + 1) + h[:, 1]
+    key = key * (K + 1) + h[:, 0]
+    assert np.all(np.diff(key) > 0)
+    # (3) every score is a positive finite half, every l in range
+    sf = s.view(np.float16)
+    assert np.all(sf > 0) and np.all(np.isfinite(sf)) and h[:, 2].max() <= L - 12 + 1
+    # (4) sampled sequences against the oracle
+    rng = np.random.default_rng(0)
+    pick = np.sort(rng.choice(N, size=40, replace=False))
+    g = so.scan_gather(bank, lens, codes[pick])          # (Lout, 40, K)
+    lo, no, ko = np.nonzero(g > 0)
+    want = {(int(k) + 1, int(pick[nn]) + 1, int(l) + 1): g[l, nn, k] for l, nn, k in zip(lo, no, ko)}
+    sel = np.isin(h[:, 1], pick + 1)
+    got = {(int(a), int(b), int(c)): v for (a, b, c), v in zip(h[sel], sf[sel])}
+    assert got.keys() == want.keys()
+    assert all(got[k_].view(np.uint16) == want[k_].view(np.uint16) for k_ in want)
