@@ -69,6 +69,14 @@ def lib():
                 f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(there is no CPU fallback)",
             )
+        # torch bundles its own libamdhip64.so.7; if it is going to live in this process it
+        # must be loaded BEFORE us so that both bind to ONE HIP runtime (the loader
+        # de-duplicates by SONAME only in that order).  torch is plumbing here: device
+        # memory, streams, torch.distributed.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)
