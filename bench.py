@@ -145,16 +145,19 @@ def main():
 
     bases = float(N) * L * world
     value = bases * args.steps / dt
-    # dominant kernel of the step = the scan kernel in COUNT mode + FILL mode (same code, same work);
-    # algorithmic bytes per launch under the fused-hits contract:
-    #   COUNT: N*L codes in + N*nch*LoutP*2 counts out ; FILL: N*L in + N*nch*LoutP*4 offsets in + 14 B per hit out
-    nch = ((K + 1) // 2 + 63) // 64
-    LoutP = (Lout + 63) // 64 * 64
-    hits_per_launch = nhits / 2.0
-    scan_ms = kms["count"][0] + kms["fill"][0]
-    scan_n = kms["count"][1] + kms["fill"][1]
-    alg_bytes = ((N * L + N * nch * LoutP * 2) + (N * L + N * nch * LoutP * 4 + hits_per_launch * 14)) / 2.0
-    achieved = alg_bytes / (scan_ms / max(scan_n, 1) * 1e-3) / 1e9
+    # One strand pass = scan_kernel<12,MASK> (all the arithmetic: every window of every PWM, `> 0`
+    # test, 128-bit hit masks) -> row sums + scan -> fill_records (records + scores, reference order).
+    # Algorithmic bytes per strand pass, fused-hits contract: N*L codes in, 14 B per hit
+    # out, K counters.  The dominant kernel is the MASK scan; it is bound by packed fp16 adds
+    # (v_pk_add_f16 issues at 4 cycles per wave on gfx950, measured: tools/ubench/valu_rate.hip).
+    hits_per_pass = nhits / 2.0
+    n_pass = max(kms["count"][1], 1)
+    mask_ms = kms["count"][0] / n_pass
+    pass_ms = (kms["count"][0] + kms["offsets"][0] + kms["fill"][0]) / n_pass
+    alg_bytes = N * L + hits_per_pass * 14 + K * 8
+    achieved = alg_bytes / (pass_ms * 1e-3) / 1e9
+    adds = float(N) * Lout * PL * K                      # useful sequential fp16 adds per strand pass
+    valu_peak = 256 * 4 * 128 / 4.0 * 2.4e9              # adds/s: 1024 SIMDs x 128 adds per 4-cycle v_pk_add_f16
     out = {
         "metric": "bases scanned/sec",
         "value": value,
@@ -175,16 +178,22 @@ def main():
             "parallelism": f"sequence shards x{world}, all-reduce of the {K}-entry hit histogram only",
         },
         "roofline": {
-            "kernel": "scan_kernel<12,COUNT|FILL> (fused threshold + ordered compaction; VALU-bound by design)",
+            "kernel": "scan_kernel<12,MASK> + fill_row_sums/scan + fill_records (one strand pass)",
             "bound": "hbm",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": None,
-            "avg_launch_ms": scan_ms / max(scan_n, 1),
-            "note": "fused-hits contract: no dense score tensor is written, so the kernel is bound by packed "
-                    "fp16 adds, not by HBM; see dense_kernel for the a17 dense-score contract",
+            "avg_launch_ms": pass_ms,
+            "dominant_kernel_ms": mask_ms,
+            "note": "fused-hits contract (no dense score tensor): the pass is bound by fp16 adds, not HBM; "
+                    "see valu_roofline for the dominant kernel and dense_kernel for the a17 dense-score contract",
+        },
+        "valu_roofline": {
+            "kernel": "scan_kernel<12,MASK>", "bound": "valu", "achieved": adds / (mask_ms * 1e-3) / 1e12,
+            "peak": valu_peak / 1e12, "unit": "T fp16-add/s", "frac": adds / (mask_ms * 1e-3) / valu_peak,
+            "avg_launch_ms": mask_ms,
         },
         "dense_kernel": {
             "kernel": "scan_kernel<12,DENSE> (a17 greedy_search! drop-in, writes (K,nb,L-len+1) fp16)",
@@ -192,7 +201,8 @@ def main():
             "frac": dense_gbs / HBM_PEAK_GBS, "avg_launch_ms": dense_ms / dense_n, "seqs_per_launch": nb,
             "bases_per_s_one_strand": nb * L / (dense_ms / dense_n * 1e-3),
         },
-        "kernel_ms_per_step": {k: v[0] / args.steps for k, v in kms.items()},
+        "kernel_ms_per_step": {"mask_scan": kms["count"][0] / args.steps, "row_sums_scan": kms["offsets"][0] / args.steps,
+                               "fill_records": kms["fill"][0] / args.steps},
     }
 
     if not args.no_cpu and world == 1:

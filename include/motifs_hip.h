@@ -88,9 +88,9 @@ int motifs_ctx_synchronize(motifs_ctx* ctx);
 enum motifs_kernel_slot {
     MOTIFS_KS_ENCODE = 0,
     MOTIFS_KS_SCAN_DENSE = 1,
-    MOTIFS_KS_SCAN_COUNT = 2,
-    MOTIFS_KS_SCAN_OFFSETS = 3,
-    MOTIFS_KS_SCAN_FILL = 4
+    MOTIFS_KS_SCAN_COUNT = 2,   /* scan_kernel<LEN,MASK>: all windows, `> 0` test, 128-bit hit masks */
+    MOTIFS_KS_SCAN_OFFSETS = 3, /* fill_row_sums + fill_row_scan: record offsets                   */
+    MOTIFS_KS_SCAN_FILL = 4     /* fill_records: (m, n, l) + fp16 score per set mask bit           */
 };
 int motifs_ctx_enable_timing(motifs_ctx* ctx, int on);
 int motifs_ctx_reset_timing(motifs_ctx* ctx);

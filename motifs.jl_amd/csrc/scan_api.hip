@@ -80,9 +80,15 @@ static int pack_bank(const uint16_t* pwms, const int64_t* lens, int K, int maxle
     return MOTIFS_OK;
 }
 
+static int pick_cpb(int nch) {
+    int cpb = 1;
+    while (cpb * 2 <= nch && cpb * 2 <= SCAN_WAVES) cpb *= 2;
+    return cpb;
+}
+
 static int pick_spw(int64_t N, int nch) {
     const int64_t items = N * nch;
-    int64_t spw = items / 16384;  // aim for >= 16k waves in flight over the launch
+    int64_t spw = items / 16384;  // aim for >= 16k wave-items over the launch
     if (spw < 1) spw = 1;
     if (spw > 16) spw = 16;
     return (int)spw;
@@ -202,8 +208,9 @@ int motifs_ctx_kernel_ms(motifs_ctx* c, int slot, double* ms, int64_t* launches)
     return MOTIFS_OK;
 }
 
-int motifs_codes_pitch(int L) { return (L + 3) & ~3; }
-size_t motifs_codes_bytes(int64_t N, int L) { return (size_t)N * motifs_codes_pitch(L) + 2 * MOTIFS_SCAN_MAX_LEN + 64; }
+// row = L codes, zero padding to a multiple of 4, then 4 flag bytes (byte 0: row has an all-zero column)
+int motifs_codes_pitch(int L) { return ((L + 3) & ~3) + 4; }
+size_t motifs_codes_bytes(int64_t N, int L) { return (size_t)N * motifs_codes_pitch(L) + SCAN_GUARD_BYTES; }
 
 int motifs_encode_dev(motifs_ctx* c, const void* data_dev, int kind, int64_t N, int L, uint8_t* codes_dev,
                       int32_t* bad_flag_dev) {
@@ -250,7 +257,8 @@ int motifs_pwm_scan_dense_dev(motifs_ctx* c, const uint16_t* pwms_fp16, const in
     a.d.KP = bank.KP;
     a.d.nch = bank.nch;
     a.d.Lout = Lout;
-    a.d.LoutP = (Lout + 63) & ~63;
+    a.d.LoutP = scan_lout_padded(Lout, bank.lenp);
+    a.d.cpb = pick_cpb(bank.nch);
     a.d.lim_min = L - bank.maxlen_true;
     a.d.spw = pick_spw(N, bank.nch);
     a.d.k_even = (K % 2 == 0);
@@ -282,36 +290,35 @@ int motifs_pwm_scan_hits_dev(motifs_ctx* c, const uint16_t* pwms_fp16, const int
     rcode = upload_bank(c, bank);
     if (rcode) return rcode;
 
-    const int LoutP = (Lout + 63) & ~63;
-    // super-batch: as many ordering batches as fit a ~6 GiB count/offset workspace
-    const size_t per_seq = (size_t)bank.nch * LoutP * 6;
-    int64_t sb = (int64_t)((6ull << 30) / per_seq);
-    sb = std::max<int64_t>(batch, sb / batch * batch);
-    sb = std::min<int64_t>(sb, (N + batch - 1) / batch * batch);
-    const int tiles = (batch + OFFS_TILE - 1) / OFFS_TILE;
-    const int nbatch_max = (int)(sb / batch);
+    const int LoutP = scan_lout_padded(Lout, bank.lenp);
+    // super-batch: as many ordering batches as fit an ~8 GiB mask workspace
+    const size_t per_batch = (size_t)LoutP * batch * bank.nch * 16;
+    int64_t nb_max = (int64_t)((8ull << 30) / per_batch);
+    nb_max = std::max<int64_t>(1, std::min<int64_t>(nb_max, (N + batch - 1) / batch));
+    const int64_t sb = nb_max * batch;
+    const int64_t cells_max = (int64_t)nb_max * LoutP * batch * bank.nch;
+    const int64_t chunks_max = (int64_t)nb_max * LoutP;   // mask rows
 
-    MOTIFS_HIP_CHECK(c->cnt.reserve((size_t)sb * bank.nch * LoutP * 2));
-    MOTIFS_HIP_CHECK(c->off.reserve((size_t)sb * bank.nch * LoutP * 4));
-    MOTIFS_HIP_CHECK(c->tilesum.reserve((size_t)nbatch_max * Lout * tiles * 4));
-    MOTIFS_HIP_CHECK(c->small.reserve((size_t)nbatch_max * 8 + 64));
+    MOTIFS_HIP_CHECK(c->cnt.reserve((size_t)cells_max * 16));        // masks
+    MOTIFS_HIP_CHECK(c->tilesum.reserve((size_t)chunks_max * 4));    // chunk sums
+    MOTIFS_HIP_CHECK(c->off.reserve((size_t)chunks_max * 8));        // chunk bases
+    MOTIFS_HIP_CHECK(c->small.reserve(64));
     MOTIFS_HIP_CHECK(c->pwmcnt.reserve((size_t)2 * bank.KP * 8));
     if (per_pwm_counts_dev) MOTIFS_HIP_CHECK(hipMemsetAsync(c->pwmcnt.p, 0, (size_t)2 * bank.KP * 8, c->stream));
 
-    int64_t* batch_base = (int64_t*)c->small.p;
-    int64_t* total_dev = batch_base + nbatch_max;
-    int32_t* overflow_dev = (int32_t*)(total_dev + 1);
+    int64_t* total_dev = (int64_t*)c->small.p;
     int64_t* h_total = (int64_t*)c->pinned;
-    int32_t* h_overflow = (int32_t*)(h_total + 1);
 
     int64_t emitted = 0;
     bool too_small = false;
     for (int64_t s0 = 0; s0 < N; s0 += sb) {
         const int64_t ns = std::min<int64_t>(sb, N - s0);
+        const int64_t nb = (ns + batch - 1) / batch;
         ScanArgs a{};
         a.tab = (const uint32_t*)c->tab.p;
         a.lim = (const int32_t*)c->lim.p;
         a.codes = codes_dev + (size_t)s0 * motifs_codes_pitch(L);
+        a.masks = (uint4*)c->cnt.p;
         a.d.N = ns;
         a.d.L = L;
         a.d.pitch = motifs_codes_pitch(L);
@@ -320,53 +327,61 @@ int motifs_pwm_scan_hits_dev(motifs_ctx* c, const uint16_t* pwms_fp16, const int
         a.d.nch = bank.nch;
         a.d.Lout = Lout;
         a.d.LoutP = LoutP;
+        a.d.cpb = pick_cpb(bank.nch);
         a.d.lim_min = L - bank.maxlen_true;
         a.d.spw = pick_spw(ns, bank.nch);
         a.d.k_even = (K % 2 == 0);
         a.d.batch = batch;
-        a.d.n0 = n0 + s0;
-        a.cnt = (uint16_t*)c->cnt.p;
-        a.off = (const uint32_t*)c->off.p;
-        a.batch_base = batch_base;
-        a.hits = (HitRec*)hits_dev;
-        a.hit_scores = hit_scores_dev;
-        a.pwm_counts = per_pwm_counts_dev ? (int64_t*)c->pwmcnt.p : nullptr;
+        FillArgs f{};
+        f.masks = a.masks;
+        f.nrows = nb * LoutP;
+        f.row_cells = (uint32_t)(batch * bank.nch);
+        f.row_sum = (uint32_t*)c->tilesum.p;
+        f.row_base = (int64_t*)c->off.p;
+        f.Lout = Lout;
+        f.hist_bins = (per_pwm_counts_dev && 2 * bank.KP <= FILL_HIST_MAX) ? 2 * bank.KP : 0;
+        {   // magic numbers for idx / nch
+            uint32_t d = (uint32_t)bank.nch, sh = 0;
+            while ((1u << sh) < d) sh++;
+            f.div_nch.d = d;
+            f.div_nch.s = sh;
+            f.div_nch.m = d == 1 ? 0u : (uint32_t)((((uint64_t)1 << 32) * (((uint64_t)1 << sh) - d)) / d + 1);
+        }
+        f.total = total_dev;
+        f.tab = a.tab;
+        f.codes = a.codes;
+        f.hits = (HitRec*)hits_dev;
+        f.hit_scores = hit_scores_dev;
+        f.pwm_counts = per_pwm_counts_dev ? (int64_t*)c->pwmcnt.p : nullptr;
+        f.base0 = emitted;
+        f.n0 = n0 + s0;
+        f.nch = bank.nch;
+        f.batch = batch;
+        f.LoutP = LoutP;
+        f.lshift = bank.lenp - 1;
+        f.lenp = bank.lenp;
+        f.KP = bank.KP;
+        f.pitch = a.d.pitch;
+        if (ns < nb * batch)  // sequences the last (partial) batch does not have: their cells must read as empty
+            MOTIFS_HIP_CHECK(hipMemsetAsync(c->cnt.p, 0, (size_t)f.nrows * f.row_cells * 16, c->stream));
         {
             KernelTimer t(c, KS_SCAN_COUNT);
-            MOTIFS_HIP_CHECK(launch_scan(MODE_COUNT, bank.lenp, a, c->stream));
+            MOTIFS_HIP_CHECK(launch_scan(MODE_MASK, bank.lenp, a, c->stream));
         }
-        OffsArgs o{};
-        o.cnt = a.cnt;
-        o.off = (uint32_t*)c->off.p;
-        o.tilesum = (uint32_t*)c->tilesum.p;
-        o.batch_base = batch_base;
-        o.total = total_dev;
-        o.overflow = overflow_dev;
-        o.N = ns;
-        o.base0 = emitted;
-        o.Lout = Lout;
-        o.LoutP = LoutP;
-        o.nch = bank.nch;
-        o.batch = batch;
-        o.tiles = tiles;
-        o.nbatch = (int)((ns + batch - 1) / batch);
-        MOTIFS_HIP_CHECK(hipMemsetAsync(overflow_dev, 0, 4, c->stream));
         {
             KernelTimer t(c, KS_SCAN_OFFSETS);
-            MOTIFS_HIP_CHECK(launch_offsets(o, c->stream));
+            MOTIFS_HIP_CHECK(launch_fill_sums(f, c->stream));
         }
-        MOTIFS_HIP_CHECK(hipMemcpyAsync(h_total, total_dev, 12, hipMemcpyDeviceToHost, c->stream));
+        MOTIFS_HIP_CHECK(hipMemcpyAsync(h_total, total_dev, 8, hipMemcpyDeviceToHost, c->stream));
         MOTIFS_HIP_CHECK(hipStreamSynchronize(c->stream));
-        if (*h_overflow) {
-            set_error("more than 2^32 hits inside one %d-sequence batch", batch);
-            return MOTIFS_ERR_UNSUPPORTED;
-        }
         const int64_t sb_total = *h_total;
         if (emitted + sb_total > cap) too_small = true;
         if (!too_small && sb_total > 0) {
             KernelTimer t(c, KS_SCAN_FILL);
-            MOTIFS_HIP_CHECK(launch_scan(MODE_FILL, bank.lenp, a, c->stream));
+            MOTIFS_HIP_CHECK(launch_fill_records(f, c->stream));
         }
+        if (f.pwm_counts && (too_small || 2 * bank.KP > FILL_HIST_MAX))
+            MOTIFS_HIP_CHECK(launch_mask_histogram(f, c->stream));
         emitted += sb_total;
     }
     *n_out = emitted;

@@ -5,11 +5,13 @@
 
 namespace motifs {
 
-constexpr int SCAN_BLOCK = 256;           // 4 waves
+constexpr int SCAN_BLOCK = 512;           // 8 waves
 constexpr int SCAN_WAVES = SCAN_BLOCK / 64;
-constexpr int OFFS_TILE = 64;             // sequences per offset tile
+constexpr int SCAN_GUARD_BYTES = 128;     // readable zero bytes behind the last code row
+constexpr int FILL_THREADS = 256;
+constexpr int FILL_HIST_MAX = 8192;       // LDS histogram bins of fill_records (PWMs, padded)
 
-enum { MODE_DENSE = 0, MODE_COUNT = 1, MODE_FILL = 2 };
+enum { MODE_DENSE = 0, MODE_MASK = 1 };
 
 struct HitRec {
     uint32_t m, n, l;
@@ -21,12 +23,12 @@ struct ScanDims {
     int64_t N;
     int L, pitch;
     int K, KP, nch;           // PWMs, padded pairs (nch*64), chunks of 64 pairs
-    int Lout, LoutP;          // L - minlen + 1; rounded up to 64
+    int Lout, LoutP;          // L - minlen + 1; positions per mask row (see scan_lout_padded)
     int lim_min;              // L - maxlen: starts <= lim_min are valid for every PWM
     int spw;                  // sequences per wave
+    int cpb;                  // PWM chunks handled side by side in one block (1, 2, 4 or 8)
     int k_even;
     int batch;                // ordering batch (5000)
-    int64_t n0;               // global index offset for records
 };
 
 struct ScanArgs {
@@ -34,30 +36,47 @@ struct ScanArgs {
     const int32_t* lim;       // [2*KP] last valid 0-based start per PWM (L - len), -1 if absent
     const uint8_t* codes;     // N rows of `pitch` bytes
     uint16_t* scores;         // DENSE: (K, N, ld_l) col-major
-    uint16_t* cnt;            // COUNT: [(n*nch + ch) * LoutP + l]
-    const uint32_t* off;      // FILL: same shape
-    const int64_t* batch_base;
-    HitRec* hits;
-    uint16_t* hit_scores;
-    int64_t* pwm_counts;      // optional [2*KP]
+    uint4* masks;             // MASK: [(batch, p, n-in-batch, chunk)] 128-bit hit masks {lo halves, hi halves}
     ScanDims d;
 };
 
-struct OffsArgs {
-    const uint16_t* cnt;
-    uint32_t* off;
-    uint32_t* tilesum;        // [(b*Lout + l) * tiles + t]
-    int64_t* batch_base;      // [nbatch]
+struct FastDivHost {
+    uint32_t d, m, s;
+};
+
+struct FillArgs {
+    const uint4* masks;       // [row = (batch, p)][cell = (n-in-batch, chunk)]
+    int64_t nrows;            // batches * LoutP
+    uint32_t row_cells;       // batch * nch
+    uint32_t* row_sum;        // [nrows]
+    int64_t* row_base;        // [nrows] exclusive
     int64_t* total;
-    int32_t* overflow;
-    int64_t N;
-    int64_t base0;            // records already emitted before this super-batch
-    int Lout, LoutP, nch, batch, tiles, nbatch;
+    const uint32_t* tab;
+    const uint8_t* codes;
+    HitRec* hits;
+    uint16_t* hit_scores;
+    int64_t* pwm_counts;      // optional [2*KP]
+    int64_t base0;            // records emitted before this super-batch
+    int64_t n0;               // global index offset for records
+    int nch, batch, Lout, LoutP, lshift, lenp, KP, pitch;
+    int hist_bins;            // 2*KP when the LDS histogram is on, else 0
+    struct {
+        uint32_t d, m, s;
+        __device__ uint32_t div(uint32_t n) const {
+            if (d == 1) return n;
+            const uint32_t t = __umulhi(n, m);
+            return (t + ((n - t) >> 1)) >> (s - 1);
+        }
+    } div_nch;
 };
 
 int scan_len_padded(int maxlen);
+// positions per mask row for windows 0..Lout-1 of padded length lenp
+int scan_lout_padded(int Lout, int lenp);
 hipError_t launch_scan(int mode, int len_padded, const ScanArgs& a, hipStream_t st);
-hipError_t launch_offsets(const OffsArgs& a, hipStream_t st);
+hipError_t launch_fill_sums(const FillArgs& a, hipStream_t st);
+hipError_t launch_fill_records(const FillArgs& a, hipStream_t st);
+hipError_t launch_mask_histogram(const FillArgs& a, hipStream_t st);
 hipError_t launch_encode(int kind, const void* x, int64_t N, int L, int pitch, uint8_t* codes, int32_t* bad,
                          hipStream_t st);
 
