@@ -90,7 +90,8 @@ enum motifs_kernel_slot {
     MOTIFS_KS_SCAN_DENSE = 1,
     MOTIFS_KS_SCAN_COUNT = 2,   /* scan_kernel<LEN,MASK>: all windows, `> 0` test, 128-bit hit masks */
     MOTIFS_KS_SCAN_OFFSETS = 3, /* fill_row_sums + fill_row_scan: record offsets                   */
-    MOTIFS_KS_SCAN_FILL = 4     /* fill_records: (m, n, l) + fp16 score per set mask bit           */
+    MOTIFS_KS_SCAN_FILL = 4,    /* fill_records: (m, n, l) + fp16 score per set mask bit           */
+    MOTIFS_KS_TRAIN_STEP = 5    /* the whole forward/backward graph of motifs_model_loss_grad_dev  */
 };
 int motifs_ctx_enable_timing(motifs_ctx* ctx, int on);
 int motifs_ctx_reset_timing(motifs_ctx* ctx);
@@ -153,6 +154,60 @@ int motifs_pwm_scan(motifs_ctx* ctx, const uint16_t* pwms_fp16, const int64_t* l
                     int maxlen, const void* data, int kind, int64_t N, int L, int rc,
                     motifs_hit* hits, uint16_t* hit_scores, int64_t cap, int64_t* n_out,
                     int64_t* per_pwm_counts);
+
+/* ---- convolutional sparse coding: src/model.jl, src/train.jl, _1_code_retrieval.jl ------------ */
+
+/* Hyperparam (model.jl:1-14); f_len = 4*filter_len and twoM = 2*M are derived. */
+typedef struct motifs_hparams {
+    int32_t filter_len, M, h, K, q, batch_size, num_pass_xyz, num_pass_df;
+    float magnifying_factor, gamma;
+} motifs_hparams;
+
+/* stored_code_component_t (_0_const.jl:3-4): (position::UInt16, fil::UInt16, seq::UInt32,
+ * mag::Float16) with Julia's isbits layout (12 bytes: offsets 0, 2, 4, 8). */
+typedef struct motifs_code_rec {
+    uint16_t position;
+    uint16_t fil;
+    uint32_t seq;
+    uint16_t mag;   /* IEEE binary16 bits */
+    uint16_t pad_;
+} motifs_code_rec;
+
+typedef struct motifs_model motifs_model;   /* opaque: the `ucdl` state + AdaBelief moments + engine arena */
+
+/* Replaces train.jl:29-35 (Hyperparam(), length_info, projectors, ucdl(hp), Flux.params, AdaBelief()).
+ * L: sequence length in bp.  arena_bytes: device memory for intermediates (0 = 8 GiB); one mini-batch of
+ * BASELINE configs[1] needs ~0.5 GiB with gradients. */
+int motifs_model_create(motifs_ctx* ctx, const motifs_hparams* hp, int L, size_t arena_bytes, motifs_model** out);
+void motifs_model_destroy(motifs_model* m);
+/* nD = 4*filter_len*M, nF = h*2M*K, nV = 33 with the default pass counts; c, l as in length_info. */
+int motifs_model_sizes(motifs_model* m, int64_t* nD, int64_t* nF, int64_t* nV, int64_t* c, int64_t* l);
+/* Filter-bank layouts are the reference's (model.jl:84-90): D (f_len,1,M) and F (h,twoM,1,K), column-major.
+ * warmup3 = {lambda_sparsity_warmup, lambda_stepsize_warmup, omega_stepsize_warmup} (plain scalars, not
+ * trained: model.jl:68,72,73); vecs = lambda_sparsity | kappa_sparsity | lambda_stepsize | omega_stepsize |
+ * kappa_stepsize | penalty_xyz | mu, raw (un-squared) values.  NULL leaves a block untouched. */
+int motifs_model_set_params(motifs_model* m, const float* D, const float* F, const float* warmup3, const float* vecs);
+int motifs_model_get_params(motifs_model* m, float* D, float* F, float* warmup3, float* vecs);
+/* ucdl(hp) initial values (model.jl:84-100) from a seeded stream. */
+int motifs_model_init_random(motifs_model* m, uint64_t seed);
+/* Replaces `gradient(ps) do forward_pass_return_loss(...) end` (train.jl:42-44) for n_groups independent
+ * mini-batches at once.  codes_dev: n_groups*batch_size rows (motifs_encode_dev layout).
+ * loss_dev[n_groups]: the reference's loss per mini-batch; grad_flat_dev[nD+nF+nV]: SUM over the
+ * mini-batches of the gradient w.r.t. [D | F | vecs] (NULL: forward only). */
+int motifs_model_loss_grad_dev(motifs_model* m, const uint8_t* codes_dev, int n_groups, float* loss_dev,
+                               float* grad_flat_dev, int keep_intermediates);
+/* Replaces Flux.Optimise.update!(opt, ps, gs) with AdaBelief() (train.jl:35,46); uses gscale*grad. */
+int motifs_model_adabelief_dev(motifs_model* m, const float* grad_flat_dev, float gscale);
+/* sum(abs.(prep_syntax_filters(cdl.F))) (train.jl:47). */
+int motifs_model_l1_syntax(motifs_model* m, float* out);
+/* Host-buffer form of one loop body of train.jl:40-52 (what Julia's ccall binds): codes = n_groups *
+ * batch_size rows of L bytes (0..3).  n_groups == 1 is exactly the reference's step. */
+int motifs_model_train_step(motifs_model* m, const uint8_t* codes, int n_groups, float* loss_out, float* l1F_out);
+/* Replaces code_retrieval (_1_code_retrieval.jl:33-56).  data: host matrix of `kind`, N sequences. */
+int motifs_model_retrieve_codes(motifs_model* m, const void* data, int kind, int64_t N, motifs_code_rec* out,
+                                int64_t cap, int64_t* n_out);
+/* Test hook: a named intermediate of the last loss_grad call made with keep_intermediates != 0. */
+int motifs_model_dump(motifs_model* m, const char* name, float* out, int64_t cap, int64_t* n);
 
 #ifdef __cplusplus
 }

@@ -14,11 +14,21 @@ LIB_PATH = os.path.join(HERE, "libmotifs_hip.so")
 
 OK, ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_BUFFER_TOO_SMALL, ERR_NOT_ONEHOT, ERR_NONFINITE, ERR_UNSUPPORTED = range(8)
 DATA_CODES_U8, DATA_ONEHOT_F32, DATA_ONEHOT_F16 = 0, 1, 2
-KS_ENCODE, KS_SCAN_DENSE, KS_SCAN_COUNT, KS_SCAN_OFFSETS, KS_SCAN_FILL = range(5)
+KS_ENCODE, KS_SCAN_DENSE, KS_SCAN_COUNT, KS_SCAN_OFFSETS, KS_SCAN_FILL, KS_TRAIN_STEP = range(6)
 SCAN_BATCH = 5000
 SCAN_MAX_LEN = 32
 
 HIT_DTYPE = np.dtype([("m", "<u4"), ("n", "<u4"), ("l", "<u4")])
+# stored_code_component_t (_0_const.jl:3-4) with Julia's 12-byte isbits layout
+CODE_DTYPE = np.dtype({"names": ["position", "fil", "seq", "mag"], "formats": ["<u2", "<u2", "<u4", "<f2"],
+                       "offsets": [0, 2, 4, 8], "itemsize": 12})
+
+
+class HParams(C.Structure):
+    """motifs_hparams == Hyperparam (model.jl:1-14)."""
+    _fields_ = [("filter_len", C.c_int32), ("M", C.c_int32), ("h", C.c_int32), ("K", C.c_int32), ("q", C.c_int32),
+                ("batch_size", C.c_int32), ("num_pass_xyz", C.c_int32), ("num_pass_df", C.c_int32),
+                ("magnifying_factor", C.c_float), ("gamma", C.c_float)]
 
 
 class MotifsError(RuntimeError):
@@ -52,6 +62,18 @@ SIGNATURES = {
         _int,
         [_p, _p, _p, _int, _int, _p, _i64, _int, _int, _i64, _int, _p, _p, _i64, C.POINTER(_i64), _p],
     ),
+    "motifs_model_create": (_int, [_p, C.POINTER(HParams), _int, C.c_size_t, C.POINTER(_p)]),
+    "motifs_model_destroy": (None, [_p]),
+    "motifs_model_sizes": (_int, [_p] + [C.POINTER(_i64)] * 5),
+    "motifs_model_set_params": (_int, [_p, _p, _p, _p, _p]),
+    "motifs_model_get_params": (_int, [_p, _p, _p, _p, _p]),
+    "motifs_model_init_random": (_int, [_p, C.c_uint64]),
+    "motifs_model_loss_grad_dev": (_int, [_p, _p, _int, _p, _p, _int]),
+    "motifs_model_adabelief_dev": (_int, [_p, _p, C.c_float]),
+    "motifs_model_l1_syntax": (_int, [_p, C.POINTER(C.c_float)]),
+    "motifs_model_train_step": (_int, [_p, _p, _int, _p, C.POINTER(C.c_float)]),
+    "motifs_model_retrieve_codes": (_int, [_p, _p, _int, _i64, _p, _i64, C.POINTER(_i64)]),
+    "motifs_model_dump": (_int, [_p, C.c_char_p, _p, _i64, C.POINTER(_i64)]),
     "motifs_pwm_scan": (
         _int,
         [_p, _p, _p, _int, _int, _p, _int, _i64, _int, _int, _p, _p, _i64, C.POINTER(_i64), _p],
@@ -102,11 +124,17 @@ class Context:
         self._h = _p()
         check(lib().motifs_ctx_create(int(device), C.byref(self._h)))
         self.device = int(device)
+        self._models = []          # weak references: models must die before their context
         if stream is not None:
             self.set_stream(stream)
 
     def close(self):
         if getattr(self, "_h", None):
+            for ref in self._models:
+                m = ref()
+                if m is not None:
+                    m.close()
+            self._models = []
             lib().motifs_ctx_destroy(self._h)
             self._h = None
 
@@ -202,3 +230,81 @@ def _bank(pwms, lens):
     maxlen, _, K = pwms.shape
     assert lens.shape == (K,)
     return pwms, lens, K, maxlen
+
+
+class Model:
+    """Owns a motifs_model: the `ucdl` state (model.jl:67-137), AdaBelief moments and the engine arena."""
+
+    def __init__(self, ctx, hp, L, arena_bytes=0):
+        self.ctx, self.hp, self.L = ctx, hp, int(L)
+        self._h = _p()
+        check(lib().motifs_model_create(ctx._h, C.byref(hp), int(L), int(arena_bytes), C.byref(self._h)))
+        v = [_i64(0) for _ in range(5)]
+        check(lib().motifs_model_sizes(self._h, *[C.byref(x) for x in v]))
+        self.nD, self.nF, self.nV, self.c, self.l = [x.value for x in v]
+        self.nP = self.nD + self.nF + self.nV
+        import weakref
+
+        ctx._models.append(weakref.ref(self))
+
+    def close(self):
+        if getattr(self, "_h", None) and getattr(self.ctx, "_h", None):
+            lib().motifs_model_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_params(self, D=None, F=None, warmup3=None, vecs=None):
+        arrs = [None if a is None else np.ascontiguousarray(a, dtype=np.float32).reshape(-1) for a in (D, F, warmup3, vecs)]
+        for a, n in zip(arrs, (self.nD, self.nF, 3, self.nV)):
+            assert a is None or a.size == n, (a.size, n)
+        check(lib().motifs_model_set_params(self._h, *[_np_ptr(a) for a in arrs]))
+
+    def get_params(self):
+        D, F = np.zeros(self.nD, np.float32), np.zeros(self.nF, np.float32)
+        w, v = np.zeros(3, np.float32), np.zeros(self.nV, np.float32)
+        check(lib().motifs_model_get_params(self._h, _np_ptr(D), _np_ptr(F), _np_ptr(w), _np_ptr(v)))
+        return D, F, w, v
+
+    def init_random(self, seed):
+        check(lib().motifs_model_init_random(self._h, int(seed)))
+
+    def loss_grad_dev(self, codes_ptr, n_groups, loss_ptr, grad_ptr, keep=False):
+        check(lib().motifs_model_loss_grad_dev(self._h, _p(codes_ptr), int(n_groups), _p(loss_ptr), _p(grad_ptr), int(keep)))
+
+    def adabelief_dev(self, grad_ptr, gscale):
+        check(lib().motifs_model_adabelief_dev(self._h, _p(grad_ptr), float(gscale)))
+
+    def l1_syntax(self):
+        out = C.c_float(0)
+        check(lib().motifs_model_l1_syntax(self._h, C.byref(out)))
+        return out.value
+
+    def train_step(self, codes, n_groups, want_l1=True):
+        codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        assert codes.shape == (n_groups * self.hp.batch_size, self.L), codes.shape
+        loss = np.zeros(n_groups, np.float32)
+        l1 = C.c_float(0)
+        check(lib().motifs_model_train_step(self._h, _np_ptr(codes), int(n_groups), _np_ptr(loss),
+                                            C.byref(l1) if want_l1 else None))
+        return loss, l1.value
+
+    def retrieve_codes(self, data, kind, N, cap=None):
+        data = np.ascontiguousarray(data)
+        n_out = _i64(0)
+        if cap is None:
+            cap = int(N) * max(4 * self.hp.q, 64)
+        out = np.zeros(max(cap, 1), dtype=CODE_DTYPE)
+        check(lib().motifs_model_retrieve_codes(self._h, _np_ptr(data), int(kind), int(N), _np_ptr(out), int(cap), C.byref(n_out)))
+        return out[: n_out.value]
+
+    def dump(self, name):
+        n = _i64(0)
+        check(lib().motifs_model_dump(self._h, name.encode(), None, 0, C.byref(n)))
+        out = np.zeros(n.value, np.float32)
+        check(lib().motifs_model_dump(self._h, name.encode(), _np_ptr(out), n.value, C.byref(n)))
+        return out

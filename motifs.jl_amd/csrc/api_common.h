@@ -40,6 +40,7 @@ enum KernelSlot {
     KS_SCAN_COUNT = 2,
     KS_SCAN_OFFSETS = 3,
     KS_SCAN_FILL = 4,
+    KS_TRAIN_STEP = 5,
     KS_COUNT_
 };
 

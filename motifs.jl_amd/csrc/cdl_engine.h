@@ -1,0 +1,104 @@
+// cdl_engine.h — a small reverse-mode engine for the unrolled-ADMM sparse-coding
+// graph of src/model.jl, batched over G independent mini-batches ("groups" of
+// batch_size sequences, the reference's unit of coupling: median mask
+// model.jl:194-204, batch sums :285/:300, loss 1/B :311).
+//
+// Everything is float32 on the device.  Tensors are flat arrays carved from one
+// arena; every forward primitive pushes the closure of its vector-Jacobian
+// product on a tape, and backward() replays the tape in reverse — the role
+// Zygote plays in the reference (train.jl:42-44).  The reference's stride-1
+// convolutions + masks are stored in their compact stride-4 form:
+//   img   [S][c][2M]   code images ZY, FX, duals (row = aligned position, col = filter/strand)
+//   x     [S][l][K]    syntax codes
+//   sig   [S][4L]      one-hot sequences, reconstructions, residuals
+//   D     [g][M][4fl]  filters in the reference layout (model.jl:67-90: D[(p-1)*4+a, 1, m])
+//   F     [g][K][2M][h] syntax filters in the reference layout (F[i, j, 1, k])
+// with g = 1 (shared parameters) or g = G (after the per-batch D/F updates).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <functional>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace motifs {
+
+struct TNode {
+    float* v = nullptr;   // values
+    float* g = nullptr;   // gradient (allocated on first use, zero-initialised)
+    size_t n = 0;
+    bool needs_grad = false;
+};
+typedef TNode* Tensor;    // nodes are owned by the engine and die at reset()
+
+struct Arena {
+    char* base = nullptr;
+    size_t cap = 0, off = 0, peak = 0;
+    float* alloc(size_t n_floats) {
+        size_t bytes = (n_floats * 4 + 255) & ~(size_t)255;
+        if (off + bytes > cap) return nullptr;
+        float* p = (float*)(base + off);
+        off += bytes;
+        if (off > peak) peak = off;
+        return p;
+    }
+    void reset() { off = 0; }
+};
+
+// Toeplitz GEMM geometry: C[s][p][n] = sum_q Aw(s,p,q) * B[grp(s)][q][n],
+// Aw(s,p,q) = A[s*lda + e], e = a0 + p*sa + q, zero when e is outside [0, amax).
+struct ToepGeom {
+    int S, P, Q, N;        // sequences, output rows, reduction length, output channels
+    int sa, a0, amax;      // row stride, window offset, valid flat range of A per sequence
+    int64_t lda, ldc;      // elements per sequence of A and C
+    int B;                 // sequences per group
+    int64_t ldb;           // elements per group of Bm (0 = shared)
+};
+
+struct Engine {
+    hipStream_t st = nullptr;
+    Arena arena;
+    std::vector<std::function<void()>> tape;
+    std::vector<TNode*> nodes;
+    bool recording = true;
+    bool failed = false;           // arena exhausted
+    std::map<std::string, Tensor> named;
+    bool keep_named = false;
+
+    ~Engine() { reset(); }
+    void reset();                  // drop every node and the tape, rewind the arena
+    Tensor make(size_t n, bool needs_grad);
+    Tensor wrap(float* v, float* g, size_t n, bool needs_grad);   // external storage (parameters)
+    float* grad(Tensor t);         // allocate + zero on first use
+    void note(const char* name, Tensor t) {
+        if (keep_named) named[name] = t;
+    }
+    void backward();
+
+    // ---- primitives (each records its VJP) ----
+    Tensor lin(Tensor x, float a, Tensor y, float b, float cst);          // a*x + b*y(bcast modulo y.n) + cst
+    Tensor mul(Tensor x, Tensor y);                                       // x .* y (y broadcast modulo y.n)
+    Tensor relu(Tensor x);
+    Tensor maskmul(Tensor x, const float* mask, float c);                 // c * mask .* x, mask constant
+    Tensor expo(Tensor x);
+    Tensor norm4(Tensor x);                                               // x / sum over each 4 consecutive
+    Tensor norml2(Tensor x, int seg);                                     // x / ||x|| per segment
+    Tensor sumsq_groups(Tensor x, float coef, int groups);                // [groups]: coef * sum x^2 per group
+    Tensor toep(Tensor A, Tensor Bm, const ToepGeom& gm);                 // Toeplitz GEMM
+    Tensor wgrad(Tensor A, Tensor C, const ToepGeom& gm);                 // [G][Q][N] = sum_{s,p} Aw * C
+    Tensor expandD(Tensor D, int g, int M, int fl);                       // [g][M][4fl] -> [g][fl*4][2M]
+    Tensor collapseD(Tensor GA, int g, int M, int fl);                    // adjoint of expandD
+    Tensor swap02(Tensor x, int g, int d0, int d1, int d2);               // per group [d0][d1][d2] -> [d2][d1][d0]
+    Tensor flipT(Tensor Bm, int g, int H, int W, int N);                  // [H][W][N] -> [H][N][W], H reversed
+};
+
+// selections (constants in the backward: @ignore, model.jl:190, :208)
+void topq_mask(hipStream_t st, const float* X, float* bitmat, int S, int n_per_seq, int q);
+void median_mask(hipStream_t st, const float* ZY, float* mask, int G, int n_per_group);
+void onehot_from_codes(hipStream_t st, const uint8_t* codes, int pitch, float* S, int nseq, int L);
+void adabelief_step(hipStream_t st, float* x, float* m, float* s, const float* grad, size_t n, float gscale, float eta,
+                    float b1, float b2, float eps, float b1p, float b2p);
+
+}  // namespace motifs

@@ -1,0 +1,635 @@
+// cdl_model.hip — the unrolled-ADMM graph of src/model.jl on the engine of
+// cdl_engine.h, the training step of src/train.jl:41-52 and the code retrieval of
+// src/inference/_1_code_retrieval.jl:33-56, behind the C ABI of motifs_hip.h.
+//
+// The graph is the reference's, function by function (cited below), written on
+// the compact stride-4 tensors: `z_mask_n`, `mapclarge` and `mapdrange`
+// (model.jl:39-65) only encode "every 4th row" and "keep f_len lags" and vanish.
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "api_common.h"
+#include "cdl_engine.h"
+
+using namespace motifs;
+
+struct motifs_model {
+    motifs_ctx* ctx = nullptr;
+    motifs_hparams hp{};
+    int L = 0;                       // bp
+    int fl, f_len, M, twoM, h, K, q, B, L4, c, l;
+    size_t nD, nF, nV, nP;           // parameter counts: D, F, the 33 vector entries, total
+    float warm[3] = {0, 0, 0};       // lambda_sparsity_warmup, lambda_stepsize_warmup, omega_stepsize_warmup (not trained)
+    float* params = nullptr;         // device [D | F | vecs]
+    float* grads = nullptr;          // device, same layout
+    float* ada_m = nullptr;
+    float* ada_s = nullptr;
+    double b1p = 0.9, b2p = 0.999;   // running powers of beta (Flux AdaBelief state)
+    Engine eng;
+    size_t arena_bytes = 0;
+    // vector offsets inside the 33-entry block, Flux.params order (model.jl:68-82)
+    int o_ls, o_ks, o_lst, o_ost, o_kst, o_pen, o_mu;
+    Tensor last_X = nullptr;
+    int last_groups = 0;
+};
+
+namespace {
+
+struct Graph {
+    motifs_model* m;
+    Engine& e;
+    int G, S;
+    ToepGeom gD1, gD2, gF1, gF2;
+    Tensor Sone;
+
+    Graph(motifs_model* mm, int groups) : m(mm), e(mm->eng), G(groups), S(groups * mm->B) {
+        const int L4 = m->L4, c = m->c, l = m->l, twoM = m->twoM, K = m->K, h = m->h, fl = m->fl;
+        gD1 = ToepGeom{S, c, 4 * fl, twoM, 4, 0, L4, L4, (int64_t)c * twoM, m->B, 0};
+        gD2 = ToepGeom{S, m->L, fl * twoM, 4, twoM, -(fl - 1) * twoM, c * twoM, (int64_t)c * twoM, L4, m->B, 0};
+        gF1 = ToepGeom{S, l, h * twoM, K, twoM, 0, c * twoM, (int64_t)c * twoM, (int64_t)l * K, m->B, 0};
+        gF2 = ToepGeom{S, c, h * K, twoM, K, -(h - 1) * K, l * K, (int64_t)l * K, (int64_t)c * twoM, m->B, 0};
+    }
+    // geometry with the filter stride of a bank that has `g` copies (1 = shared)
+    ToepGeom with(const ToepGeom& gm, int g) const {
+        ToepGeom r = gm;
+        r.ldb = g == 1 ? 0 : (int64_t)gm.Q * gm.N;
+        return r;
+    }
+    Tensor sq(Tensor x) { return e.mul(x, x); }
+
+    // cat_ZY (model.jl:206-210): magnifying_factor * (ZY >= median of the positive entries of the mini-batch) .* ZY
+    Tensor cat_ZY(Tensor ZY) {
+        Tensor mask = e.make(ZY->n, false);
+        if (e.failed) return ZY;
+        median_mask(e.st, ZY->v, mask->v, G, (int)(ZY->n / G));
+        return e.maskmul(ZY, mask->v, m->hp.magnifying_factor);
+    }
+    // project_X (model.jl:181-192): keep the entries >= the q-th largest of each sequence
+    Tensor project_X(Tensor Xu) {
+        Tensor bit = e.make(Xu->n, false);
+        if (e.failed) return Xu;
+        topq_mask(e.st, Xu->v, bit->v, S, m->l * m->K, m->q);
+        return e.maskmul(Xu, bit->v, 1.0f);
+    }
+    // the two filter banks in GEMM layout, analysis and (flipped) synthesis form
+    struct Bank {
+        Tensor an, syn;
+        int g;
+    };
+    Bank bankD(Tensor D, int g) {   // D [g][M][4fl]
+        Tensor DA = e.expandD(D, g, m->M, m->fl);
+        return Bank{DA, e.flipT(DA, g, m->fl, 4, m->twoM), g};
+    }
+    Bank bankF(Tensor F, int g) {   // F [g][K][2M][h]
+        Tensor FA = e.swap02(F, g, m->K, m->twoM, m->h);
+        return Bank{FA, e.flipT(FA, g, m->h, m->twoM, m->K), g};
+    }
+    Tensor synD(Tensor ZY, const Bank& b) { return e.toep(ZY, b.syn, with(gD2, b.g)); }     // sum_m conv(Z,D)+conv(Y,D,flipped)
+    Tensor anaD(Tensor sig, const Bank& b) { return e.toep(sig, b.an, with(gD1, b.g)); }    // [conv(.,D,flipped) | conv(.,D)] rows 1:4:end
+    Tensor synF(Tensor X, const Bank& b) { return e.toep(X, b.syn, with(gF2, b.g)); }       // sum(conv(X,F,pad,groups=K),dims=3)
+    Tensor anaF(Tensor img, const Bank& b) { return e.toep(img, b.an, with(gF1, b.g)); }    // conv(img,F,flipped)
+};
+
+struct Scalars {
+    std::vector<Tensor> ls, ks, lst, ost, kst, pen, mu;   // prepped (squared), model.jl:154-163
+};
+
+}  // namespace
+
+static Scalars prep_scalars(motifs_model* m, Graph& gr, bool train) {
+    Engine& e = m->eng;
+    float* v = m->params + m->nD + m->nF;
+    float* g = m->grads + m->nD + m->nF;
+    auto block = [&](int off, int n) {
+        std::vector<Tensor> out;
+        for (int i = 0; i < n; i++) {
+            Tensor raw = e.wrap(v + off + i, g + off + i, 1, train);
+            out.push_back(gr.sq(raw));
+        }
+        return out;
+    };
+    Scalars s;
+    const int x = m->hp.num_pass_xyz, d = m->hp.num_pass_df;
+    s.ls = block(m->o_ls, x);
+    s.ks = block(m->o_ks, d);
+    s.lst = block(m->o_lst, x);
+    s.ost = block(m->o_ost, x);
+    s.kst = block(m->o_kst, d);
+    s.pen = block(m->o_pen, x);
+    s.mu = block(m->o_mu, d);
+    return s;
+}
+
+// ADMM_XYZ (model.jl:330-357) on G mini-batches.  Returns ZY (unmagnified codes) and X.
+static void admm_xyz(motifs_model* m, Graph& gr, const Scalars& sc, const Graph::Bank& bD, const Graph::Bank& bF,
+                     Tensor& ZY, Tensor& X) {
+    Engine& e = m->eng;
+    const float lspw = m->warm[0] * m->warm[0], lsw = m->warm[1] * m->warm[1], osw = m->warm[2] * m->warm[2];
+    // warm-up (:224-232, :171-179, :212-216)
+    Tensor raw = gr.anaD(gr.Sone, bD);                                   // D'S | DS on the aligned rows
+    ZY = e.relu(e.lin(raw, lsw, nullptr, 0.0f, -lspw * lsw));
+    X = gr.project_X(e.lin(gr.anaF(gr.cat_ZY(ZY), bF), osw, nullptr, 0.0f, 0.0f));
+    Tensor FX = gr.synF(X, bF);
+    Tensor ab = nullptr;                                                  // scaled duals alpha|beta, zero at start (:338)
+    e.note("ZY0", ZY);
+    e.note("X0", X);
+    for (int t = 0; t < m->hp.num_pass_xyz; t++) {
+        // update_ZY (:237-245)
+        Tensor diff = e.lin(gr.synD(ZY, bD), 1.0f, gr.Sone, -1.0f, 0.0f);
+        Tensor g1 = gr.anaD(diff, bD);
+        Tensor FXab = ab ? e.lin(FX, 1.0f, ab, 1.0f, 0.0f) : FX;
+        Tensor inner = e.lin(ZY, 1.0f, FXab, -1.0f, 0.0f);
+        Tensor grad = e.lin(g1, 1.0f, e.mul(inner, sc.pen[t]), 1.0f, 0.0f);
+        Tensor u = e.lin(e.lin(ZY, 1.0f, e.mul(grad, sc.lst[t]), -1.0f, 0.0f), 1.0f, e.mul(sc.ls[t], sc.lst[t]), -1.0f, 0.0f);
+        ZY = e.relu(u);
+        // update_X (:247-254); `sum(FX, dims=3)` is a no-op on the already summed FX
+        Tensor ZYm = gr.cat_ZY(ZY);
+        Tensor rhs = ab ? e.lin(ZYm, 1.0f, ab, -1.0f, 0.0f) : ZYm;
+        Tensor xg = gr.anaF(e.lin(FX, 1.0f, rhs, -1.0f, 0.0f), bF);
+        X = gr.project_X(e.lin(X, 1.0f, e.mul(xg, sc.ost[t]), -1.0f, 0.0f));
+        // (:263-266)
+        FX = gr.synF(X, bF);
+        Tensor ab1 = ab ? e.lin(ab, 1.0f, FX, 1.0f, 0.0f) : FX;
+        ab = e.lin(ab1, 1.0f, ZY, -1.0f, 0.0f);
+    }
+    e.note("ZY", ZY);
+    e.note("X", X);
+}
+
+// forward_pass_return_loss (model.jl:375-395) for G mini-batches; per-group losses in `loss` ([G]).
+static Tensor forward_loss(motifs_model* m, Graph& gr, bool train) {
+    Engine& e = m->eng;
+    Tensor Draw = e.wrap(m->params, m->grads, m->nD, train);
+    Tensor Fraw = e.wrap(m->params + m->nD, m->grads + m->nD, m->nF, train);
+    Scalars sc = prep_scalars(m, gr, train);
+    // prep_filters (:139-146), prep_syntax_filters (:148-151)
+    Tensor Dp = e.norm4(e.lin(gr.sq(Draw), 1.0f, nullptr, 0.0f, 0.001f));
+    Tensor Fp = e.norml2(gr.sq(Fraw), m->h * m->twoM);
+    e.note("Dp", Dp);
+    e.note("Fp", Fp);
+    Graph::Bank bD = gr.bankD(Dp, 1), bF = gr.bankF(Fp, 1);
+    Tensor ZY, X;
+    admm_xyz(m, gr, sc, bD, bF, ZY, X);
+
+    // ADMM_DF (:362-373)
+    Tensor ZYm = gr.cat_ZY(ZY);
+    Tensor Dc = Dp, Fc = Fp, theta = nullptr;
+    int gD = 1, gF = 1;
+    Graph::Bank bDc = bD, bFc = bF;
+    const int G = gr.G;
+    for (int t = 0; t < m->hp.num_pass_df; t++) {
+        // update_D (:275-290): D_grad = Z'(sumZD + sumYRD + S) + reverse(Y'(...)), only the f_len needed lags
+        Tensor sig = e.lin(gr.synD(ZY, bDc), 1.0f, gr.Sone, 1.0f, 0.0f);
+        Tensor Dgrad = e.collapseD(e.wgrad(sig, ZY, gr.gD1), G, m->M, m->fl);
+        Tensor ex = e.expo(e.mul(Dgrad, e.lin(sc.mu[t], -1.0f, nullptr, 0.0f, 0.0f)));
+        Dc = e.norm4(e.mul(ex, Dc));
+        gD = G;
+        bDc = gr.bankD(Dc, gD);
+        // update_F (:292-308)
+        Tensor FXc = gr.synF(X, bFc);
+        Tensor tgt = theta ? e.lin(ZYm, 1.0f, theta, 1.0f, 0.0f) : ZYm;
+        Tensor R = e.lin(FXc, 1.0f, tgt, -1.0f, 0.0f);
+        Tensor Fgrad = e.swap02(e.wgrad(R, X, gr.gF1), G, m->h, m->twoM, m->K);
+        Tensor t2 = e.lin(e.mul(Fgrad, sc.kst[t]), -1.0f, Fc, 1.0f, 0.0f);
+        Tensor t3 = e.lin(t2, 1.0f, e.mul(sc.kst[t], sc.ks[t]), -1.0f, 0.0f);
+        Fc = e.norml2(e.relu(t3), m->h * m->twoM);
+        gF = G;
+        bFc = gr.bankF(Fc, gF);
+        // theta (:370)
+        Tensor FXn = gr.synF(X, bFc);
+        Tensor th1 = theta ? e.lin(theta, 1.0f, FXn, 1.0f, 0.0f) : FXn;
+        theta = e.lin(th1, 1.0f, ZYm, -1.0f, 0.0f);
+    }
+    e.note("Dfinal", Dc);
+    e.note("Ffinal", Fc);
+    // loss (:310-325)
+    const float nf = 1.0f / (float)m->B;
+    Tensor r1 = e.lin(gr.synD(ZY, bDc), 1.0f, gr.Sone, -1.0f, 0.0f);
+    Tensor r2 = e.lin(gr.synF(X, bFc), 1.0f, ZYm, -1.0f, 0.0f);
+    Tensor Lv = e.lin(e.sumsq_groups(r1, nf, G), 1.0f, e.sumsq_groups(r2, nf, G), 1.0f, 0.0f);
+    (void)gD;
+    (void)gF;
+    return Lv;
+}
+
+static int check_model(motifs_model* m, const char* fn) {
+    if (!m || !m->ctx) {
+        set_error("%s: null model", fn);
+        return MOTIFS_ERR_INVALID;
+    }
+    return MOTIFS_OK;
+}
+
+// one-hot signal of G*B sequences from a code matrix (rows of motifs_codes_pitch(L) bytes)
+static Tensor make_onehot(motifs_model* m, const uint8_t* codes_dev, int S) {
+    Tensor t = m->eng.make((size_t)S * m->L4, false);
+    if (!m->eng.failed) onehot_from_codes(m->eng.st, codes_dev, motifs_codes_pitch(m->L), t->v, S, m->L);
+    return t;
+}
+
+__global__ void k_fill(float* x, size_t n, float v) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) x[i] = v;
+}
+__global__ void k_abs_sum(const float* x, size_t n, float* out) {
+    double acc = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) acc += fabsf(x[i]);
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, (float)acc);
+}
+
+// ---- code retrieval kernels ---------------------------------------------------------------------
+__global__ void k_count_pos(const float* X, int n, int32_t* cnt) {
+    const float* xs = X + (size_t)blockIdx.x * n;
+    int c = 0;
+    for (int i = threadIdx.x; i < n; i += 64) c += xs[i] > 0.0f;
+    for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d);
+    if (threadIdx.x == 0) cnt[blockIdx.x] = c;
+}
+// one wave per sequence; records in the order of `findall(X .> 0)` over (l, 1, K, B):
+// position fastest, then syntax filter, then sequence (_1_code_retrieval.jl:27-31)
+__global__ void k_write_codes(const float* X, int l, int K, const int64_t* off, int64_t seq0, motifs_code_rec* out) {
+    const float* xs = X + (size_t)blockIdx.x * l * K;        // [l][K]
+    int64_t at = off[blockIdx.x];
+    const int lane = threadIdx.x;
+    for (int k = 0; k < K; k++)
+        for (int p0 = 0; p0 < l; p0 += 64) {
+            const int p = p0 + lane;
+            const float v = p < l ? xs[(size_t)p * K + k] : 0.0f;
+            const bool hit = v > 0.0f;
+            const uint64_t mask = __builtin_amdgcn_ballot_w64(hit);
+            if (hit) {
+                const int r = __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+                motifs_code_rec rec;
+                rec.position = (uint16_t)(p + 1);
+                rec.fil = (uint16_t)(k + 1);
+                rec.seq = (uint32_t)(seq0 + blockIdx.x + 1);
+                rec.mag = __half_as_ushort(__float2half_rn(v));
+                rec.pad_ = 0;
+                out[at + r] = rec;
+            }
+            at += __builtin_popcountll(mask);
+        }
+}
+
+extern "C" {
+
+int motifs_model_create(motifs_ctx* ctx, const motifs_hparams* hp, int L, size_t arena_bytes, motifs_model** out) {
+    if (!ctx || !hp || !out || L <= 0) {
+        set_error("motifs_model_create: bad argument");
+        return MOTIFS_ERR_INVALID;
+    }
+    *out = nullptr;
+    const int c = L - hp->filter_len + 1, l = c - hp->h + 1;
+    if (hp->filter_len < 1 || hp->M < 1 || hp->h < 1 || hp->K < 1 || hp->batch_size < 1 || hp->num_pass_xyz < 1 ||
+        hp->num_pass_df < 1 || c < 1 || l < 1 || hp->q < 1 || hp->q > l * hp->K) {
+        set_error("motifs_model_create: hyper-parameters do not fit L=%d (c=%d, l=%d, q=%d)", L, c, l, hp->q);
+        return MOTIFS_ERR_INVALID;
+    }
+    MOTIFS_HIP_CHECK(hipSetDevice(ctx->device));
+    motifs_model* m = new motifs_model();
+    m->ctx = ctx;
+    m->hp = *hp;
+    m->L = L;
+    m->fl = hp->filter_len;
+    m->f_len = 4 * hp->filter_len;
+    m->M = hp->M;
+    m->twoM = 2 * hp->M;
+    m->h = hp->h;
+    m->K = hp->K;
+    m->q = hp->q;
+    m->B = hp->batch_size;
+    m->L4 = 4 * L;
+    m->c = c;
+    m->l = l;
+    m->nD = (size_t)m->M * m->f_len;
+    m->nF = (size_t)m->K * m->twoM * m->h;
+    const int x = hp->num_pass_xyz, d = hp->num_pass_df;
+    m->o_ls = 0;
+    m->o_ks = m->o_ls + x;
+    m->o_lst = m->o_ks + d;
+    m->o_ost = m->o_lst + x;
+    m->o_kst = m->o_ost + x;
+    m->o_pen = m->o_kst + d;
+    m->o_mu = m->o_pen + x;
+    m->nV = (size_t)(m->o_mu + d);
+    m->nP = m->nD + m->nF + m->nV;
+    MOTIFS_HIP_CHECK(hipMalloc(&m->params, m->nP * 4));
+    MOTIFS_HIP_CHECK(hipMalloc(&m->grads, m->nP * 4));
+    MOTIFS_HIP_CHECK(hipMalloc(&m->ada_m, m->nP * 4));
+    MOTIFS_HIP_CHECK(hipMalloc(&m->ada_s, m->nP * 4));
+    MOTIFS_HIP_CHECK(hipMemset(m->params, 0, m->nP * 4));
+    MOTIFS_HIP_CHECK(hipMemset(m->ada_m, 0, m->nP * 4));
+    MOTIFS_HIP_CHECK(hipMemset(m->ada_s, 0, m->nP * 4));
+    m->arena_bytes = arena_bytes ? arena_bytes : ((size_t)8 << 30);
+    void* base = nullptr;
+    MOTIFS_HIP_CHECK(hipMalloc(&base, m->arena_bytes));
+    m->eng.arena.base = (char*)base;
+    m->eng.arena.cap = m->arena_bytes;
+    m->eng.st = ctx->stream;
+    *out = m;
+    return MOTIFS_OK;
+}
+
+void motifs_model_destroy(motifs_model* m) {
+    if (!m) return;
+    (void)hipSetDevice(m->ctx->device);
+    (void)hipStreamSynchronize(m->ctx->stream);
+    m->eng.reset();
+    for (void* p : {(void*)m->params, (void*)m->grads, (void*)m->ada_m, (void*)m->ada_s, (void*)m->eng.arena.base})
+        if (p) (void)hipFree(p);
+    delete m;
+}
+
+int motifs_model_sizes(motifs_model* m, int64_t* nD, int64_t* nF, int64_t* nV, int64_t* c, int64_t* l) {
+    int r = check_model(m, "motifs_model_sizes");
+    if (r) return r;
+    if (nD) *nD = (int64_t)m->nD;
+    if (nF) *nF = (int64_t)m->nF;
+    if (nV) *nV = (int64_t)m->nV;
+    if (c) *c = m->c;
+    if (l) *l = m->l;
+    return MOTIFS_OK;
+}
+
+int motifs_model_set_params(motifs_model* m, const float* D, const float* F, const float* warmup3, const float* vecs) {
+    int r = check_model(m, "motifs_model_set_params");
+    if (r) return r;
+    MOTIFS_HIP_CHECK(hipSetDevice(m->ctx->device));
+    hipStream_t st = m->ctx->stream;
+    if (D) MOTIFS_HIP_CHECK(hipMemcpyAsync(m->params, D, m->nD * 4, hipMemcpyHostToDevice, st));
+    if (F) MOTIFS_HIP_CHECK(hipMemcpyAsync(m->params + m->nD, F, m->nF * 4, hipMemcpyHostToDevice, st));
+    if (vecs) MOTIFS_HIP_CHECK(hipMemcpyAsync(m->params + m->nD + m->nF, vecs, m->nV * 4, hipMemcpyHostToDevice, st));
+    if (warmup3) memcpy(m->warm, warmup3, 12);
+    MOTIFS_HIP_CHECK(hipStreamSynchronize(st));
+    return MOTIFS_OK;
+}
+
+int motifs_model_get_params(motifs_model* m, float* D, float* F, float* warmup3, float* vecs) {
+    int r = check_model(m, "motifs_model_get_params");
+    if (r) return r;
+    MOTIFS_HIP_CHECK(hipSetDevice(m->ctx->device));
+    hipStream_t st = m->ctx->stream;
+    if (D) MOTIFS_HIP_CHECK(hipMemcpyAsync(D, m->params, m->nD * 4, hipMemcpyDeviceToHost, st));
+    if (F) MOTIFS_HIP_CHECK(hipMemcpyAsync(F, m->params + m->nD, m->nF * 4, hipMemcpyDeviceToHost, st));
+    if (vecs) MOTIFS_HIP_CHECK(hipMemcpyAsync(vecs, m->params + m->nD + m->nF, m->nV * 4, hipMemcpyDeviceToHost, st));
+    if (warmup3) memcpy(warmup3, m->warm, 12);
+    MOTIFS_HIP_CHECK(hipStreamSynchronize(st));
+    return MOTIFS_OK;
+}
+
+// ucdl(hp) (model.jl:84-100) with a seeded splitmix64 stream (the reference draws from Julia's
+// unseeded global RNG, so only the distribution can be reproduced).
+int motifs_model_init_random(motifs_model* m, uint64_t seed) {
+    int r = check_model(m, "motifs_model_init_random");
+    if (r) return r;
+    uint64_t s = seed;
+    auto next = [&]() {
+        uint64_t z = (s += 0x9e3779b97f4a7c15ull);
+        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+        z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+        return z ^ (z >> 31);
+    };
+    auto uni = [&]() { return (double)(next() >> 11) * (1.0 / 9007199254740992.0); };
+    auto nrm = [&]() {
+        double u1 = uni(), u2 = uni();
+        if (u1 < 1e-300) u1 = 1e-300;
+        return std::sqrt(-2.0 * std::log(u1)) * std::cos(6.283185307179586 * u2);
+    };
+    std::vector<float> D(m->nD), F(m->nF), V(m->nV);
+    for (int mm = 0; mm < m->M; mm++)            // randomly_initialize_filters (MOTIFs.jl:17-33) then sqrt (:88)
+        for (int k = 0; k < m->fl; k++) {
+            double u[3] = {uni(), uni(), uni()};
+            std::sort(u, u + 3);
+            const double sp[4] = {u[0], u[1] - u[0], u[2] - u[1], 1.0 - u[2]};
+            for (int a = 0; a < 4; a++) D[(size_t)mm * m->f_len + 4 * k + a] = (float)std::sqrt(sp[a]);
+        }
+    for (size_t i = 0; i < m->nF; i++) F[i] = (float)std::fabs(0.1 * nrm());   // :90
+    float warm[3];
+    warm[0] = (float)(0.05 * uni());
+    for (size_t i = 0; i < m->nV; i++) V[i] = (float)(0.05 * uni());
+    warm[1] = (float)(0.05 * uni());
+    warm[2] = (float)(0.05 * uni());
+    m->b1p = 0.9;
+    m->b2p = 0.999;
+    MOTIFS_HIP_CHECK(hipMemset(m->ada_m, 0, m->nP * 4));
+    MOTIFS_HIP_CHECK(hipMemset(m->ada_s, 0, m->nP * 4));
+    return motifs_model_set_params(m, D.data(), F.data(), warm, V.data());
+}
+
+// loss and gradient of G mini-batches: train.jl:42-44.  grad_flat_dev receives the SUM over the
+// groups of d loss_g / d [D | F | vecs]; loss_dev the G losses.
+int motifs_model_loss_grad_dev(motifs_model* m, const uint8_t* codes_dev, int n_groups, float* loss_dev,
+                               float* grad_flat_dev, int keep_intermediates) {
+    int r = check_model(m, "motifs_model_loss_grad_dev");
+    if (r) return r;
+    if (!codes_dev || n_groups < 1 || (int64_t)n_groups * m->B > 65535) {
+        set_error("motifs_model_loss_grad_dev: bad argument (n_groups=%d)", n_groups);
+        return MOTIFS_ERR_INVALID;
+    }
+    MOTIFS_HIP_CHECK(hipSetDevice(m->ctx->device));
+    Engine& e = m->eng;
+    e.st = m->ctx->stream;
+    e.reset();
+    e.recording = grad_flat_dev != nullptr;
+    e.keep_named = keep_intermediates != 0;
+    MOTIFS_HIP_CHECK(hipMemsetAsync(m->grads, 0, m->nP * 4, e.st));
+    KernelTimer tm(m->ctx, KS_TRAIN_STEP);
+    Graph gr(m, n_groups);
+    gr.Sone = make_onehot(m, codes_dev, gr.S);
+    Tensor Lv = forward_loss(m, gr, e.recording);
+    if (!e.failed && e.recording) {
+        float* g = e.grad(Lv);
+        if (g) hipLaunchKernelGGL(k_fill, dim3(1), dim3(256), 0, e.st, g, (size_t)n_groups, 1.0f);
+        e.backward();
+    }
+    if (e.failed) {
+        set_error("engine arena exhausted (%zu bytes): lower n_groups or create the model with a larger arena",
+                  m->arena_bytes);
+        return MOTIFS_ERR_UNSUPPORTED;
+    }
+    if (loss_dev) MOTIFS_HIP_CHECK(hipMemcpyAsync(loss_dev, Lv->v, (size_t)n_groups * 4, hipMemcpyDeviceToDevice, e.st));
+    if (grad_flat_dev) MOTIFS_HIP_CHECK(hipMemcpyAsync(grad_flat_dev, m->grads, m->nP * 4, hipMemcpyDeviceToDevice, e.st));
+    MOTIFS_HIP_CHECK(hipGetLastError());
+    return MOTIFS_OK;
+}
+
+// Flux.Optimise.update!(opt, ps, gs) with opt = AdaBelief() (train.jl:35, :46) on the flat parameter block;
+// the gradient used is gscale * grad (1/n_groups turns the summed gradient into the mean).
+int motifs_model_adabelief_dev(motifs_model* m, const float* grad_flat_dev, float gscale) {
+    int r = check_model(m, "motifs_model_adabelief_dev");
+    if (r) return r;
+    if (!grad_flat_dev) return MOTIFS_ERR_INVALID;
+    MOTIFS_HIP_CHECK(hipSetDevice(m->ctx->device));
+    adabelief_step(m->ctx->stream, m->params, m->ada_m, m->ada_s, grad_flat_dev, m->nP, gscale, 1e-3f, 0.9f, 0.999f, 1e-8f,
+                   (float)m->b1p, (float)m->b2p);
+    m->b1p *= 0.9;
+    m->b2p *= 0.999;
+    MOTIFS_HIP_CHECK(hipGetLastError());
+    return MOTIFS_OK;
+}
+
+// sum(abs.(prep_syntax_filters(cdl.F))) (train.jl:47): the early-stop statistic
+int motifs_model_l1_syntax(motifs_model* m, float* out) {
+    int r = check_model(m, "motifs_model_l1_syntax");
+    if (r) return r;
+    MOTIFS_HIP_CHECK(hipSetDevice(m->ctx->device));
+    Engine& e = m->eng;
+    e.st = m->ctx->stream;
+    e.reset();
+    e.recording = false;
+    Tensor Fraw = e.wrap(m->params + m->nD, nullptr, m->nF, false);
+    Tensor Fp = e.norml2(e.mul(Fraw, Fraw), m->h * m->twoM);
+    Tensor acc = e.make(1, false);
+    if (e.failed) return MOTIFS_ERR_UNSUPPORTED;
+    MOTIFS_HIP_CHECK(hipMemsetAsync(acc->v, 0, 4, e.st));
+    hipLaunchKernelGGL(k_abs_sum, dim3(64), dim3(256), 0, e.st, Fp->v, m->nF, acc->v);
+    MOTIFS_HIP_CHECK(hipMemcpyAsync(out, acc->v, 4, hipMemcpyDeviceToHost, e.st));
+    MOTIFS_HIP_CHECK(hipStreamSynchronize(e.st));
+    return MOTIFS_OK;
+}
+
+// One optimiser step on host data: the body of the loop at train.jl:40-52 for n_groups mini-batches
+// (n_groups = 1 is exactly the reference step).  codes: n_groups*batch_size rows of L bytes (0..3).
+int motifs_model_train_step(motifs_model* m, const uint8_t* codes, int n_groups, float* loss_out, float* l1F_out) {
+    int r = check_model(m, "motifs_model_train_step");
+    if (r) return r;
+    if (!codes || n_groups < 1) return MOTIFS_ERR_INVALID;
+    MOTIFS_HIP_CHECK(hipSetDevice(m->ctx->device));
+    motifs_ctx* c = m->ctx;
+    const int64_t S = (int64_t)n_groups * m->B;
+    MOTIFS_HIP_CHECK(c->codes.reserve(motifs_codes_bytes(S, m->L)));
+    MOTIFS_HIP_CHECK(c->data_tmp.reserve((size_t)S * m->L + m->nP * 4 + (size_t)n_groups * 4 + 64));
+    MOTIFS_HIP_CHECK(hipMemcpyAsync(c->data_tmp.p, codes, (size_t)S * m->L, hipMemcpyHostToDevice, c->stream));
+    r = motifs_encode_dev(c, c->data_tmp.p, MOTIFS_DATA_CODES_U8, S, m->L, (uint8_t*)c->codes.p, nullptr);
+    if (r) return r;
+    float* gflat = (float*)((char*)c->data_tmp.p + (((size_t)S * m->L + 63) & ~(size_t)63));
+    float* lossd = gflat + m->nP;
+    r = motifs_model_loss_grad_dev(m, (const uint8_t*)c->codes.p, n_groups, lossd, gflat, 0);
+    if (r) return r;
+    r = motifs_model_adabelief_dev(m, gflat, 1.0f / (float)n_groups);
+    if (r) return r;
+    if (loss_out) MOTIFS_HIP_CHECK(hipMemcpyAsync(loss_out, lossd, (size_t)n_groups * 4, hipMemcpyDeviceToHost, c->stream));
+    MOTIFS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (l1F_out) return motifs_model_l1_syntax(m, l1F_out);
+    return MOTIFS_OK;
+}
+
+// code_retrieval (_1_code_retrieval.jl:33-56): ADMM_XYZ only, batches of batch_size in file order,
+// remainder dropped (partial=false, :38); records as `findall(X .> 0)` yields them.
+int motifs_model_retrieve_codes(motifs_model* m, const void* data, int kind, int64_t N, motifs_code_rec* out, int64_t cap,
+                                int64_t* n_out) {
+    int r = check_model(m, "motifs_model_retrieve_codes");
+    if (r) return r;
+    if (!n_out || N < 0 || (N > 0 && !data) || cap < 0 || (cap > 0 && !out) || kind < 0 || kind > 2) {
+        set_error("motifs_model_retrieve_codes: bad argument");
+        return MOTIFS_ERR_INVALID;
+    }
+    *n_out = 0;
+    MOTIFS_HIP_CHECK(hipSetDevice(m->ctx->device));
+    motifs_ctx* c = m->ctx;
+    Engine& e = m->eng;
+    e.st = c->stream;
+    const int64_t nfull = N - N % m->B;
+    // groups per launch: bounded by the arena (forward only keeps ~40 code images alive) and the grid limit
+    const size_t per_group = (size_t)m->B * ((size_t)m->c * m->twoM * 48 + (size_t)m->L4 * 16 + (size_t)m->l * m->K * 24) * 4;
+    int64_t gmax = (int64_t)(m->arena_bytes / 2 / std::max<size_t>(per_group, 1));
+    gmax = std::max<int64_t>(1, std::min<int64_t>(gmax, 65535 / m->B));
+    const size_t elt = kind == MOTIFS_DATA_ONEHOT_F32 ? 16 : kind == MOTIFS_DATA_ONEHOT_F16 ? 8 : 1;
+    const int pitch = motifs_codes_pitch(m->L);
+    int64_t total = 0;
+    bool too_small = false;
+    std::vector<int32_t> h_cnt;
+    std::vector<int64_t> h_off;
+    for (int64_t s0 = 0; s0 < nfull; s0 += gmax * m->B) {
+        const int64_t S = std::min<int64_t>(gmax * m->B, nfull - s0);
+        const int G = (int)(S / m->B);
+        MOTIFS_HIP_CHECK(c->codes.reserve(motifs_codes_bytes(S, m->L)));
+        MOTIFS_HIP_CHECK(c->data_tmp.reserve((size_t)S * m->L * elt + 64));
+        MOTIFS_HIP_CHECK(hipMemcpyAsync(c->data_tmp.p, (const char*)data + (size_t)s0 * m->L * elt, (size_t)S * m->L * elt,
+                                        hipMemcpyHostToDevice, c->stream));
+        MOTIFS_HIP_CHECK(c->small.reserve(4096));
+        int32_t* bad_dev = (int32_t*)c->small.p;
+        MOTIFS_HIP_CHECK(hipMemsetAsync(bad_dev, 0, 4, c->stream));
+        r = motifs_encode_dev(c, c->data_tmp.p, kind, S, m->L, (uint8_t*)c->codes.p, bad_dev);
+        if (r) return r;
+        e.reset();
+        e.recording = false;
+        e.keep_named = false;
+        Graph gr(m, G);
+        gr.Sone = make_onehot(m, (const uint8_t*)c->codes.p, (int)S);
+        Tensor Draw = e.wrap(m->params, nullptr, m->nD, false), Fraw = e.wrap(m->params + m->nD, nullptr, m->nF, false);
+        Scalars sc = prep_scalars(m, gr, false);
+        Tensor Dp = e.norm4(e.lin(gr.sq(Draw), 1.0f, nullptr, 0.0f, 0.001f));
+        Tensor Fp = e.norml2(gr.sq(Fraw), m->h * m->twoM);
+        Graph::Bank bD = gr.bankD(Dp, 1), bF = gr.bankF(Fp, 1);
+        Tensor ZY, X;
+        admm_xyz(m, gr, sc, bD, bF, ZY, X);
+        if (e.failed) {
+            set_error("engine arena exhausted during code retrieval");
+            return MOTIFS_ERR_UNSUPPORTED;
+        }
+        // counts -> host offsets -> ordered records
+        MOTIFS_HIP_CHECK(c->pwmcnt.reserve((size_t)S * 12 + 64));
+        int32_t* cnt_dev = (int32_t*)c->pwmcnt.p;
+        int64_t* off_dev = (int64_t*)((char*)c->pwmcnt.p + (((size_t)S * 4 + 63) & ~(size_t)63));
+        hipLaunchKernelGGL(k_count_pos, dim3((unsigned)S), dim3(64), 0, c->stream, X->v, m->l * m->K, cnt_dev);
+        h_cnt.resize(S);
+        h_off.resize(S);
+        MOTIFS_HIP_CHECK(hipMemcpyAsync(h_cnt.data(), cnt_dev, (size_t)S * 4, hipMemcpyDeviceToHost, c->stream));
+        int32_t h_bad = 0;
+        MOTIFS_HIP_CHECK(hipMemcpyAsync(&h_bad, bad_dev, 4, hipMemcpyDeviceToHost, c->stream));
+        MOTIFS_HIP_CHECK(hipStreamSynchronize(c->stream));
+        if (h_bad) {
+            set_error("data matrix has a column that is neither one-hot nor all-zero");
+            return MOTIFS_ERR_NOT_ONEHOT;
+        }
+        int64_t run = 0;
+        for (int64_t i = 0; i < S; i++) {
+            h_off[i] = run;
+            run += h_cnt[i];
+        }
+        if (total + run > cap) too_small = true;
+        if (!too_small && run > 0) {
+            MOTIFS_HIP_CHECK(hipMemcpyAsync(off_dev, h_off.data(), (size_t)S * 8, hipMemcpyHostToDevice, c->stream));
+            MOTIFS_HIP_CHECK(c->hits_tmp.reserve((size_t)run * sizeof(motifs_code_rec)));
+            hipLaunchKernelGGL(k_write_codes, dim3((unsigned)S), dim3(64), 0, c->stream, X->v, m->l, m->K, off_dev, s0,
+                               (motifs_code_rec*)c->hits_tmp.p);
+            MOTIFS_HIP_CHECK(hipMemcpyAsync(out + total, c->hits_tmp.p, (size_t)run * sizeof(motifs_code_rec),
+                                            hipMemcpyDeviceToHost, c->stream));
+            MOTIFS_HIP_CHECK(hipStreamSynchronize(c->stream));
+        }
+        total += run;
+    }
+    *n_out = total;
+    if (too_small && !(cap == 0 && out == nullptr)) {
+        set_error("code buffer too small: need %lld records, cap %lld", (long long)total, (long long)cap);
+        return MOTIFS_ERR_BUFFER_TOO_SMALL;
+    }
+    return MOTIFS_OK;
+}
+
+// Test hook: copy a named intermediate of the last motifs_model_loss_grad_dev(keep_intermediates=1) call.
+int motifs_model_dump(motifs_model* m, const char* name, float* out, int64_t cap, int64_t* n) {
+    int r = check_model(m, "motifs_model_dump");
+    if (r) return r;
+    auto it = m->eng.named.find(name ? name : "");
+    if (it == m->eng.named.end()) {
+        set_error("motifs_model_dump: no intermediate named '%s'", name ? name : "");
+        return MOTIFS_ERR_INVALID;
+    }
+    if (n) *n = (int64_t)it->second->n;
+    if (out) {
+        if ((int64_t)it->second->n > cap) return MOTIFS_ERR_BUFFER_TOO_SMALL;
+        MOTIFS_HIP_CHECK(hipSetDevice(m->ctx->device));
+        MOTIFS_HIP_CHECK(hipMemcpyAsync(out, it->second->v, it->second->n * 4, hipMemcpyDeviceToHost, m->ctx->stream));
+        MOTIFS_HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
+    }
+    return MOTIFS_OK;
+}
+
+}  // extern "C"

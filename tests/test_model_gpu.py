@@ -1,0 +1,175 @@
+"""Parity of the HIP sparse-coding engine (motifs_model_* through the C ABI) against the CPU oracle
+(oracle/model_oracle.py, a restatement of src/model.jl + train.jl + _1_code_retrieval.jl).
+Tolerance: BASELINE.json north_star asks 1e-5 relative for float32 values; gradients are compared
+relative to the largest entry of each array."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import model_oracle as mo
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+RTOL = 1e-5
+NAMES = ["lambda_sparsity", "kappa_sparsity", "lambda_stepsize", "omega_stepsize", "kappa_stepsize", "D", "F",
+         "penalty_xyz", "mu"]
+
+
+def to_model(pkg, ctx, hp_o, L, cdl_o, arena=1 << 30):
+    md = pkg.model
+    hp = md.Hyperparam(filter_len=hp_o.filter_len, M=hp_o.M, h=hp_o.h, K=hp_o.K, q=hp_o.q, batch_size=hp_o.batch_size,
+                       num_pass_xyz=hp_o.num_pass_xyz, num_pass_df=hp_o.num_pass_df,
+                       magnifying_factor=hp_o.magnifying_factor, gamma=hp_o.gamma)
+    cdl = md.ucdl(hp, L, ctx=ctx, arena_bytes=arena)
+    vecs = {n: getattr(cdl_o, n).detach().numpy() for n in mo.PARAM_VECS}
+    cdl.set_fields(D=cdl_o.D.detach().numpy(), F=cdl_o.F.detach().numpy(),
+                   lambda_sparsity_warmup=cdl_o.lambda_sparsity_warmup,
+                   lambda_stepsize_warmup=cdl_o.lambda_stepsize_warmup,
+                   omega_stepsize_warmup=cdl_o.omega_stepsize_warmup, **vecs)
+    return cdl
+
+
+def gpu_loss_grad(pkg, ctx, cdl, codes, n_groups, keep=False):
+    lib = pkg._lib
+    S, L = codes.shape
+    raw = torch.from_numpy(np.ascontiguousarray(codes, dtype=np.uint8)).cuda()
+    dcodes = torch.zeros(lib.Context.codes_bytes(S, L), dtype=torch.uint8, device="cuda")
+    loss = torch.zeros(n_groups, dtype=torch.float32, device="cuda")
+    grad = torch.zeros(cdl.model.nP, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    ctx.encode_dev(raw.data_ptr(), lib.DATA_CODES_U8, S, L, dcodes.data_ptr())
+    cdl.model.loss_grad_dev(dcodes.data_ptr(), n_groups, loss.data_ptr(), grad.data_ptr(), keep)
+    ctx.synchronize()
+    return loss.cpu().numpy(), grad.cpu().numpy()
+
+
+def split_grad(cdl, flat):
+    m = cdl.model
+    out = {"D": flat[: m.nD], "F": flat[m.nD: m.nD + m.nF]}
+    o = m.nD + m.nF
+    for name, n in zip(pkg_vec_fields(), pkg_vec_sizes(cdl.hp)):
+        out[name] = flat[o:o + n]
+        o += n
+    return out
+
+
+def pkg_vec_fields():
+    return ["lambda_sparsity", "kappa_sparsity", "lambda_stepsize", "omega_stepsize", "kappa_stepsize", "penalty_xyz", "mu"]
+
+
+def pkg_vec_sizes(hp):
+    x, d = hp.num_pass_xyz, hp.num_pass_df
+    return [x, d, x, x, d, x, d]
+
+
+def rel_inf(a, b):
+    a, b = np.asarray(a, np.float64).ravel(), np.asarray(b, np.float64).ravel()
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+def tiny(seed, G=2, B=3, Lbp=30):
+    hp = mo.Hyperparam(filter_len=4, M=5, h=3, K=4, q=6, batch_size=B, num_pass_xyz=2, num_pass_df=2)
+    rng = np.random.default_rng(seed)
+    codes = rng.integers(0, 4, size=(G * B, Lbp)).astype(np.uint8)
+    cdl = mo.UCDL(hp, rng).to(torch.float64)
+    return hp, codes, cdl
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_tiny_loss_grads_and_intermediates(ctx, pkg, seed):
+    hp, codes, cdl_o = tiny(seed)
+    G, B = 2, hp.batch_size
+    cdl = to_model(pkg, ctx, hp, codes.shape[1], cdl_o)
+    loss, flat = gpu_loss_grad(pkg, ctx, cdl, codes, G, keep=True)
+    got = split_grad(cdl, flat)
+    ln = mo.LengthInfo.make(hp, codes.shape[1])
+    projs = mo.Projectors(hp, ln, torch.float64)
+    want = {n: 0.0 for n in NAMES}
+    for g in range(G):
+        val, grads = mo.loss_and_grads(codes[g * B:(g + 1) * B], cdl_o, hp, torch.float64)
+        assert abs(loss[g] - val.item()) <= RTOL * abs(val.item()), (g, loss[g], val.item())
+        for n, gr in zip(NAMES, grads):
+            want[n] = want[n] + gr.numpy()
+        # intermediates of this mini-batch
+        S = mo.onehot_batch(codes[g * B:(g + 1) * B], torch.float64)
+        with torch.no_grad():
+            _, Z, Y, X = mo.retrieve_code(S, cdl_o.to(torch.float64), hp, ln, projs)
+        zy = torch.cat((Z[..., 0::4], Y[..., 0::4]), dim=1).permute(0, 2, 1).numpy()      # [B][c][2M]
+        gzy = cdl.model.dump("ZY").reshape(G, B, ln.c, hp.twoM)[g]
+        assert rel_inf(gzy, zy) <= RTOL
+        gx = cdl.model.dump("X").reshape(G, B, ln.l, hp.K)[g]
+        assert rel_inf(gx, X[:, :, 0, :].permute(0, 2, 1).numpy()) <= RTOL
+    for n in NAMES:                      # the flat gradient is the SUM over the mini-batches
+        assert rel_inf(got[n], want[n]) <= 5 * RTOL, (n, rel_inf(got[n], want[n]))
+
+
+def test_cfg1_golden(ctx, pkg):
+    g = np.load(os.path.join(HERE, "golden", "model_cfg1.npz"))
+    hp = mo.Hyperparam(filter_len=8, M=32)
+    cdl_o = mo.UCDL(hp, np.random.default_rng(0)).to(torch.float64)
+    for n in mo.PARAM_VECS + ["D", "F"]:
+        setattr(cdl_o, n, torch.tensor(g["init_" + n]))
+    cdl_o.lambda_sparsity_warmup, cdl_o.lambda_stepsize_warmup, cdl_o.omega_stepsize_warmup = [float(x) for x in g["warm"]]
+    cdl = to_model(pkg, ctx, hp, 100, cdl_o)
+    codes = g["codes"]
+    loss, flat = gpu_loss_grad(pkg, ctx, cdl, codes, 2)
+    got = split_grad(cdl, flat)
+    for k in range(2):
+        assert abs(loss[k] - g[f"loss{k}"]) <= RTOL * g[f"loss{k}"]
+    for n in NAMES:
+        want = g[f"grad0_{n}"] + g[f"grad1_{n}"]
+        assert rel_inf(got[n], want) <= 5 * RTOL, (n, rel_inf(got[n], want))
+    # code retrieval: positions / filters / sequence numbers exact, magnitudes to one fp16 ulp
+    rec = pkg.model.code_retrieval(codes, cdl)
+    assert np.array_equal(np.stack([rec["position"], rec["fil"], rec["seq"]], 1).astype(np.int64), g["codes_rec"])
+    d = np.abs(rec["mag"].view(np.uint16).astype(np.int64) - g["codes_mag"].astype(np.int64))
+    assert d.max() <= 1
+
+
+def test_train_step_matches_adabelief_oracle(ctx, pkg):
+    hp, codes, cdl_o = tiny(5, G=1)
+    cdl = to_model(pkg, ctx, hp, codes.shape[1], cdl_o)
+    opt = mo.AdaBelief()
+    cdl_ref = cdl_o
+    for step in range(3):                 # three reference steps on the same mini-batch (train.jl:41-46)
+        val, grads = mo.loss_and_grads(codes, cdl_ref, hp, torch.float64)
+        opt.update(cdl_ref, grads)
+        loss, l1 = cdl.model.train_step(codes, 1)
+        assert abs(loss[0] - val.item()) <= 2 * RTOL * abs(val.item())
+        assert abs(l1 - mo.l1_syntax(cdl_ref).item()) <= 1e-4 * l1
+    f = cdl.fields()
+    for n in mo.PARAM_VECS + ["D", "F"]:
+        assert rel_inf(f[n], getattr(cdl_ref, n).detach().numpy()) <= 2e-5, n
+
+
+def test_groups_are_independent(ctx, pkg):
+    """G mini-batches in one launch == the same mini-batches one at a time."""
+    hp, codes, cdl_o = tiny(9, G=3)
+    B = hp.batch_size
+    cdl = to_model(pkg, ctx, hp, codes.shape[1], cdl_o)
+    loss, flat = gpu_loss_grad(pkg, ctx, cdl, codes, 3)
+    acc = np.zeros_like(flat, dtype=np.float64)
+    for g in range(3):
+        l1, f1 = gpu_loss_grad(pkg, ctx, cdl, codes[g * B:(g + 1) * B], 1)
+        assert l1[0] == loss[g]
+        acc += f1
+    assert rel_inf(flat, acc) <= 1e-5
+
+
+def test_train_ucdl_runs_and_code_retrieval_format(ctx, pkg):
+    md = pkg.model
+    hp = md.Hyperparam(filter_len=4, M=6, h=3, K=4, q=5, batch_size=3)
+    codes = pkg.synth.gen_codes(31, 40, 3, n_plant=2, k=4)
+    cdl, _, losses = md.train_ucdl(codes, hp, num_epochs=2, groups_per_step=2, ctx=ctx, arena_bytes=1 << 30,
+                                     l1_loss_thresh=0.0)
+    assert len(losses) == 2 * 10 and np.all(np.isfinite(losses))
+    # the reference stops as soon as sum|F| < 95 (train.jl:47-52); this small bank is below it from the start
+    _, _, short = md.train_ucdl(codes, hp, num_epochs=2, groups_per_step=2, ctx=ctx, arena_bytes=1 << 30)
+    assert len(short) == 2
+    rec = md.code_retrieval(codes, cdl)
+    assert rec["seq"].max() <= 30 and rec["seq"].min() >= 1          # remainder (31st read) dropped: partial=false
+    key = list(zip(rec["seq"].tolist(), rec["fil"].tolist(), rec["position"].tolist()))
+    assert key == sorted(key) and len(key) >= 30 * hp.q // 2         # findall order: position fastest, then fil, then seq
+    assert (rec["mag"] > 0).all()
