@@ -513,6 +513,46 @@ __global__ void k_sum_groups(const float* x, size_t per, int G, float* y) {
     y[j] += (float)acc;
 }
 
+// per group [H][W][N] -> out[i'][n][j] = in[H-1-i'][j][n]
+__global__ void k_flipT(const float* x, int g, int H, int W, int N, float* out, int acc) {
+    const size_t per = (size_t)H * W * N, total = per * g;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t gg = i / per, r = i % per;      // r indexes the OUTPUT [H][N][W]
+        const int j = (int)(r % W), n = (int)((r / W) % N), ip = (int)(r / ((size_t)W * N));
+        const float v = x[gg * per + ((size_t)(H - 1 - ip) * W + j) * N + n];
+        out[i] = acc ? out[i] + v : v;
+    }
+}
+
+// dA[s][e] += sum_{p,q: a0 + p*sa + q = e} sum_n dC[s][p][n] * Bm[g][q][n]  (adjoint of the Toeplitz
+// gather).  With A viewed as rows of W = sa columns and the window as H = Q/W rows, this is again a
+// Toeplitz GEMM: over dC (rows of N columns) with the filter flipT(Bm) = [H][N][W], rows reversed.
+static bool toep_adjoint_a(Engine& e, const float* dC, const float* Bm, float* dA, const ToepGeom& gm) {
+    const int W = gm.sa, H = gm.Q / gm.sa;
+    const int gB = gm.ldb == 0 ? 1 : gm.S / gm.B;
+    const size_t per = (size_t)gm.Q * gm.N;
+    float* tmp = e.arena.alloc(per * gB);
+    if (!tmp) {
+        e.failed = true;
+        return false;
+    }
+    hipLaunchKernelGGL(k_flipT, dim3(nblocks(per * gB)), dim3(256), 0, e.st, Bm, gB, H, W, gm.N, tmp, 0);
+    ToepGeom g2;
+    g2.S = gm.S;
+    g2.P = gm.amax / W;
+    g2.Q = H * gm.N;
+    g2.N = W;
+    g2.sa = gm.N;
+    g2.a0 = -(H - 1) * gm.N - (gm.a0 / W) * gm.N;
+    g2.amax = gm.P * gm.N;
+    g2.lda = gm.ldc;
+    g2.ldc = gm.lda;
+    g2.B = gm.B;
+    g2.ldb = gm.ldb == 0 ? 0 : (int64_t)per;
+    launch_toep(e.st, dC, tmp, dA, g2, 1);
+    return true;
+}
+
 Tensor Engine::toep(Tensor A, Tensor Bm, const ToepGeom& gm) {
     Tensor out = make((size_t)gm.S * gm.ldc, A->needs_grad || Bm->needs_grad);
     if (failed) return out;
@@ -522,7 +562,7 @@ Tensor Engine::toep(Tensor A, Tensor Bm, const ToepGeom& gm) {
             if (!out->g) return;
             if (A->needs_grad) {
                 float* dA = grad(A);
-                if (dA) hipLaunchKernelGGL(k_toep_bwd_a, dim3(nblocks((size_t)gm.S * gm.amax)), dim3(256), 0, st, out->g, Bm->v, dA, gm);
+                if (dA) toep_adjoint_a(*this, out->g, Bm->v, dA, gm);
             }
             if (Bm->needs_grad) {
                 float* dB = grad(Bm);
@@ -557,7 +597,7 @@ Tensor Engine::wgrad(Tensor A, Tensor C, const ToepGeom& gm) {
             g2.ldb = (int64_t)gm.Q * gm.N;   // the "filter" of the adjoints is dOut, one slice per group
             if (A->needs_grad) {
                 float* dA = grad(A);
-                if (dA) hipLaunchKernelGGL(k_toep_bwd_a, dim3(nblocks((size_t)gm.S * gm.amax)), dim3(256), 0, st, C->v, out->g, dA, g2);
+                if (dA) toep_adjoint_a(*this, C->v, out->g, dA, g2);
             }
             if (C->needs_grad) {
                 float* dCc = grad(C);
@@ -638,16 +678,6 @@ Tensor Engine::swap02(Tensor x, int g, int d0, int d1, int d2) {
     return out;
 }
 
-// per group [H][W][N] -> out[i'][n][j] = in[H-1-i'][j][n]
-__global__ void k_flipT(const float* x, int g, int H, int W, int N, float* out, int acc) {
-    const size_t per = (size_t)H * W * N, total = per * g;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const size_t gg = i / per, r = i % per;      // r indexes the OUTPUT [H][N][W]
-        const int j = (int)(r % W), n = (int)((r / W) % N), ip = (int)(r / ((size_t)W * N));
-        const float v = x[gg * per + ((size_t)(H - 1 - ip) * W + j) * N + n];
-        out[i] = acc ? out[i] + v : v;
-    }
-}
 Tensor Engine::flipT(Tensor Bm, int g, int H, int W, int N) {
     Tensor out = make(Bm->n, Bm->needs_grad);
     if (failed) return out;
