@@ -39,6 +39,11 @@ def parse():
     ap.add_argument("--pwms", type=int, default=200)
     ap.add_argument("--pwm-len", type=int, default=12)
     ap.add_argument("--cpu-sample", type=int, default=600, help="sequences in the CPU-baseline sample")
+    ap.add_argument("--train-groups", type=int, default=32, help="mini-batches (of 6 reads) per optimiser step per GPU")
+    ap.add_argument("--train-steps", type=int, default=5)
+    ap.add_argument("--filters", type=int, default=200)
+    ap.add_argument("--filter-len", type=int, default=12)
+    ap.add_argument("--no-train", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     return ap.parse_args()
 
@@ -138,6 +143,54 @@ def main():
     dense_gbs = dense_bytes / (dense_ms / dense_n * 1e-3) / 1e9
     del dense
 
+    # ---- conv-train step (BASELINE metric, second half): unrolled-ADMM forward/backward + AdaBelief ----
+    train = None
+    if not args.no_train:
+        md, par = pkg.model, pkg.parallel
+        hp = md.Hyperparam(filter_len=args.filter_len, M=args.filters)
+        Gt = args.train_groups
+        St = Gt * hp.batch_size
+        cdl = md.ucdl(hp, L, ctx=ctx, seed=seed, arena_bytes=int((1.3 * Gt + 2) * (1 << 30)))
+        tcodes = sy.gen_codes(St, L, seed + 77 + 1000 * rank, n_plant=5, k=args.filter_len)
+        traw = torch.from_numpy(tcodes).cuda()
+        tdev = torch.zeros(lib.Context.codes_bytes(St, L), dtype=torch.uint8, device="cuda")
+        ctx.encode_dev(traw.data_ptr(), lib.DATA_CODES_U8, St, L, tdev.data_ptr())
+        tloss = torch.zeros(Gt, dtype=torch.float32, device="cuda")
+        tgrad = torch.zeros(cdl.model.nP, dtype=torch.float32, device="cuda")
+        par.dp_train_step(cdl.model, tdev.data_ptr(), Gt, tloss, tgrad)        # warm-up
+        torch.cuda.synchronize()
+        ctx.enable_timing(True)
+        ctx.reset_timing()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.train_steps):
+            par.dp_train_step(cdl.model, tdev.data_ptr(), Gt, tloss, tgrad)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        tdt = time.perf_counter() - t0
+        ctx.enable_timing(False)
+        if world > 1:
+            tt = torch.tensor([tdt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            tdt = float(tt.item())
+        gms, gn = ctx.kernel_ms(lib.KS_TRAIN_STEP)
+        train = {
+            "workload": f"unrolled-ADMM sparse coding, {Gt} mini-batches x {hp.batch_size} reads x {L} bp per GPU per "
+                        f"optimiser step, {args.filters} filters len {args.filter_len}, h=12 K=24 q=32, 6+3 passes, f32",
+            "ms_per_step": tdt / args.train_steps * 1e3,
+            "seqs_per_s": St * world * args.train_steps / tdt,
+            "bases_per_s": St * world * L * args.train_steps / tdt,
+            "device_ms_fwd_bwd": gms / max(gn, 1),
+            "loss_first_group": float(tloss[0].item()),
+            "grad_allreduce_floats": int(cdl.model.nP) if world > 1 else 0,
+            "reference_schedule_equivalent": f"{Gt * world} reference steps (batch 6) worth of reads per step",
+        }
+        cdl.model.close()
+
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -205,6 +258,9 @@ def main():
                                "fill_records": kms["fill"][0] / args.steps},
     }
 
+    if train is not None:
+        out["train"] = train
+
     if not args.no_cpu and world == 1:
         from oracle import scan_oracle as so
 
@@ -231,6 +287,32 @@ def main():
             "optimised_port_note": "gather formulation (one add per position, no dense 4L dim), same threads",
         }
         out["gpu_over_cpu"] = value / (ns * L / cdt)
+        if train is not None:
+            # the reference-faithful oracle (full-lag conv_code_diff etc.) needs ~220 s per mini-batch at
+            # configs[1] on 8 cores, so the CPU leg of the train step is timed at configs[0] shape
+            # (100 bp, 32 filters of length 8) for BOTH sides
+            from oracle import model_oracle as mo
+            import torch as _t
+
+            hp1 = mo.Hyperparam(filter_len=8, M=32)
+            rng = np.random.default_rng(1)
+            c1 = rng.integers(0, 4, size=(6, 100)).astype(np.uint8)
+            cdl1 = mo.UCDL(hp1, rng)
+            t0 = time.perf_counter()
+            mo.loss_and_grads(c1, cdl1, hp1, _t.float32)
+            ct = time.perf_counter() - t0
+            g1 = pkg.model.ucdl(pkg.model.Hyperparam(filter_len=8, M=32), 100, ctx=ctx, seed=1, arena_bytes=8 << 30)
+            cc = sy.gen_codes(64 * 6, 100, 3)
+            g1.model.train_step(cc, 64, want_l1=False)
+            t0 = time.perf_counter()
+            g1.model.train_step(cc, 64, want_l1=False)
+            gt = time.perf_counter() - t0
+            out["train"]["cpu_baseline_cfg0"] = {
+                "value": 6 / ct, "unit": "seqs/s", "cores": _t.get_num_threads(), "kind": "port",
+                "sample": f"one mini-batch fwd+bwd of the torch-CPU restatement at configs[0] shape, {ct:.1f} s",
+                "gpu_same_shape_seqs_per_s": 64 * 6 / gt,
+            }
+            g1.model.close()
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

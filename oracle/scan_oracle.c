@@ -218,6 +218,14 @@ void oracle_scan_gather(const uint16_t* pwms, const int64_t* lens, int K, const 
     }
 }
 
+void oracle_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 int oracle_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

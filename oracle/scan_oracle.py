@@ -35,6 +35,12 @@ def lib():
         h.oracle_scan_gather.restype = None
         h.oracle_scan_gather.argtypes = [p, p, i, p, i64, i, i, p]
         h.oracle_num_threads.restype = i
+        h.oracle_set_threads.restype = None
+        h.oracle_set_threads.argtypes = [i]
+        try:
+            h.oracle_set_threads(min(len(os.sched_getaffinity(0)), 64))
+        except AttributeError:
+            pass
         h.oracle_h_add.restype = C.c_uint16
         h.oracle_h_add.argtypes = [C.c_uint16, C.c_uint16]
         h.oracle_f32_to_f16.restype = C.c_uint16
