@@ -96,7 +96,8 @@ struct Engine {
 
 // selections (constants in the backward: @ignore, model.jl:190, :208)
 void topq_mask(hipStream_t st, const float* X, float* bitmat, int S, int n_per_seq, int q);
-void median_mask(hipStream_t st, const float* ZY, float* mask, int G, int n_per_group);
+size_t median_workspace_bytes(int G);
+void median_mask(hipStream_t st, const float* ZY, float* mask, int G, int n_per_group, void* workspace);
 void onehot_from_codes(hipStream_t st, const uint8_t* codes, int pitch, float* S, int nseq, int L);
 void adabelief_step(hipStream_t st, float* x, float* m, float* s, const float* grad, size_t n, float gscale, float eta,
                     float b1, float b2, float eps, float b1p, float b2p);

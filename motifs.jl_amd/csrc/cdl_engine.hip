@@ -384,7 +384,255 @@ __global__ __launch_bounds__(256) void k_toep(const float* __restrict__ A, const
     }
 }
 
+// ---- f32 MFMA forms for narrow outputs (8 < N <= 32): the syntax-layer contraction (model.jl:214, :251) and
+// its adjoints, reduction length h*2M.  v_mfma_f32_32x32x2_f32 is an exact f32 fma chain (same numerics as
+// the FMA kernel up to summation order).  Block = 2 waves, each a 32-row x 32-column tile; LDS stages of 32.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Stage a [ROWS][32] tile of Toeplitz rows into a wave-private LDS tile (row stride 33).  Rows are
+// (group-local) indices loc0.. of group g; lanes walk float4 columns.
+template <int ROWS>
+static __device__ __forceinline__ void stage_rows(const float* __restrict__ A, const ToepGeom& gm, int g, int loc0, int q0,
+                                                  float (*As)[33], int lane) {
+    const int grp_rows = gm.B * gm.P;
+#pragma unroll
+    for (int j = 0; j < ROWS / 8; j++) {          // ROWS*8 float4 per tile, 64 lanes
+        const int f = lane + j * 64, row = f >> 3, cg = (f & 7) * 4;
+        const int loc = loc0 + row;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (loc < grp_rows) {
+            const int sl = loc / gm.P, p = loc - sl * gm.P;
+            const int q = q0 + cg;
+            const int e = gm.a0 + p * gm.sa + q;
+            const float* src = A + (size_t)(g * gm.B + sl) * gm.lda + e;
+            if (q + 3 < gm.Q && e >= 0 && e + 3 < gm.amax && (((uintptr_t)src) & 15) == 0) {
+                v = *(const float4*)src;
+            } else {
+                float t[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (q + u < gm.Q && e + u >= 0 && e + u < gm.amax) t[u] = src[u];
+                v = make_float4(t[0], t[1], t[2], t[3]);
+            }
+        }
+        As[row][cg + 0] = v.x;
+        As[row][cg + 1] = v.y;
+        As[row][cg + 2] = v.z;
+        As[row][cg + 3] = v.w;
+    }
+}
+
+// 8 waves per block: 2 row tiles of 32 x 4 interleaved slices of the reduction.  Every wave owns its LDS
+// tiles and runs un-synchronised (4 waves per SIMD hide each other's load latency); the four partial
+// tiles are summed through LDS at the end.
+__global__ __launch_bounds__(512) void k_toep_mfma(const float* __restrict__ A, const float* __restrict__ Bm,
+                                                   float* __restrict__ C, ToepGeom gm, int acc) {
+    constexpr int BK = 32, KS = 4;
+    __shared__ float As[8][32][33];
+    __shared__ float Bs[8][BK][33];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rt = wave & 1, ks = wave >> 1;
+    const int grp_rows = gm.B * gm.P;
+    const int g = blockIdx.y;
+    const int loc0 = blockIdx.x * 64 + rt * 32;
+    const float* Bg = Bm + (size_t)g * gm.ldb;
+    f32x16 accv;
+#pragma unroll
+    for (int i = 0; i < 16; i++) accv[i] = 0.0f;
+    for (int q0 = ks * BK; q0 < gm.Q; q0 += KS * BK) {
+        stage_rows<32>(A, gm, g, loc0, q0, As[wave], lane);
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const int f = lane + j * 64, kk = f >> 5, n = f & 31;
+            const int q = q0 + kk;
+            Bs[wave][kk][n] = (q < gm.Q && n < gm.N) ? Bg[(size_t)q * gm.N + n] : 0.0f;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            const float a = As[wave][lane & 31][kk + (lane >> 5)];
+            const float b = Bs[wave][kk + (lane >> 5)][lane & 31];
+            accv = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, accv, 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    // reduce the KS partial tiles: slices 1..3 park theirs in their A tile region ([16 regs][64 lanes] floats)
+    float* park = &As[wave][0][0];               // 32*33 = 1056 floats >= 1024
+    __syncthreads();
+    if (ks > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) park[r * 64 + lane] = accv[r];
+    }
+    __syncthreads();
+    if (ks == 0) {
+#pragma unroll
+        for (int o = 1; o < KS; o++) {
+            const float* src = &As[rt + 2 * o][0][0];
+#pragma unroll
+            for (int r = 0; r < 16; r++) accv[r] += src[r * 64 + lane];
+        }
+        const int col = lane & 31;
+        if (col < gm.N) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int loc = loc0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (loc < grp_rows) {
+                    const int sl = loc / gm.P, p = loc - sl * gm.P;
+                    float* o = C + (size_t)(g * gm.B + sl) * gm.ldc + (size_t)p * gm.N + col;
+                    *o = acc ? *o + accv[r] : accv[r];
+                }
+            }
+        }
+    }
+}
+
+// N <= 4 outputs (D-layer synthesis and its relatives: an image 4 bases wide): one row per lane, 4
+// accumulators, 8 waves = 2 row tiles of 64 x 4 slices of the reduction, wave-private LDS as above.
+__global__ __launch_bounds__(512) void k_toep_n4(const float* __restrict__ A, const float* __restrict__ Bm,
+                                                 float* __restrict__ C, ToepGeom gm, int acc) {
+    constexpr int BK = 32, KS = 4;
+    __shared__ float As[8][64][33];
+    __shared__ float4 Bs[8][BK];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rt = wave & 1, ks = wave >> 1;
+    const int grp_rows = gm.B * gm.P;
+    const int g = blockIdx.y;
+    const int loc0 = blockIdx.x * 128 + rt * 64;
+    const float* Bg = Bm + (size_t)g * gm.ldb;
+    float4 accv = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int q0 = ks * BK; q0 < gm.Q; q0 += KS * BK) {
+        stage_rows<64>(A, gm, g, loc0, q0, As[wave], lane);
+        if (lane < BK) {
+            const int q = q0 + lane;
+            float t[4] = {0.f, 0.f, 0.f, 0.f};
+            if (q < gm.Q)
+#pragma unroll
+                for (int n = 0; n < 4; n++)
+                    if (n < gm.N) t[n] = Bg[(size_t)q * gm.N + n];
+            Bs[wave][lane] = make_float4(t[0], t[1], t[2], t[3]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int kk = 0; kk < BK; kk++) {
+            const float a = As[wave][lane][kk];
+            const float4 b = Bs[wave][kk];
+            accv.x = fmaf(a, b.x, accv.x);
+            accv.y = fmaf(a, b.y, accv.y);
+            accv.z = fmaf(a, b.z, accv.z);
+            accv.w = fmaf(a, b.w, accv.w);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    float4* park = (float4*)&As[wave][0][0];
+    __syncthreads();
+    if (ks > 0) park[lane] = accv;
+    __syncthreads();
+    if (ks == 0) {
+#pragma unroll
+        for (int o = 1; o < KS; o++) {
+            const float4 t = ((const float4*)&As[rt + 2 * o][0][0])[lane];
+            accv.x += t.x;
+            accv.y += t.y;
+            accv.z += t.z;
+            accv.w += t.w;
+        }
+        const int loc = loc0 + lane;
+        if (loc < grp_rows) {
+            const int sl = loc / gm.P, p = loc - sl * gm.P;
+            float* o = C + (size_t)(g * gm.B + sl) * gm.ldc + (size_t)p * gm.N;
+            const float v[4] = {accv.x, accv.y, accv.z, accv.w};
+#pragma unroll
+            for (int n = 0; n < 4; n++)
+                if (n < gm.N) o[n] = acc ? o[n] + v[n] : v[n];
+        }
+    }
+}
+
+// dB[g][q][n] (+)= sum_{s in g, p} Aw(s,p,q) * C[s][p][n] for N <= 32: 4 waves, each 32 q x 32 n
+__global__ __launch_bounds__(256) void k_wgrad_mfma(const float* __restrict__ A, const float* __restrict__ C,
+                                                    float* __restrict__ dB, ToepGeom gm, int acc) {
+    constexpr int BQ = 128, BK = 32;
+    __shared__ float As[BK][BQ + 4];   // [k][q]
+    __shared__ float Cs[BK][32 + 1];   // [k][n]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = blockIdx.y, q0 = blockIdx.x * BQ;
+    const int KT = gm.B * gm.P;
+    f32x16 accv;
+#pragma unroll
+    for (int i = 0; i < 16; i++) accv[i] = 0.0f;
+    for (int k0 = 0; k0 < KT; k0 += BK) {
+        // A stage: 32 k-rows x 128 q = 1024 float4, 4 per thread; consecutive threads walk q
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int f = tid + j * 256, kk = f >> 5, cg = (f & 31) * 4;
+            const int k = k0 + kk, q = q0 + cg;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k < KT) {
+                const int sl = k / gm.P, p = k - sl * gm.P;
+                const int e = gm.a0 + p * gm.sa + q;
+                const float* src = A + (size_t)(g * gm.B + sl) * gm.lda + e;
+                if (q + 3 < gm.Q && e >= 0 && e + 3 < gm.amax && (((uintptr_t)src) & 15) == 0) {
+                    v = *(const float4*)src;
+                } else {
+                    float t[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+                        if (q + u < gm.Q && e + u >= 0 && e + u < gm.amax) t[u] = src[u];
+                    v = make_float4(t[0], t[1], t[2], t[3]);
+                }
+            }
+            *(float4*)&As[kk][cg] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int f = tid + j * 256, kk = f >> 5, n = f & 31;
+            const int k = k0 + kk;
+            float v = 0.0f;
+            if (k < KT && n < gm.N) {
+                const int sl = k / gm.P, p = k - sl * gm.P;
+                v = C[(size_t)(g * gm.B + sl) * gm.ldc + (size_t)p * gm.N + n];
+            }
+            Cs[kk][n] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            const float a = As[kk + (lane >> 5)][wave * 32 + (lane & 31)];
+            const float b = Cs[kk + (lane >> 5)][lane & 31];
+            accv = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, accv, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    const int col = lane & 31;
+    if (col < gm.N) {
+        float* out = dB + (size_t)g * gm.Q * gm.N;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int q = q0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (q < gm.Q) {
+                float* o = &out[(size_t)q * gm.N + col];
+                *o = acc ? *o + accv[r] : accv[r];
+            }
+        }
+    }
+}
+
 static void launch_toep(hipStream_t st, const float* A, const float* Bm, float* C, const ToepGeom& gm, int acc) {
+    // MFMA form: narrow output, long reduction, and blocks of 64 rows never straddle two filter groups
+    if (gm.N > 8 && gm.N <= 32 && gm.Q >= 256) {
+        const int grp_rows = gm.B * gm.P;
+        hipLaunchKernelGGL(k_toep_mfma, dim3((unsigned)((grp_rows + 63) / 64), (unsigned)(gm.S / gm.B)), dim3(512), 0, st, A, Bm,
+                           C, gm, acc);
+        return;
+    }
+    if (gm.N <= 4 && gm.Q >= 256) {
+        const int grp_rows = gm.B * gm.P;
+        hipLaunchKernelGGL(k_toep_n4, dim3((unsigned)((grp_rows + 127) / 128), (unsigned)(gm.S / gm.B)), dim3(512), 0, st, A, Bm, C,
+                           gm, acc);
+        return;
+    }
     if (gm.N <= 32) {
         dim3 grid((gm.N + 31) / 32, (gm.P + 63) / 64, gm.S);
         hipLaunchKernelGGL(k_toep<32>, grid, dim3(256), 0, st, A, Bm, C, gm, acc);
@@ -470,6 +718,10 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ A, cons
 
 static void launch_wgrad(hipStream_t st, const float* A, const float* C, float* dB, const ToepGeom& gm, int acc) {
     const int G = gm.S / gm.B;
+    if (gm.N > 8 && gm.N <= 32 && gm.Q >= 256) {
+        hipLaunchKernelGGL(k_wgrad_mfma, dim3((gm.Q + 127) / 128, G), dim3(256), 0, st, A, C, dB, gm, acc);
+        return;
+    }
     if (gm.N <= 32) {
         dim3 grid((gm.N + 31) / 32, (gm.Q + 63) / 64, G);
         hipLaunchKernelGGL(k_wgrad<32>, grid, dim3(256), 0, st, A, C, dB, gm, acc);
@@ -752,34 +1004,92 @@ void topq_mask(hipStream_t st, const float* X, float* bitmat, int S, int n_per_s
 // create_ZY_mask (model.jl:194-204): median of the strictly positive entries of the whole mini-batch
 // (mean of the two middle values for an even count: Statistics.middle(a, b) = a/2 + b/2); mask = ZY >= median.
 // No positive entry -> the reference skips the mask (:209); that is mask == 1 here.
-__global__ __launch_bounds__(1024) void k_median_mask(const float* ZY, float* mask, int n) {
-    __shared__ uint32_t hist[256];
-    __shared__ uint32_t sh[2];
-    __shared__ uint32_t cnt_sh;
-    const float* xs = ZY + (size_t)blockIdx.x * n;
-    if (threadIdx.x == 0) cnt_sh = 0;
+// Multi-block radix select: 4 passes of (histogram over all blocks, digit choice per group); the lower
+// and the upper middle element are tracked side by side.
+struct MedState {
+    uint32_t cnt, pref[2], k[2];
+};
+
+__global__ __launch_bounds__(256) void k_med_hist(const float* __restrict__ x, int n, const MedState* __restrict__ state,
+                                                  uint32_t* __restrict__ hist, int shift) {
+    __shared__ uint32_t h[2][256];
+    const int g = blockIdx.y;
+    for (int i = threadIdx.x; i < 512; i += 256) (&h[0][0])[i] = 0;
     __syncthreads();
-    uint32_t c = 0;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) c += xs[i] > 0.0f;
-    for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d);
-    if ((threadIdx.x & 63) == 0) atomicAdd(&cnt_sh, c);
-    __syncthreads();
-    const uint32_t cnt = cnt_sh;
-    float med = -INFINITY;
-    if (cnt > 0) {
-        auto pos = [](float v) { return v > 0.0f; };
-        const float lo = unkey(block_radix_select(xs, n, (cnt - 1) / 2, pos, hist, sh));
-        med = lo;
-        if ((cnt & 1u) == 0) {
-            const float hi = unkey(block_radix_select(xs, n, cnt / 2, pos, hist, sh));
-            med = lo / 2 + hi / 2;
-        }
+    const uint32_t mask = shift == 24 ? 0u : (0xffffffffu << (shift + 8));
+    const uint32_t p0 = shift == 24 ? 0u : state[g].pref[0], p1 = shift == 24 ? 0u : state[g].pref[1];
+    const float* xs = x + (size_t)g * n;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const float v = xs[i];
+        if (!(v > 0.0f)) continue;
+        const uint32_t key = __float_as_uint(v);       // positive floats order like their bit patterns
+        const uint32_t d = (key >> shift) & 0xffu;
+        if ((key & mask) == p0) atomicAdd(&h[0][d], 1u);
+        if (shift != 24 && (key & mask) == p1) atomicAdd(&h[1][d], 1u);
     }
-    for (int i = threadIdx.x; i < n; i += blockDim.x) mask[(size_t)blockIdx.x * n + i] = xs[i] >= med ? 1.0f : 0.0f;
+    __syncthreads();
+    for (int i = threadIdx.x; i < 512; i += 256) {
+        const uint32_t c = (&h[0][0])[i];
+        if (c) atomicAdd(&hist[(size_t)g * 512 + i], c);
+    }
 }
-void median_mask(hipStream_t st, const float* ZY, float* mask, int G, int n_per_group) {
-    hipLaunchKernelGGL(k_median_mask, dim3(G), dim3(1024), 0, st, ZY, mask, n_per_group);
+
+__global__ void k_med_select(MedState* state, uint32_t* hist, int shift) {
+    const int g = blockIdx.x;
+    uint32_t* h = hist + (size_t)g * 512;
+    if (threadIdx.x == 0) {
+        MedState st = state[g];
+        if (shift == 24) {
+            uint32_t c = 0;
+            for (int b = 0; b < 256; b++) c += h[b];
+            st.cnt = c;
+            st.pref[0] = st.pref[1] = 0;
+            st.k[0] = c ? (c - 1) / 2 : 0;
+            st.k[1] = c / 2;
+        }
+        if (st.cnt) {
+            for (int sel = 0; sel < 2; sel++) {
+                const uint32_t* hh = h + (shift == 24 ? 0 : sel * 256);
+                uint32_t run = 0;
+                int b = 0;
+                for (; b < 255; b++) {
+                    if (run + hh[b] > st.k[sel]) break;
+                    run += hh[b];
+                }
+                st.pref[sel] |= (uint32_t)b << shift;
+                st.k[sel] -= run;
+            }
+        }
+        state[g] = st;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 512; i += blockDim.x) h[i] = 0;   // ready for the next pass
 }
+
+__global__ void k_med_apply(const float* __restrict__ x, int n, const MedState* __restrict__ state, float* __restrict__ mask) {
+    const int g = blockIdx.y;
+    const MedState st = state[g];
+    float med = -INFINITY;
+    if (st.cnt) {
+        const float lo = __uint_as_float(st.pref[0]), hi = __uint_as_float(st.pref[1]);
+        med = (st.cnt & 1u) ? lo : lo / 2 + hi / 2;
+    }
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
+        mask[(size_t)g * n + i] = x[(size_t)g * n + i] >= med ? 1.0f : 0.0f;
+}
+
+void median_mask(hipStream_t st, const float* ZY, float* mask, int G, int n_per_group, void* workspace) {
+    MedState* state = (MedState*)workspace;
+    uint32_t* hist = (uint32_t*)((char*)workspace + (((size_t)G * sizeof(MedState) + 255) & ~(size_t)255));
+    (void)hipMemsetAsync(workspace, 0, median_workspace_bytes(G), st);
+    const unsigned nb = (unsigned)std::min<size_t>((n_per_group + 256 * 16 - 1) / (256 * 16), 64);
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        hipLaunchKernelGGL(k_med_hist, dim3(nb, G), dim3(256), 0, st, ZY, n_per_group, state, hist, shift);
+        hipLaunchKernelGGL(k_med_select, dim3(G), dim3(64), 0, st, state, hist, shift);
+    }
+    hipLaunchKernelGGL(k_med_apply, dim3(nb, G), dim3(256), 0, st, ZY, n_per_group, state, mask);
+}
+size_t median_workspace_bytes(int G) { return (((size_t)G * sizeof(MedState) + 255) & ~(size_t)255) + (size_t)G * 512 * 4; }
 
 __global__ void k_onehot(const uint8_t* codes, int pitch, float* S, int nseq, int L) {
     const size_t total = (size_t)nseq * L;

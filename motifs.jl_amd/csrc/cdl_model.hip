@@ -65,8 +65,9 @@ struct Graph {
     // cat_ZY (model.jl:206-210): magnifying_factor * (ZY >= median of the positive entries of the mini-batch) .* ZY
     Tensor cat_ZY(Tensor ZY) {
         Tensor mask = e.make(ZY->n, false);
+        Tensor ws = e.make(median_workspace_bytes(G) / 4 + 64, false);
         if (e.failed) return ZY;
-        median_mask(e.st, ZY->v, mask->v, G, (int)(ZY->n / G));
+        median_mask(e.st, ZY->v, mask->v, G, (int)(ZY->n / G), ws->v);
         return e.maskmul(ZY, mask->v, m->hp.magnifying_factor);
     }
     // project_X (model.jl:181-192): keep the entries >= the q-th largest of each sequence
