@@ -337,12 +337,11 @@ __global__ __launch_bounds__(256) void k_toep(const float* __restrict__ A, const
             const int idx = tid + it * 256;
             const int row = idx / BK, qq = idx % BK;
             const int p = p0 + row, q = q0 + qq;
-            float v = 0.0f;
-            if (p < gm.P && q < gm.Q) {
-                const int e = gm.a0 + p * gm.sa + q;
-                if (e >= 0 && e < gm.amax) v = As_g[e];
-            }
-            As[qq][row] = v;
+            // unconditional (clamped) load + select: a guarded load would serialise the stage
+            const int e = gm.a0 + p * gm.sa + q;
+            const bool ok = p < gm.P && q < gm.Q && e >= 0 && e < gm.amax;
+            const float v = As_g[ok ? e : 0];
+            As[qq][row] = ok ? v : 0.0f;
         }
 #pragma unroll
         for (int it = 0; it < (BK * BN + 255) / 256; it++) {
@@ -350,7 +349,9 @@ __global__ __launch_bounds__(256) void k_toep(const float* __restrict__ A, const
             if (idx < BK * BN) {
                 const int qq = idx / BN, nn = idx % BN;
                 const int q = q0 + qq, n = n0 + nn;
-                Bs[qq][nn] = (q < gm.Q && n < gm.N) ? Bg[(size_t)q * gm.N + n] : 0.0f;
+                const bool ok = q < gm.Q && n < gm.N;
+                const float v = Bg[ok ? (size_t)q * gm.N + n : 0];
+                Bs[qq][nn] = ok ? v : 0.0f;
             }
         }
         __syncthreads();
@@ -395,30 +396,55 @@ template <int ROWS>
 static __device__ __forceinline__ void stage_rows(const float* __restrict__ A, const ToepGeom& gm, int g, int loc0, int q0,
                                                   float (*As)[33], int lane) {
     const int grp_rows = gm.B * gm.P;
+    constexpr int NJ = ROWS / 8;                  // ROWS*8 float4 per tile, 64 lanes
+    const float* src[NJ];
+    bool rowok[NJ], fast[NJ];
+    bool allfast = true;
 #pragma unroll
-    for (int j = 0; j < ROWS / 8; j++) {          // ROWS*8 float4 per tile, 64 lanes
+    for (int j = 0; j < NJ; j++) {
         const int f = lane + j * 64, row = f >> 3, cg = (f & 7) * 4;
         const int loc = loc0 + row;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (loc < grp_rows) {
-            const int sl = loc / gm.P, p = loc - sl * gm.P;
-            const int q = q0 + cg;
-            const int e = gm.a0 + p * gm.sa + q;
-            const float* src = A + (size_t)(g * gm.B + sl) * gm.lda + e;
-            if (q + 3 < gm.Q && e >= 0 && e + 3 < gm.amax && (((uintptr_t)src) & 15) == 0) {
-                v = *(const float4*)src;
-            } else {
-                float t[4] = {0.f, 0.f, 0.f, 0.f};
+        rowok[j] = loc < grp_rows;
+        const int lc = rowok[j] ? loc : grp_rows - 1;
+        const int sl = lc / gm.P, p = lc - sl * gm.P;
+        const int q = q0 + cg;
+        const int e = gm.a0 + p * gm.sa + q;
+        src[j] = A + (size_t)(g * gm.B + sl) * gm.lda + e;
+        fast[j] = q + 3 < gm.Q && e >= 0 && e + 3 < gm.amax && (((uintptr_t)src[j]) & 15) == 0;
+        allfast = allfast && fast[j];
+    }
+    float4 v[NJ];
+    if (__all(allfast)) {                         // wave-uniform: the loads below are unconditional and pipeline
 #pragma unroll
-                for (int u = 0; u < 4; u++)
-                    if (q + u < gm.Q && e + u >= 0 && e + u < gm.amax) t[u] = src[u];
-                v = make_float4(t[0], t[1], t[2], t[3]);
+        for (int j = 0; j < NJ; j++) v[j] = *(const float4*)src[j];
+    } else {
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            const int f = lane + j * 64, cg = (f & 7) * 4;
+            const int q = q0 + cg;
+            const int loc = loc0 + (f >> 3);
+            const int lc = rowok[j] ? loc : grp_rows - 1;
+            const int sl = lc / gm.P, p = lc - sl * gm.P;
+            const int e = gm.a0 + p * gm.sa + q;
+            const float* base = A + (size_t)(g * gm.B + sl) * gm.lda;
+            float t[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const bool ok = q + u < gm.Q && e + u >= 0 && e + u < gm.amax;
+                const float x = base[ok ? e + u : 0];
+                t[u] = ok ? x : 0.0f;
             }
+            v[j] = make_float4(t[0], t[1], t[2], t[3]);
         }
-        As[row][cg + 0] = v.x;
-        As[row][cg + 1] = v.y;
-        As[row][cg + 2] = v.z;
-        As[row][cg + 3] = v.w;
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+        const int f = lane + j * 64, row = f >> 3, cg = (f & 7) * 4;
+        const float4 w = rowok[j] ? v[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+        As[row][cg + 0] = w.x;
+        As[row][cg + 1] = w.y;
+        As[row][cg + 2] = w.z;
+        As[row][cg + 3] = w.w;
     }
 }
 
@@ -441,11 +467,19 @@ __global__ __launch_bounds__(512) void k_toep_mfma(const float* __restrict__ A, 
     for (int i = 0; i < 16; i++) accv[i] = 0.0f;
     for (int q0 = ks * BK; q0 < gm.Q; q0 += KS * BK) {
         stage_rows<32>(A, gm, g, loc0, q0, As[wave], lane);
+        float bt[16];
 #pragma unroll
         for (int j = 0; j < 16; j++) {
             const int f = lane + j * 64, kk = f >> 5, n = f & 31;
             const int q = q0 + kk;
-            Bs[wave][kk][n] = (q < gm.Q && n < gm.N) ? Bg[(size_t)q * gm.N + n] : 0.0f;
+            const bool ok = q < gm.Q && n < gm.N;
+            const float x = Bg[ok ? (size_t)q * gm.N + n : 0];
+            bt[j] = ok ? x : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const int f = lane + j * 64;
+            Bs[wave][f >> 5][f & 31] = bt[j];
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -503,14 +537,16 @@ __global__ __launch_bounds__(512) void k_toep_n4(const float* __restrict__ A, co
     float4 accv = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int q0 = ks * BK; q0 < gm.Q; q0 += KS * BK) {
         stage_rows<64>(A, gm, g, loc0, q0, As[wave], lane);
-        if (lane < BK) {
-            const int q = q0 + lane;
-            float t[4] = {0.f, 0.f, 0.f, 0.f};
-            if (q < gm.Q)
+        {
+            const int q = q0 + (lane & 31);
+            float t[4];
 #pragma unroll
-                for (int n = 0; n < 4; n++)
-                    if (n < gm.N) t[n] = Bg[(size_t)q * gm.N + n];
-            Bs[wave][lane] = make_float4(t[0], t[1], t[2], t[3]);
+            for (int n = 0; n < 4; n++) {
+                const bool ok = q < gm.Q && n < gm.N;
+                const float x = Bg[ok ? (size_t)q * gm.N + n : 0];
+                t[n] = ok ? x : 0.0f;
+            }
+            Bs[wave][lane & 31] = make_float4(t[0], t[1], t[2], t[3]);   // lanes 32..63 rewrite the same values
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -568,33 +604,28 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(const float* __restrict__ A,
         for (int j = 0; j < 4; j++) {
             const int f = tid + j * 256, kk = f >> 5, cg = (f & 31) * 4;
             const int k = k0 + kk, q = q0 + cg;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (k < KT) {
-                const int sl = k / gm.P, p = k - sl * gm.P;
-                const int e = gm.a0 + p * gm.sa + q;
-                const float* src = A + (size_t)(g * gm.B + sl) * gm.lda + e;
-                if (q + 3 < gm.Q && e >= 0 && e + 3 < gm.amax && (((uintptr_t)src) & 15) == 0) {
-                    v = *(const float4*)src;
-                } else {
-                    float t[4] = {0.f, 0.f, 0.f, 0.f};
+            const int kc = k < KT ? k : 0;
+            const int sl = kc / gm.P, p = kc - sl * gm.P;
+            const int e = gm.a0 + p * gm.sa + q;
+            const float* base = A + (size_t)(g * gm.B + sl) * gm.lda;
+            float t[4];
 #pragma unroll
-                    for (int u = 0; u < 4; u++)
-                        if (q + u < gm.Q && e + u >= 0 && e + u < gm.amax) t[u] = src[u];
-                    v = make_float4(t[0], t[1], t[2], t[3]);
-                }
+            for (int u = 0; u < 4; u++) {
+                const bool ok = k < KT && q + u < gm.Q && e + u >= 0 && e + u < gm.amax;
+                const float x = base[ok ? e + u : 0];
+                t[u] = ok ? x : 0.0f;
             }
-            *(float4*)&As[kk][cg] = v;
+            *(float4*)&As[kk][cg] = make_float4(t[0], t[1], t[2], t[3]);
         }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int f = tid + j * 256, kk = f >> 5, n = f & 31;
             const int k = k0 + kk;
-            float v = 0.0f;
-            if (k < KT && n < gm.N) {
-                const int sl = k / gm.P, p = k - sl * gm.P;
-                v = C[(size_t)(g * gm.B + sl) * gm.ldc + (size_t)p * gm.N + n];
-            }
-            Cs[kk][n] = v;
+            const bool ok = k < KT && n < gm.N;
+            const int kc = ok ? k : 0;
+            const int sl = kc / gm.P, p = kc - sl * gm.P;
+            const float x = C[(size_t)(g * gm.B + sl) * gm.ldc + (size_t)p * gm.N + (ok ? n : 0)];
+            Cs[kk][n] = ok ? x : 0.0f;
         }
         __syncthreads();
 #pragma unroll
@@ -663,13 +694,12 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ A, cons
             const int idx = tid + it * 256;
             const int kk = idx / BM, qq = idx % BM;       // contiguous in q
             const int k = k0 + kk, q = q0 + qq;
-            float v = 0.0f;
-            if (k < KT && q < gm.Q) {
-                const int sl = k / gm.P, p = k - sl * gm.P;
-                const int e = gm.a0 + p * gm.sa + q;
-                if (e >= 0 && e < gm.amax) v = A[(size_t)(g * gm.B + sl) * gm.lda + e];
-            }
-            As[kk][qq] = v;
+            const int kc = k < KT ? k : 0;
+            const int sl = kc / gm.P, p = kc - sl * gm.P;
+            const int e = gm.a0 + p * gm.sa + q;
+            const bool ok = k < KT && q < gm.Q && e >= 0 && e < gm.amax;
+            const float v = A[(size_t)(g * gm.B + sl) * gm.lda + (ok ? e : 0)];
+            As[kk][qq] = ok ? v : 0.0f;
         }
 #pragma unroll
         for (int it = 0; it < (BK * BN + 255) / 256; it++) {
@@ -677,12 +707,11 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ A, cons
             if (idx < BK * BN) {
                 const int kk = idx / BN, nn = idx % BN;
                 const int k = k0 + kk, n = n0 + nn;
-                float v = 0.0f;
-                if (k < KT && n < gm.N) {
-                    const int sl = k / gm.P, p = k - sl * gm.P;
-                    v = C[(size_t)(g * gm.B + sl) * gm.ldc + (size_t)p * gm.N + n];
-                }
-                Cs[kk][nn] = v;
+                const bool ok = k < KT && n < gm.N;
+                const int kc = ok ? k : 0;
+                const int sl = kc / gm.P, p = kc - sl * gm.P;
+                const float v = C[(size_t)(g * gm.B + sl) * gm.ldc + (size_t)p * gm.N + (ok ? n : 0)];
+                Cs[kk][nn] = ok ? v : 0.0f;
             }
         }
         __syncthreads();

@@ -153,7 +153,7 @@ def test_groups_are_independent(ctx, pkg):
     acc = np.zeros_like(flat, dtype=np.float64)
     for g in range(3):
         l1, f1 = gpu_loss_grad(pkg, ctx, cdl, codes[g * B:(g + 1) * B], 1)
-        assert l1[0] == loss[g]
+        assert abs(l1[0] - loss[g]) <= 1e-6 * abs(loss[g])     # block partial sums meet in float atomics: last bit may differ
         acc += f1
     assert rel_inf(flat, acc) <= 1e-5
 
