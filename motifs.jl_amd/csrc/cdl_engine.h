@@ -30,6 +30,7 @@ struct TNode {
     float* g = nullptr;   // gradient (allocated on first use, zero-initialised)
     size_t n = 0;
     bool needs_grad = false;
+    const float* gmask = nullptr;   // if set: the gradient is only ever consumed where gmask != 0
 };
 typedef TNode* Tensor;    // nodes are owned by the engine and die at reset()
 
@@ -55,6 +56,12 @@ struct ToepGeom {
     int64_t lda, ldc;      // elements per sequence of A and C
     int B;                 // sequences per group
     int64_t ldb;           // elements per group of Bm (0 = shared)
+};
+
+// Syntax-layer geometry for the sparse forms: codes T [S][l][K], images [S][c][W], filters of height h.
+struct SpDims {
+    int S, B, l, K, c, W, h;
+    int64_t ldf;   // filter elements per group (h*W*K), 0 = shared
 };
 
 struct Engine {
@@ -88,6 +95,10 @@ struct Engine {
     Tensor sumsq_groups(Tensor x, float coef, int groups);                // [groups]: coef * sum x^2 per group
     Tensor toep(Tensor A, Tensor Bm, const ToepGeom& gm);                 // Toeplitz GEMM
     Tensor wgrad(Tensor A, Tensor C, const ToepGeom& gm);                 // [G][Q][N] = sum_{s,p} Aw * C
+    // syntax layer with sparse codes (X keeps ~q entries per read; gradients into it are masked):
+    Tensor sp_syn(Tensor T, Tensor FAf, Tensor Fk, const SpDims& d);      // FX = sum(conv(X,F,pad,groups=K),dims=3)
+    Tensor ana_sp(Tensor img, Tensor FA, Tensor FAf, const SpDims& d, const ToepGeom& gm);   // conv(img,F,flipped)
+    Tensor wgrad_sp(Tensor img, Tensor T, const SpDims& d);               // [G][h][W][K] = sum_{s,p} img[p+i][j] T[p][k]
     Tensor expandD(Tensor D, int g, int M, int fl);                       // [g][M][4fl] -> [g][fl*4][2M]
     Tensor collapseD(Tensor GA, int g, int M, int fl);                    // adjoint of expandD
     Tensor swap02(Tensor x, int g, int d0, int d1, int d2);               // per group [d0][d1][d2] -> [d2][d1][d0]

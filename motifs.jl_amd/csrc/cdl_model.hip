@@ -75,25 +75,31 @@ struct Graph {
         Tensor bit = e.make(Xu->n, false);
         if (e.failed) return Xu;
         topq_mask(e.st, Xu->v, bit->v, S, m->l * m->K, m->q);
-        return e.maskmul(Xu, bit->v, 1.0f);
+        Tensor X = e.maskmul(Xu, bit->v, 1.0f);
+        X->gmask = bit->v;            // every gradient into X passes this mask on its way to Xu
+        return X;
     }
     // the two filter banks in GEMM layout, analysis and (flipped) synthesis form
     struct Bank {
-        Tensor an, syn;
+        Tensor an, syn, raw;   // analysis layout, flipped synthesis layout, the reference layout it came from
         int g;
     };
+    SpDims spd(int g) const {
+        return SpDims{S, m->B, m->l, m->K, m->c, m->twoM, m->h, g == 1 ? 0 : (int64_t)m->h * m->twoM * m->K};
+    }
     Bank bankD(Tensor D, int g) {   // D [g][M][4fl]
         Tensor DA = e.expandD(D, g, m->M, m->fl);
-        return Bank{DA, e.flipT(DA, g, m->fl, 4, m->twoM), g};
+        return Bank{DA, e.flipT(DA, g, m->fl, 4, m->twoM), D, g};
     }
     Bank bankF(Tensor F, int g) {   // F [g][K][2M][h]
         Tensor FA = e.swap02(F, g, m->K, m->twoM, m->h);
-        return Bank{FA, e.flipT(FA, g, m->h, m->twoM, m->K), g};
+        return Bank{FA, e.flipT(FA, g, m->h, m->twoM, m->K), F, g};
     }
     Tensor synD(Tensor ZY, const Bank& b) { return e.toep(ZY, b.syn, with(gD2, b.g)); }     // sum_m conv(Z,D)+conv(Y,D,flipped)
     Tensor anaD(Tensor sig, const Bank& b) { return e.toep(sig, b.an, with(gD1, b.g)); }    // [conv(.,D,flipped) | conv(.,D)] rows 1:4:end
-    Tensor synF(Tensor X, const Bank& b) { return e.toep(X, b.syn, with(gF2, b.g)); }       // sum(conv(X,F,pad,groups=K),dims=3)
-    Tensor anaF(Tensor img, const Bank& b) { return e.toep(img, b.an, with(gF1, b.g)); }    // conv(img,F,flipped)
+    // syntax layer: X keeps ~q entries per read, so synthesis and every adjoint run per non-zero
+    Tensor synF(Tensor X, const Bank& b) { return e.sp_syn(X, b.syn, b.raw, spd(b.g)); }    // sum(conv(X,F,pad,groups=K),dims=3)
+    Tensor anaF(Tensor img, const Bank& b) { return e.ana_sp(img, b.an, b.syn, spd(b.g), with(gF1, b.g)); }   // conv(img,F,flipped)
 };
 
 struct Scalars {
@@ -195,7 +201,7 @@ static Tensor forward_loss(motifs_model* m, Graph& gr, bool train) {
         Tensor FXc = gr.synF(X, bFc);
         Tensor tgt = theta ? e.lin(ZYm, 1.0f, theta, 1.0f, 0.0f) : ZYm;
         Tensor R = e.lin(FXc, 1.0f, tgt, -1.0f, 0.0f);
-        Tensor Fgrad = e.swap02(e.wgrad(R, X, gr.gF1), G, m->h, m->twoM, m->K);
+        Tensor Fgrad = e.swap02(e.wgrad_sp(R, X, gr.spd(G)), G, m->h, m->twoM, m->K);
         Tensor t2 = e.lin(e.mul(Fgrad, sc.kst[t]), -1.0f, Fc, 1.0f, 0.0f);
         Tensor t3 = e.lin(t2, 1.0f, e.mul(sc.kst[t], sc.ks[t]), -1.0f, 0.0f);
         Fc = e.norml2(e.relu(t3), m->h * m->twoM);
