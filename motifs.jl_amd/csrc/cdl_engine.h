@@ -31,6 +31,17 @@ struct TNode {
     size_t n = 0;
     bool needs_grad = false;
     const float* gmask = nullptr;   // if set: the gradient is only ever consumed where gmask != 0
+    // cached non-zero lists (built on first use): of the values, and of gmask
+    int* nz_cnt = nullptr;
+    uint2* nz_ent = nullptr;
+    int* gm_cnt = nullptr;
+    uint2* gm_ent = nullptr;
+};
+
+struct NzView {
+    const int* cnt;       // [S]
+    const uint2* ent;     // [S][cap]: {flat index p*K + k, value bits}
+    int cap;
 };
 typedef TNode* Tensor;    // nodes are owned by the engine and die at reset()
 
@@ -79,6 +90,9 @@ struct Engine {
     Tensor make(size_t n, bool needs_grad);
     Tensor wrap(float* v, float* g, size_t n, bool needs_grad);   // external storage (parameters)
     float* grad(Tensor t);         // allocate + zero on first use
+    NzView nz_build(const float* data, int S, int n_per);   // non-zero list of [S][n_per] values (memory order)
+    NzView nz_of(Tensor t, int S);                           // cached list of t's values
+    NzView nz_of_mask(Tensor t, int S);                      // cached list of t->gmask
     void note(const char* name, Tensor t) {
         if (keep_named) named[name] = t;
     }

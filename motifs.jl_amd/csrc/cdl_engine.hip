@@ -978,185 +978,170 @@ Tensor Engine::flipT(Tensor Bm, int g, int H, int W, int N) {
 // scan T for non-zeros themselves, so they stay correct (just slower) if T happens to be dense.
 // Non-zeros are taken in memory order (deterministic sums).
 // ---------------------------------------------------------------------------------------------
-struct NzList {
-    int p[64], k[64];
-    float v[64];
-};
-
-// Compact the non-zeros of chunk [e0, e0+nthreads) of a sequence's T into `nz` (LDS); returns the count.
-// All threads of the block must call it (it contains barriers).  Order = memory order.
-static __device__ __forceinline__ int block_collect_nz(const float* __restrict__ T, int e0, int n, int K,
-                                                       NzList* nz, int* wcnt, int first_slot) {
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nw = blockDim.x >> 6;
-    const int e = e0 + tid;
-    const float v = e < n ? T[e] : 0.0f;
-    const bool hit = v != 0.0f;
-    const uint64_t m = __builtin_amdgcn_ballot_w64(hit);
-    if (lane == 0) wcnt[wv] = __builtin_popcountll(m);
+// Non-zero list of a [S][n] tensor: one block per read, entries in memory order (deterministic sums).
+__global__ __launch_bounds__(256) void k_build_nz(const float* __restrict__ x, int n, int* __restrict__ cnt,
+                                                  uint2* __restrict__ ent) {
+    __shared__ int wcnt[4];
+    __shared__ int run_sh;
+    const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const float* xs = x + (size_t)s * n;
+    uint2* es = ent + (size_t)s * n;
+    if (tid == 0) run_sh = 0;
     __syncthreads();
-    int base = first_slot, total = first_slot;
-    for (int w = 0; w < nw; w++) {
-        if (w < wv) base += wcnt[w];
-        total += wcnt[w];
+    for (int e0 = 0; e0 < n; e0 += 256) {
+        const int e = e0 + tid;
+        const float v = e < n ? xs[e] : 0.0f;
+        const bool hit = v != 0.0f;
+        const uint64_t m = __builtin_amdgcn_ballot_w64(hit);
+        if (lane == 0) wcnt[wv] = __builtin_popcountll(m);
+        __syncthreads();
+        int base = run_sh;
+        for (int w = 0; w < wv; w++) base += wcnt[w];
+        if (hit) es[base + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = make_uint2((unsigned)e, __float_as_uint(v));
+        __syncthreads();
+        if (tid == 0) run_sh += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+        __syncthreads();
     }
-    if (hit) {
-        const int slot = base + __builtin_popcountll(m & ((1ull << lane) - 1ull));
-        if (slot >= 0 && slot < 64) {
-            nz->p[slot] = e / K;
-            nz->k[slot] = e - (e / K) * K;
-            nz->v[slot] = v;
-        }
-    }
-    __syncthreads();
-    return total;   // first_slot + number of non-zeros in the chunk
+    if (tid == 0) cnt[s] = run_sh;
 }
 
-// S1: out[s][r][j] (+)= sum_nz v * FAf[g][p - r + h - 1][k][j]      (block = one read, thread = column j)
-__global__ __launch_bounds__(512) void k_sp_syn(const float* __restrict__ T, const float* __restrict__ FAf,
-                                                float* __restrict__ out, SpDims d, int acc) {
-    __shared__ NzList nz;
-    __shared__ int wcnt[8];
-    const int s = blockIdx.x, tid = threadIdx.x;
-    const float* Ts = T + (size_t)s * d.l * d.K;
+// S1: out[s][r][j] (+)= sum_nz v * FAf[g][p - r + h - 1][k][j]      (block = (read, 128 columns), thread = column j)
+__global__ __launch_bounds__(128) void k_sp_syn(NzView nz, const float* __restrict__ FAf, float* __restrict__ out,
+                                                SpDims d, int acc) {
+    const int s = blockIdx.y, j = blockIdx.x * 128 + threadIdx.x;
+    if (j >= d.W) return;
     const float* Fg = FAf + (size_t)(s / d.B) * d.ldf;
     float* os = out + (size_t)s * d.c * d.W;
-    if (!acc) {
-        for (int i = tid; i < d.c * d.W; i += 512) os[i] = 0.0f;
-        __syncthreads();
-    }
-    const int n = d.l * d.K;
-    for (int e0 = 0; e0 < n; e0 += 512) {
-        // a chunk of 512 entries holds up to 512 non-zeros; they are consumed in rounds of 64 slots
-        const int total = block_collect_nz(Ts, e0, n, d.K, &nz, wcnt, 0);
-        for (int done = 0; done < total; done += 64) {
-            if (done > 0) block_collect_nz(Ts, e0, n, d.K, &nz, wcnt, -done);   // re-scan: ranks [done, done+64)
-            const int m = total - done < 64 ? total - done : 64;
-            for (int z = 0; z < m; z++) {
-                const int p = nz.p[z], k = nz.k[z];
-                const float v = nz.v[z];
-                for (int j = tid; j < d.W; j += 512)
-                    for (int ip = 0; ip < d.h; ip++) {
-                        const int r = p + d.h - 1 - ip;
-                        os[(size_t)r * d.W + j] += v * Fg[((size_t)ip * d.K + k) * d.W + j];
-                    }
-            }
-            __syncthreads();
+    if (!acc)
+        for (int r = 0; r < d.c; r++) os[(size_t)r * d.W + j] = 0.0f;
+    const int cnt = nz.cnt[s];
+    const uint2* es = nz.ent + (size_t)s * nz.cap;
+    for (int z = 0; z < cnt; z++) {
+        const uint2 en = es[z];
+        const int p = (int)(en.x / (unsigned)d.K), k = (int)(en.x - (unsigned)p * d.K);
+        const float v = __uint_as_float(en.y);
+        for (int ip = 0; ip < d.h; ip++) {
+            const int r = p + d.h - 1 - ip;
+            os[(size_t)r * d.W + j] += v * Fg[((size_t)ip * d.K + k) * d.W + j];
         }
-        __syncthreads();
     }
 }
 
-// S2: dFAf[g][ip][k][j] += sum_{s in g} sum_nz v * dOut[s][p + h - 1 - ip][j]     (block = (group, 128 columns))
-__global__ __launch_bounds__(128) void k_sp_wgrad_syn(const float* __restrict__ T, const float* __restrict__ dOut,
-                                                      float* __restrict__ dF, SpDims d) {
-    __shared__ NzList nz;
-    __shared__ int wcnt[2];
-    const int g = blockIdx.y, j = blockIdx.x * 128 + threadIdx.x;
-    float* dFg = dF + (size_t)g * d.h * d.K * d.W;
-    const int n = d.l * d.K;
+// S2: dFAf[g][ip][k][j] += sum_{s in g} sum_nz v * dOut[s][p + h - 1 - ip][j]     (block = (128 columns, ip, group))
+__global__ __launch_bounds__(128) void k_sp_wgrad_syn(NzView nz, const float* __restrict__ dOut, float* __restrict__ dF,
+                                                      SpDims d) {
+    const int g = blockIdx.z, ip = blockIdx.y, j = blockIdx.x * 128 + threadIdx.x;
+    if (j >= d.W) return;
+    float* dFg = dF + (size_t)g * d.h * d.K * d.W + (size_t)ip * d.K * d.W;
     for (int b = 0; b < d.B; b++) {
         const int s = g * d.B + b;
-        const float* Ts = T + (size_t)s * n;
         const float* ds = dOut + (size_t)s * d.c * d.W;
-        for (int e0 = 0; e0 < n; e0 += 128) {
-            const int total = block_collect_nz(Ts, e0, n, d.K, &nz, wcnt, 0);
-            for (int done = 0; done < total; done += 64) {
-                if (done > 0) block_collect_nz(Ts, e0, n, d.K, &nz, wcnt, -done);
-                const int m = total - done < 64 ? total - done : 64;
-                if (j < d.W)
-                    for (int z = 0; z < m; z++) {
-                        const int p = nz.p[z], k = nz.k[z];
-                        const float v = nz.v[z];
-                        for (int ip = 0; ip < d.h; ip++)
-                            dFg[((size_t)ip * d.K + k) * d.W + j] += v * ds[(size_t)(p + d.h - 1 - ip) * d.W + j];
-                    }
-                __syncthreads();
-            }
-            __syncthreads();
+        const int cnt = nz.cnt[s];
+        const uint2* es = nz.ent + (size_t)s * nz.cap;
+        for (int z = 0; z < cnt; z++) {
+            const uint2 en = es[z];
+            const int p = (int)(en.x / (unsigned)d.K), k = (int)(en.x - (unsigned)p * d.K);
+            dFg[(size_t)k * d.W + j] += __uint_as_float(en.y) * ds[(size_t)(p + d.h - 1 - ip) * d.W + j];
         }
     }
 }
 
-// S3: dB[g][i][j][k] (+)= sum_{s in g} sum_nz v * img[s][p + i][j]                 (block = (group, 128 columns))
-__global__ __launch_bounds__(128) void k_sp_wgrad_ana(const float* __restrict__ img, const float* __restrict__ T,
-                                                      float* __restrict__ dB, SpDims d, int acc) {
-    __shared__ NzList nz;
-    __shared__ int wcnt[2];
-    const int g = blockIdx.y, j = blockIdx.x * 128 + threadIdx.x;
-    float* dBg = dB + (size_t)g * d.h * d.W * d.K;
-    const int n = d.l * d.K;
-    if (!acc && j < d.W)
-        for (int i = 0; i < d.h; i++)
-            for (int k = 0; k < d.K; k++) dBg[((size_t)i * d.W + j) * d.K + k] = 0.0f;
+// S3: dB[g][i][j][k] (+)= sum_{s in g} sum_nz v * img[s][p + i][j]                 (block = (128 columns, i, group))
+__global__ __launch_bounds__(128) void k_sp_wgrad_ana(const float* __restrict__ img, NzView nz, float* __restrict__ dB,
+                                                      SpDims d, int acc) {
+    const int g = blockIdx.z, i = blockIdx.y, j = blockIdx.x * 128 + threadIdx.x;
+    if (j >= d.W) return;
+    float* row = dB + (size_t)g * d.h * d.W * d.K + ((size_t)i * d.W + j) * d.K;
+    if (!acc)
+        for (int k = 0; k < d.K; k++) row[k] = 0.0f;
     for (int b = 0; b < d.B; b++) {
         const int s = g * d.B + b;
-        const float* Ts = T + (size_t)s * n;
         const float* is = img + (size_t)s * d.c * d.W;
-        for (int e0 = 0; e0 < n; e0 += 128) {
-            const int total = block_collect_nz(Ts, e0, n, d.K, &nz, wcnt, 0);
-            for (int done = 0; done < total; done += 64) {
-                if (done > 0) block_collect_nz(Ts, e0, n, d.K, &nz, wcnt, -done);
-                const int m = total - done < 64 ? total - done : 64;
-                if (j < d.W)
-                    for (int z = 0; z < m; z++) {
-                        const int p = nz.p[z], k = nz.k[z];
-                        const float v = nz.v[z];
-                        for (int i = 0; i < d.h; i++) dBg[((size_t)i * d.W + j) * d.K + k] += v * is[(size_t)(p + i) * d.W + j];
-                    }
-                __syncthreads();
-            }
-            __syncthreads();
+        const int cnt = nz.cnt[s];
+        const uint2* es = nz.ent + (size_t)s * nz.cap;
+        for (int z = 0; z < cnt; z++) {
+            const uint2 en = es[z];
+            const int p = (int)(en.x / (unsigned)d.K), k = (int)(en.x - (unsigned)p * d.K);
+            row[k] += __uint_as_float(en.y) * is[(size_t)(p + i) * d.W + j];
         }
     }
 }
 
-// S4: out[s][p][k] += sum_{i,j} img[s][p+i][j] * Fk[g][k][j][i]   only where mask[s][p][k] != 0
-// (block = one read, one wave per masked entry; Fk is the reference layout F (h,2M,1,K): i fastest)
-__global__ __launch_bounds__(512) void k_sp_ana_masked(const float* __restrict__ img, const float* __restrict__ Fk,
-                                                       const float* __restrict__ mask, float* __restrict__ out, SpDims d) {
-    __shared__ NzList nz;
-    __shared__ int wcnt[8];
-    const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const float* ms = mask + (size_t)s * d.l * d.K;
+// S4: out[s][p][k] += sum_{i,j} img[s][p+i][j] * Fk[g][k][j][i]   only at the listed (masked) entries
+// (one wave per entry; Fk is the reference layout F (h,2M,1,K): i fastest)
+__global__ __launch_bounds__(256) void k_sp_ana_masked(const float* __restrict__ img, const float* __restrict__ Fk,
+                                                       NzView nz, float* __restrict__ out, SpDims d) {
+    const int s = blockIdx.y, lane = threadIdx.x & 63;
+    const int cnt = nz.cnt[s];
     const float* is = img + (size_t)s * d.c * d.W;
-    const float* Fg = Fk + (size_t)(s / d.B) * d.ldf;
-    float* os = out + (size_t)s * d.l * d.K;
-    const int n = d.l * d.K;
-    for (int e0 = 0; e0 < n; e0 += 512) {
-        const int total = block_collect_nz(ms, e0, n, d.K, &nz, wcnt, 0);
-        for (int done = 0; done < total; done += 64) {
-            if (done > 0) block_collect_nz(ms, e0, n, d.K, &nz, wcnt, -done);
-            const int m = total - done < 64 ? total - done : 64;
-            for (int z = wv; z < m; z += 8) {
-                const int p = nz.p[z], k = nz.k[z];
-                const float* fk = Fg + (size_t)k * d.W * d.h;
-                float a = 0.0f;
-                for (int j = lane; j < d.W; j += 64)
-                    for (int i = 0; i < d.h; i++) a = fmaf(is[(size_t)(p + i) * d.W + j], fk[(size_t)j * d.h + i], a);
-                for (int dd = 32; dd >= 1; dd >>= 1) a += __shfl_xor(a, dd);
-                if (lane == 0) os[(size_t)p * d.K + k] += a;
-            }
-            __syncthreads();
-        }
-        __syncthreads();
+    for (int z = blockIdx.x * 4 + (threadIdx.x >> 6); z < cnt; z += gridDim.x * 4) {   // wave-uniform
+        const uint2 en = nz.ent[(size_t)s * nz.cap + z];
+        const int p = (int)(en.x / (unsigned)d.K), k = (int)(en.x - (unsigned)p * d.K);
+        const float* fk = Fk + (size_t)(s / d.B) * d.ldf + (size_t)k * d.W * d.h;
+        float a = 0.0f;
+        for (int j = lane; j < d.W; j += 64)
+            for (int i = 0; i < d.h; i++) a = fmaf(is[(size_t)(p + i) * d.W + j], fk[(size_t)j * d.h + i], a);
+        for (int dd = 32; dd >= 1; dd >>= 1) a += __shfl_xor(a, dd);
+        if (lane == 0) out[(size_t)s * d.l * d.K + en.x] += a;
     }
 }
 
-static void launch_sp_syn(hipStream_t st, const float* T, const float* FAf, float* out, const SpDims& d, int acc) {
-    hipLaunchKernelGGL(k_sp_syn, dim3(d.S), dim3(512), 0, st, T, FAf, out, d, acc);
+NzView Engine::nz_build(const float* data, int S, int n_per) {
+    NzView v{nullptr, nullptr, n_per};
+    int* cnt = (int*)arena.alloc((size_t)S + 64);
+    uint2* ent = (uint2*)arena.alloc((size_t)S * n_per * 2);
+    if (!cnt || !ent) {
+        failed = true;
+        return v;
+    }
+    hipLaunchKernelGGL(k_build_nz, dim3(S), dim3(256), 0, st, data, n_per, cnt, ent);
+    v.cnt = cnt;
+    v.ent = ent;
+    return v;
+}
+NzView Engine::nz_of(Tensor t, int S) {
+    const int n_per = (int)(t->n / S);
+    if (!t->nz_cnt) {
+        NzView v = nz_build(t->v, S, n_per);
+        t->nz_cnt = const_cast<int*>(v.cnt);
+        t->nz_ent = const_cast<uint2*>(v.ent);
+    }
+    return NzView{t->nz_cnt, t->nz_ent, n_per};
+}
+NzView Engine::nz_of_mask(Tensor t, int S) {
+    const int n_per = (int)(t->n / S);
+    if (!t->gm_cnt) {
+        NzView v = nz_build(t->gmask, S, n_per);
+        t->gm_cnt = const_cast<int*>(v.cnt);
+        t->gm_ent = const_cast<uint2*>(v.ent);
+    }
+    return NzView{t->gm_cnt, t->gm_ent, n_per};
+}
+
+// 32 waves per read walk its entry list (any length)
+static void launch_sp_ana_masked(hipStream_t st, const float* img, const float* Fk, const NzView& nz, float* out,
+                                 const SpDims& d, int) {
+    hipLaunchKernelGGL(k_sp_ana_masked, dim3(8, d.S), dim3(256), 0, st, img, Fk, nz, out, d);
+}
+
+static void launch_sp_syn(hipStream_t st, const NzView& nz, const float* FAf, float* out, const SpDims& d, int acc) {
+    hipLaunchKernelGGL(k_sp_syn, dim3((d.W + 127) / 128, d.S), dim3(128), 0, st, nz, FAf, out, d, acc);
 }
 
 Tensor Engine::sp_syn(Tensor T, Tensor FAf, Tensor Fk, const SpDims& d) {
     Tensor out = make((size_t)d.S * d.c * d.W, T->needs_grad || FAf->needs_grad);
     if (failed) return out;
-    launch_sp_syn(st, T->v, FAf->v, out->v, d, 0);
+    NzView nz = nz_of(T, d.S);
+    if (failed) return out;
+    launch_sp_syn(st, nz, FAf->v, out->v, d, 0);
     if (recording && out->needs_grad)
-        tape.push_back([this, out, T, FAf, Fk, d]() {
+        tape.push_back([this, out, T, FAf, Fk, d, nz]() {
             if (!out->g) return;
             if (T->needs_grad) {
                 float* dT = grad(T);
                 if (dT && T->gmask) {
-                    hipLaunchKernelGGL(k_sp_ana_masked, dim3(d.S), dim3(512), 0, st, out->g, Fk->v, T->gmask, dT, d);
+                    NzView mz = nz_of_mask(T, d.S);
+                    if (!failed) launch_sp_ana_masked(st, out->g, Fk->v, mz, dT, d, d.l * d.K);
                 } else if (dT) {   // no mask known: dense adjoint
                     ToepGeom gm{d.S, d.c, d.h * d.K, d.W, d.K, -(d.h - 1) * d.K, d.l * d.K, (int64_t)d.l * d.K,
                                 (int64_t)d.c * d.W, d.B, d.ldf};
@@ -1168,7 +1153,7 @@ Tensor Engine::sp_syn(Tensor T, Tensor FAf, Tensor Fk, const SpDims& d) {
                 const int G = d.S / d.B;
                 if (!dF) return;
                 if (d.ldf != 0) {
-                    hipLaunchKernelGGL(k_sp_wgrad_syn, dim3((d.W + 127) / 128, G), dim3(128), 0, st, T->v, out->g, dF, d);
+                    hipLaunchKernelGGL(k_sp_wgrad_syn, dim3((d.W + 127) / 128, d.h, G), dim3(128), 0, st, nz, out->g, dF, d);
                 } else {
                     const size_t per = (size_t)d.h * d.K * d.W;
                     float* tmp = arena.alloc(per * G);
@@ -1177,7 +1162,7 @@ Tensor Engine::sp_syn(Tensor T, Tensor FAf, Tensor Fk, const SpDims& d) {
                         return;
                     }
                     (void)hipMemsetAsync(tmp, 0, per * G * 4, st);
-                    hipLaunchKernelGGL(k_sp_wgrad_syn, dim3((d.W + 127) / 128, G), dim3(128), 0, st, T->v, out->g, tmp, d);
+                    hipLaunchKernelGGL(k_sp_wgrad_syn, dim3((d.W + 127) / 128, d.h, G), dim3(128), 0, st, nz, out->g, tmp, d);
                     hipLaunchKernelGGL(k_sum_groups, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, st, tmp, per, G, dF);
                 }
             }
@@ -1193,16 +1178,18 @@ Tensor Engine::ana_sp(Tensor img, Tensor FA, Tensor FAf, const SpDims& d, const 
         tape.push_back([this, out, img, FA, FAf, d]() {
             if (!out->g) return;
             // d(out) is non-zero only where the top-q masks let it through
+            NzView gz = nz_build(out->g, d.S, d.l * d.K);
+            if (failed) return;
             if (img->needs_grad) {
                 float* di = grad(img);
-                if (di) launch_sp_syn(st, out->g, FAf->v, di, d, 1);
+                if (di) launch_sp_syn(st, gz, FAf->v, di, d, 1);
             }
             if (FA->needs_grad) {
                 float* dB = grad(FA);
                 const int G = d.S / d.B;
                 if (!dB) return;
                 if (d.ldf != 0) {
-                    hipLaunchKernelGGL(k_sp_wgrad_ana, dim3((d.W + 127) / 128, G), dim3(128), 0, st, img->v, out->g, dB, d, 1);
+                    hipLaunchKernelGGL(k_sp_wgrad_ana, dim3((d.W + 127) / 128, d.h, G), dim3(128), 0, st, img->v, gz, dB, d, 1);
                 } else {
                     const size_t per = (size_t)d.h * d.W * d.K;
                     float* tmp = arena.alloc(per * G);
@@ -1210,7 +1197,7 @@ Tensor Engine::ana_sp(Tensor img, Tensor FA, Tensor FAf, const SpDims& d, const 
                         failed = true;
                         return;
                     }
-                    hipLaunchKernelGGL(k_sp_wgrad_ana, dim3((d.W + 127) / 128, G), dim3(128), 0, st, img->v, out->g, tmp, d, 0);
+                    hipLaunchKernelGGL(k_sp_wgrad_ana, dim3((d.W + 127) / 128, d.h, G), dim3(128), 0, st, img->v, gz, tmp, d, 0);
                     hipLaunchKernelGGL(k_sum_groups, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, st, tmp, per, G, dB);
                 }
             }
@@ -1222,9 +1209,11 @@ Tensor Engine::wgrad_sp(Tensor img, Tensor T, const SpDims& d) {
     const int G = d.S / d.B;
     Tensor out = make((size_t)G * d.h * d.W * d.K, img->needs_grad || T->needs_grad);
     if (failed) return out;
-    hipLaunchKernelGGL(k_sp_wgrad_ana, dim3((d.W + 127) / 128, G), dim3(128), 0, st, img->v, T->v, out->v, d, 0);
+    NzView nz = nz_of(T, d.S);
+    if (failed) return out;
+    hipLaunchKernelGGL(k_sp_wgrad_ana, dim3((d.W + 127) / 128, d.h, G), dim3(128), 0, st, img->v, nz, out->v, d, 0);
     if (recording && out->needs_grad)
-        tape.push_back([this, out, img, T, d, G]() {
+        tape.push_back([this, out, img, T, d, G, nz]() {
             if (!out->g) return;
             const size_t per = (size_t)d.h * d.W * d.K;
             SpDims dg = d;
@@ -1237,7 +1226,7 @@ Tensor Engine::wgrad_sp(Tensor img, Tensor T, const SpDims& d) {
                     return;
                 }
                 hipLaunchKernelGGL(k_flipT, dim3(nblocks(per * G)), dim3(256), 0, st, out->g, G, d.h, d.W, d.K, tmp, 0);
-                launch_sp_syn(st, T->v, tmp, di, dg, 1);
+                launch_sp_syn(st, nz, tmp, di, dg, 1);
             }
             if (T->needs_grad) {
                 float* dT = grad(T);
@@ -1249,7 +1238,8 @@ Tensor Engine::wgrad_sp(Tensor img, Tensor T, const SpDims& d) {
                         return;
                     }
                     hipLaunchKernelGGL(k_swap02, dim3(nblocks(per * G)), dim3(256), 0, st, out->g, G, d.h, d.W, d.K, tk, 0);
-                    hipLaunchKernelGGL(k_sp_ana_masked, dim3(d.S), dim3(512), 0, st, img->v, tk, T->gmask, dT, dg);
+                    NzView mz = nz_of_mask(T, d.S);
+                    if (!failed) launch_sp_ana_masked(st, img->v, tk, mz, dT, dg, d.l * d.K);
                 } else {
                     ToepGeom gm{d.S, d.l, d.h * d.W, d.K, d.W, 0, d.c * d.W, (int64_t)d.c * d.W, (int64_t)d.l * d.K, d.B,
                                 (int64_t)per};
