@@ -461,6 +461,7 @@ __global__ __launch_bounds__(512) void k_toep_mfma(const float* __restrict__ A, 
     const int grp_rows = gm.B * gm.P;
     const int g = blockIdx.y;
     const int loc0 = blockIdx.x * 64 + rt * 32;
+    const int n0 = blockIdx.z * 32;                // column tile
     const float* Bg = Bm + (size_t)g * gm.ldb;
     f32x16 accv;
 #pragma unroll
@@ -472,8 +473,8 @@ __global__ __launch_bounds__(512) void k_toep_mfma(const float* __restrict__ A, 
         for (int j = 0; j < 16; j++) {
             const int f = lane + j * 64, kk = f >> 5, n = f & 31;
             const int q = q0 + kk;
-            const bool ok = q < gm.Q && n < gm.N;
-            const float x = Bg[ok ? (size_t)q * gm.N + n : 0];
+            const bool ok = q < gm.Q && n0 + n < gm.N;
+            const float x = Bg[ok ? (size_t)q * gm.N + n0 + n : 0];
             bt[j] = ok ? x : 0.0f;
         }
 #pragma unroll
@@ -506,7 +507,7 @@ __global__ __launch_bounds__(512) void k_toep_mfma(const float* __restrict__ A, 
 #pragma unroll
             for (int r = 0; r < 16; r++) accv[r] += src[r * 64 + lane];
         }
-        const int col = lane & 31;
+        const int col = n0 + (lane & 31);
         if (col < gm.N) {
 #pragma unroll
             for (int r = 0; r < 16; r++) {
@@ -593,7 +594,7 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(const float* __restrict__ A,
     __shared__ float As[BK][BQ + 4];   // [k][q]
     __shared__ float Cs[BK][32 + 1];   // [k][n]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int g = blockIdx.y, q0 = blockIdx.x * BQ;
+    const int g = blockIdx.y, q0 = blockIdx.x * BQ, n0 = blockIdx.z * 32;
     const int KT = gm.B * gm.P;
     f32x16 accv;
 #pragma unroll
@@ -621,10 +622,10 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(const float* __restrict__ A,
         for (int j = 0; j < 4; j++) {
             const int f = tid + j * 256, kk = f >> 5, n = f & 31;
             const int k = k0 + kk;
-            const bool ok = k < KT && n < gm.N;
+            const bool ok = k < KT && n0 + n < gm.N;
             const int kc = ok ? k : 0;
             const int sl = kc / gm.P, p = kc - sl * gm.P;
-            const float x = C[(size_t)(g * gm.B + sl) * gm.ldc + (size_t)p * gm.N + (ok ? n : 0)];
+            const float x = C[(size_t)(g * gm.B + sl) * gm.ldc + (size_t)p * gm.N + (ok ? n0 + n : 0)];
             Cs[kk][n] = ok ? x : 0.0f;
         }
         __syncthreads();
@@ -636,7 +637,7 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(const float* __restrict__ A,
         }
         __syncthreads();
     }
-    const int col = lane & 31;
+    const int col = n0 + (lane & 31);
     if (col < gm.N) {
         float* out = dB + (size_t)g * gm.Q * gm.N;
 #pragma unroll
@@ -650,12 +651,104 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(const float* __restrict__ A,
     }
 }
 
-static void launch_toep(hipStream_t st, const float* A, const float* Bm, float* C, const ToepGeom& gm, int acc) {
-    // MFMA form: narrow output, long reduction, and blocks of 64 rows never straddle two filter groups
-    if (gm.N > 8 && gm.N <= 32 && gm.Q >= 256) {
+// ---- "tall" Toeplitz GEMMs: few output channels (N <= 8) over a window of H = Q/sa whole image rows of sa >= 64
+// columns (the D-layer synthesis: N = 4 bases, H = filter_len, sa = 2M).  Every image row then serves H*N outputs:
+//   W[s][rho][(i',n)] = sum_j A[s][rho][j] * Bm[i'][j][n]          (row GEMM, MFMA)
+//   C[s][r][n]        = sum_i' W[s][r + i' + a0/sa][i'][n]          (gather of H terms)
+// which reads each image element once per 32 x (H*N) tile instead of once per output row.
+__global__ void k_tall_bt(const float* __restrict__ Bm, int g, int H, int W, int N, float* __restrict__ Bt) {
+    const size_t per = (size_t)H * W * N, total = per * g;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t gg = i / per, r = i % per;          // r indexes Bt [W][H][N]
+        const int n = (int)(r % N), ip = (int)((r / N) % H), j = (int)(r / ((size_t)N * H));
+        Bt[i] = Bm[gg * per + ((size_t)ip * W + j) * N + n];
+    }
+}
+__global__ void k_tall_bt_T(const float* __restrict__ dBt, int g, int H, int W, int N, float* __restrict__ dBm, int acc) {
+    const size_t per = (size_t)H * W * N, total = per * g;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t gg = i / per, r = i % per;          // r indexes dBm [H][W][N]
+        const int n = (int)(r % N), j = (int)((r / N) % W), ip = (int)(r / ((size_t)N * W));
+        const float v = dBt[gg * per + ((size_t)j * H + ip) * N + n];
+        dBm[i] = acc ? dBm[i] + v : v;
+    }
+}
+__global__ void k_tall_gather(const float* __restrict__ Wt, float* __restrict__ C, int S, int P, int H, int N, int R, int off,
+                              int64_t ldc, int acc) {
+    const size_t total = (size_t)S * P * N;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int n = (int)(i % N), r = (int)((i / N) % P), s = (int)(i / ((size_t)N * P));
+        float a = 0.0f;
+        for (int ip = 0; ip < H; ip++) {
+            const int rho = r + ip + off;
+            if (rho >= 0 && rho < R) a += Wt[(((size_t)s * R + rho) * H + ip) * N + n];
+        }
+        float* o = &C[(size_t)s * ldc + (size_t)r * N + n];
+        *o = acc ? *o + a : a;
+    }
+}
+// dW[s][rho][i'][n] = dC[s][rho - i' - off][n]
+__global__ void k_tall_scatter(const float* __restrict__ dC, float* __restrict__ dW, int S, int P, int H, int N, int R, int off,
+                               int64_t ldc) {
+    const size_t total = (size_t)S * R * H * N;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int n = (int)(i % N), ip = (int)((i / N) % H);
+        const size_t t = i / ((size_t)N * H);
+        const int rho = (int)(t % R), s = (int)(t / R);
+        const int r = rho - ip - off;
+        dW[i] = (r >= 0 && r < P) ? dC[(size_t)s * ldc + (size_t)r * N + n] : 0.0f;
+    }
+}
+
+static bool is_tall(const ToepGeom& gm) {
+    if (gm.N > 8 || gm.sa < 64 || gm.Q % gm.sa != 0 || gm.amax % gm.sa != 0 || gm.a0 % gm.sa != 0) return false;
+    const int H = gm.Q / gm.sa;
+    return H >= 2 && H * gm.N <= 64 && H * gm.N > 8;
+}
+// the row GEMM behind both tall forms: rows = image rows, reduction = one row (sa), outputs = H*N
+static ToepGeom tall_row_geom(const ToepGeom& gm) {
+    const int H = gm.Q / gm.sa, R = gm.amax / gm.sa;
+    ToepGeom r;
+    r.S = gm.S;
+    r.P = R;
+    r.Q = gm.sa;
+    r.N = H * gm.N;
+    r.sa = gm.sa;
+    r.a0 = 0;
+    r.amax = gm.amax;
+    r.lda = gm.lda;
+    r.ldc = (int64_t)R * H * gm.N;
+    r.B = gm.B;
+    r.ldb = gm.ldb == 0 ? 0 : (int64_t)gm.Q * gm.N;
+    return r;
+}
+
+static void launch_toep(Engine& e, const float* A, const float* Bm, float* C, const ToepGeom& gm, int acc) {
+    hipStream_t st = e.st;
+    if (is_tall(gm)) {
+        const int H = gm.Q / gm.sa, R = gm.amax / gm.sa;
+        const int gB = gm.ldb == 0 ? 1 : gm.S / gm.B;
+        const size_t per = (size_t)gm.Q * gm.N;
+        float* Bt = e.arena.alloc(per * gB);
+        float* Wt = e.arena.alloc((size_t)gm.S * R * H * gm.N);
+        if (!Bt || !Wt) {
+            e.failed = true;
+            return;
+        }
+        hipLaunchKernelGGL(k_tall_bt, dim3(nblocks(per * gB)), dim3(256), 0, st, Bm, gB, H, gm.sa, gm.N, Bt);
+        const ToepGeom rg = tall_row_geom(gm);
+        const int grp_rows = rg.B * rg.P;
+        hipLaunchKernelGGL(k_toep_mfma, dim3((unsigned)((grp_rows + 63) / 64), (unsigned)(rg.S / rg.B), (unsigned)((rg.N + 31) / 32)),
+                           dim3(512), 0, st, A, Bt, Wt, rg, 0);
+        hipLaunchKernelGGL(k_tall_gather, dim3(nblocks((size_t)gm.S * gm.P * gm.N)), dim3(256), 0, st, Wt, C, gm.S, gm.P, H, gm.N, R,
+                           gm.a0 / gm.sa, gm.ldc, acc);
+        return;
+    }
+    // MFMA form: narrow output, long reduction (tiles never straddle two filter groups)
+    if (gm.N > 8 && gm.N <= 64 && gm.Q >= 256) {
         const int grp_rows = gm.B * gm.P;
-        hipLaunchKernelGGL(k_toep_mfma, dim3((unsigned)((grp_rows + 63) / 64), (unsigned)(gm.S / gm.B)), dim3(512), 0, st, A, Bm,
-                           C, gm, acc);
+        hipLaunchKernelGGL(k_toep_mfma, dim3((unsigned)((grp_rows + 63) / 64), (unsigned)(gm.S / gm.B), (unsigned)((gm.N + 31) / 32)),
+                           dim3(512), 0, st, A, Bm, C, gm, acc);
         return;
     }
     if (gm.N <= 4 && gm.Q >= 256) {
@@ -745,10 +838,27 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ A, cons
     }
 }
 
-static void launch_wgrad(hipStream_t st, const float* A, const float* C, float* dB, const ToepGeom& gm, int acc) {
+static void launch_wgrad(Engine& e, const float* A, const float* C, float* dB, const ToepGeom& gm, int acc) {
+    hipStream_t st = e.st;
     const int G = gm.S / gm.B;
-    if (gm.N > 8 && gm.N <= 32 && gm.Q >= 256) {
-        hipLaunchKernelGGL(k_wgrad_mfma, dim3((gm.Q + 127) / 128, G), dim3(256), 0, st, A, C, dB, gm, acc);
+    if (is_tall(gm)) {   // dBt[j][(i',n)] = sum_{s,rho} A[s][rho][j] * dW[s][rho][(i',n)], dW = scatter of C
+        const int H = gm.Q / gm.sa, R = gm.amax / gm.sa;
+        const size_t per = (size_t)gm.Q * gm.N;
+        float* dW = e.arena.alloc((size_t)gm.S * R * H * gm.N);
+        float* dBt = e.arena.alloc(per * G);
+        if (!dW || !dBt) {
+            e.failed = true;
+            return;
+        }
+        hipLaunchKernelGGL(k_tall_scatter, dim3(nblocks((size_t)gm.S * R * H * gm.N)), dim3(256), 0, st, C, dW, gm.S, gm.P, H, gm.N, R,
+                           gm.a0 / gm.sa, gm.ldc);
+        const ToepGeom rg = tall_row_geom(gm);
+        hipLaunchKernelGGL(k_wgrad_mfma, dim3((rg.Q + 127) / 128, G, (rg.N + 31) / 32), dim3(256), 0, st, A, dW, dBt, rg, 0);
+        hipLaunchKernelGGL(k_tall_bt_T, dim3(nblocks(per * G)), dim3(256), 0, st, dBt, G, H, gm.sa, gm.N, dB, acc);
+        return;
+    }
+    if (gm.N > 8 && gm.N <= 64 && gm.Q >= 256) {
+        hipLaunchKernelGGL(k_wgrad_mfma, dim3((gm.Q + 127) / 128, G, (gm.N + 31) / 32), dim3(256), 0, st, A, C, dB, gm, acc);
         return;
     }
     if (gm.N <= 32) {
@@ -830,14 +940,14 @@ static bool toep_adjoint_a(Engine& e, const float* dC, const float* Bm, float* d
     g2.ldc = gm.lda;
     g2.B = gm.B;
     g2.ldb = gm.ldb == 0 ? 0 : (int64_t)per;
-    launch_toep(e.st, dC, tmp, dA, g2, 1);
+    launch_toep(e, dC, tmp, dA, g2, 1);
     return true;
 }
 
 Tensor Engine::toep(Tensor A, Tensor Bm, const ToepGeom& gm) {
     Tensor out = make((size_t)gm.S * gm.ldc, A->needs_grad || Bm->needs_grad);
     if (failed) return out;
-    launch_toep(st, A->v, Bm->v, out->v, gm, 0);
+    launch_toep(*this, A->v, Bm->v, out->v, gm, 0);
     if (recording && out->needs_grad)
         tape.push_back([this, out, A, Bm, gm]() {
             if (!out->g) return;
@@ -850,7 +960,7 @@ Tensor Engine::toep(Tensor A, Tensor Bm, const ToepGeom& gm) {
                 if (!dB) return;
                 const int G = gm.S / gm.B;
                 if (gm.ldb != 0) {
-                    launch_wgrad(st, A->v, out->g, dB, gm, 1);
+                    launch_wgrad(*this, A->v, out->g, dB, gm, 1);
                 } else {   // shared filter: per-group partials, then a sum over groups
                     const size_t per = (size_t)gm.Q * gm.N;
                     float* tmp = arena.alloc(per * G);
@@ -858,7 +968,7 @@ Tensor Engine::toep(Tensor A, Tensor Bm, const ToepGeom& gm) {
                         failed = true;
                         return;
                     }
-                    launch_wgrad(st, A->v, out->g, tmp, gm, 0);
+                    launch_wgrad(*this, A->v, out->g, tmp, gm, 0);
                     hipLaunchKernelGGL(k_sum_groups, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, st, tmp, per, G, dB);
                 }
             }
@@ -870,7 +980,7 @@ Tensor Engine::wgrad(Tensor A, Tensor C, const ToepGeom& gm) {
     const int G = gm.S / gm.B;
     Tensor out = make((size_t)G * gm.Q * gm.N, A->needs_grad || C->needs_grad);
     if (failed) return out;
-    launch_wgrad(st, A->v, C->v, out->v, gm, 0);
+    launch_wgrad(*this, A->v, C->v, out->v, gm, 0);
     if (recording && out->needs_grad)
         tape.push_back([this, out, A, C, gm]() {
             if (!out->g) return;
@@ -882,7 +992,7 @@ Tensor Engine::wgrad(Tensor A, Tensor C, const ToepGeom& gm) {
             }
             if (C->needs_grad) {
                 float* dCc = grad(C);
-                if (dCc) launch_toep(st, A->v, out->g, dCc, g2, 1);
+                if (dCc) launch_toep(*this, A->v, out->g, dCc, g2, 1);
             }
         });
     return out;
@@ -1173,7 +1283,7 @@ Tensor Engine::sp_syn(Tensor T, Tensor FAf, Tensor Fk, const SpDims& d) {
 Tensor Engine::ana_sp(Tensor img, Tensor FA, Tensor FAf, const SpDims& d, const ToepGeom& gm) {
     Tensor out = make((size_t)d.S * d.l * d.K, img->needs_grad || FA->needs_grad);
     if (failed) return out;
-    launch_toep(st, img->v, FA->v, out->v, gm, 0);          // dense forward: every position is needed
+    launch_toep(*this, img->v, FA->v, out->v, gm, 0);       // dense forward: every position is needed
     if (recording && out->needs_grad)
         tape.push_back([this, out, img, FA, FAf, d]() {
             if (!out->g) return;
@@ -1243,7 +1353,7 @@ Tensor Engine::wgrad_sp(Tensor img, Tensor T, const SpDims& d) {
                 } else {
                     ToepGeom gm{d.S, d.l, d.h * d.W, d.K, d.W, 0, d.c * d.W, (int64_t)d.c * d.W, (int64_t)d.l * d.K, d.B,
                                 (int64_t)per};
-                    launch_toep(st, img->v, out->g, dT, gm, 1);
+                    launch_toep(*this, img->v, out->g, dT, gm, 1);
                 }
             }
         });
