@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--pwms", type=int, default=200)
     ap.add_argument("--pwm-len", type=int, default=12)
     ap.add_argument("--cpu-sample", type=int, default=600, help="sequences in the CPU-baseline sample")
-    ap.add_argument("--train-groups", type=int, default=32, help="mini-batches (of 6 reads) per optimiser step per GPU")
+    ap.add_argument("--train-groups", type=int, default=64, help="mini-batches (of 6 reads) per optimiser step per GPU")
     ap.add_argument("--train-steps", type=int, default=5)
     ap.add_argument("--filters", type=int, default=200)
     ap.add_argument("--filter-len", type=int, default=12)

@@ -1157,23 +1157,29 @@ __global__ __launch_bounds__(128) void k_sp_wgrad_syn(NzView nz, const float* __
 }
 
 // S3: dB[g][i][j][k] (+)= sum_{s in g} sum_nz v * img[s][p + i][j]                 (block = (128 columns, i, group))
+// Each thread owns the K outputs of its (i, j); they are accumulated in a private LDS row (the k index is
+// data-dependent) and written once.
 __global__ __launch_bounds__(128) void k_sp_wgrad_ana(const float* __restrict__ img, NzView nz, float* __restrict__ dB,
                                                       SpDims d, int acc) {
+    extern __shared__ float accs[];                      // [128][K + 1]
     const int g = blockIdx.z, i = blockIdx.y, j = blockIdx.x * 128 + threadIdx.x;
-    if (j >= d.W) return;
-    float* row = dB + (size_t)g * d.h * d.W * d.K + ((size_t)i * d.W + j) * d.K;
-    if (!acc)
-        for (int k = 0; k < d.K; k++) row[k] = 0.0f;
+    float* my = accs + (size_t)threadIdx.x * (d.K + 1);
+    for (int k = 0; k < d.K; k++) my[k] = 0.0f;
+    const int jc = j < d.W ? j : d.W - 1;                // clamp: out-of-range threads compute, do not store
     for (int b = 0; b < d.B; b++) {
         const int s = g * d.B + b;
-        const float* is = img + (size_t)s * d.c * d.W;
+        const float* is = img + (size_t)s * d.c * d.W + (size_t)i * d.W + jc;
         const int cnt = nz.cnt[s];
         const uint2* es = nz.ent + (size_t)s * nz.cap;
         for (int z = 0; z < cnt; z++) {
             const uint2 en = es[z];
             const int p = (int)(en.x / (unsigned)d.K), k = (int)(en.x - (unsigned)p * d.K);
-            row[k] += __uint_as_float(en.y) * is[(size_t)(p + i) * d.W + j];
+            my[k] = fmaf(__uint_as_float(en.y), is[(size_t)p * d.W], my[k]);
         }
+    }
+    if (j < d.W) {
+        float* row = dB + (size_t)g * d.h * d.W * d.K + ((size_t)i * d.W + j) * d.K;
+        for (int k = 0; k < d.K; k++) row[k] = acc ? row[k] + my[k] : my[k];
     }
 }
 
@@ -1299,7 +1305,7 @@ Tensor Engine::ana_sp(Tensor img, Tensor FA, Tensor FAf, const SpDims& d, const 
                 const int G = d.S / d.B;
                 if (!dB) return;
                 if (d.ldf != 0) {
-                    hipLaunchKernelGGL(k_sp_wgrad_ana, dim3((d.W + 127) / 128, d.h, G), dim3(128), 0, st, img->v, gz, dB, d, 1);
+                    hipLaunchKernelGGL(k_sp_wgrad_ana, dim3((d.W + 127) / 128, d.h, G), dim3(128), (size_t)128 * (d.K + 1) * 4, st, img->v, gz, dB, d, 1);
                 } else {
                     const size_t per = (size_t)d.h * d.W * d.K;
                     float* tmp = arena.alloc(per * G);
@@ -1307,7 +1313,7 @@ Tensor Engine::ana_sp(Tensor img, Tensor FA, Tensor FAf, const SpDims& d, const 
                         failed = true;
                         return;
                     }
-                    hipLaunchKernelGGL(k_sp_wgrad_ana, dim3((d.W + 127) / 128, d.h, G), dim3(128), 0, st, img->v, gz, tmp, d, 0);
+                    hipLaunchKernelGGL(k_sp_wgrad_ana, dim3((d.W + 127) / 128, d.h, G), dim3(128), (size_t)128 * (d.K + 1) * 4, st, img->v, gz, tmp, d, 0);
                     hipLaunchKernelGGL(k_sum_groups, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, st, tmp, per, G, dB);
                 }
             }
@@ -1321,7 +1327,7 @@ Tensor Engine::wgrad_sp(Tensor img, Tensor T, const SpDims& d) {
     if (failed) return out;
     NzView nz = nz_of(T, d.S);
     if (failed) return out;
-    hipLaunchKernelGGL(k_sp_wgrad_ana, dim3((d.W + 127) / 128, d.h, G), dim3(128), 0, st, img->v, nz, out->v, d, 0);
+    hipLaunchKernelGGL(k_sp_wgrad_ana, dim3((d.W + 127) / 128, d.h, G), dim3(128), (size_t)128 * (d.K + 1) * 4, st, img->v, nz, out->v, d, 0);
     if (recording && out->needs_grad)
         tape.push_back([this, out, img, T, d, G, nz]() {
             if (!out->g) return;
