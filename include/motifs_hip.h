@@ -209,6 +209,30 @@ int motifs_model_retrieve_codes(motifs_model* m, const void* data, int kind, int
 /* Test hook: a named intermediate of the last loss_grad call made with keep_intermediates != 0. */
 int motifs_model_dump(motifs_model* m, const char* name, float* out, int64_t cap, int64_t* n);
 
+/* ---- either side of the scan ----------------------------------------------------- */
+
+/* `reading`/`read_fasta` + base coding (loadfasta/helpers.jl:83-139): reads with N/n dropped, first
+ * max_entries kept (the reference uses 100000, helpers.jl:2), then only reads as long as the first.
+ * Host only.  codes_out: n_reads rows of L bytes (0..3); NULL queries *n_reads and *L. */
+int motifs_fasta_read(const char* path, int64_t max_entries, uint8_t* codes_out, int64_t cap_bytes, int64_t* n_reads,
+                      int32_t* L);
+/* get_min_score / get_max_score (_s2_filter_pos_w_scores.jl:11-35) over one record array: binary16 bits per
+ * PWM; +Inf / -Inf where a PWM has no record.  Combine data and background on the host (min of mins). */
+int motifs_hits_minmax_dev(motifs_ctx* ctx, const motifs_hit* hits_dev, const uint16_t* scores_dev, int64_t n, int K,
+                           uint16_t* min_dev, uint16_t* max_dev);
+/* get_hits (:3-9) for a whole threshold sweep at once: counts[m][j] += #{records of PWM m with
+ * score > thr[m][j]}; thr_dev: K rows of T ascending binary16 thresholds (pad with +Inf). */
+int motifs_hits_threshold_counts_dev(motifs_ctx* ctx, const motifs_hit* hits_dev, const uint16_t* scores_dev, int64_t n,
+                                     int K, const uint16_t* thr_dev, int T, int64_t* counts_dev);
+/* filter_position_by_best_thresh! (:116-125): keep records with score > thresh[m], order preserved. */
+int motifs_hits_filter_dev(motifs_ctx* ctx, const motifs_hit* hits_dev, const uint16_t* scores_dev, int64_t n, int K,
+                           const uint16_t* thresh_dev, motifs_hit* out_hits_dev, uint16_t* out_scores_dev, int64_t* n_out);
+/* posdicts2countmats (_h6_positions2countmat.jl:26-55) without the pseudo-count: counts_dev has the bytes of
+ * a (4, maxlen, K) UInt32 array and is incremented by the one-hot window of every record; comp != 0 adds the
+ * reverse complement (submat_comlement, _3_make_pfms.jl:49-52).  codes_dev row 0 is global sequence n0 + 1. */
+int motifs_hits_count_matrices_dev(motifs_ctx* ctx, const motifs_hit* hits_dev, int64_t n, const uint8_t* codes_dev, int L,
+                                   int64_t n0, const int64_t* lens, int K, int maxlen, int comp, uint32_t* counts_dev);
+
 #ifdef __cplusplus
 }
 #endif

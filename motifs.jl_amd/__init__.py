@@ -9,6 +9,6 @@ The directory name carries a dot, so it is not importable by name; load it with
   scan     host mirror of src/inference/_h3_1_alignment.jl:38-112
   synth    synthetic inputs of SURVEY.md §8(d)
 """
-from . import _lib, model, parallel, scan, synth  # noqa: F401
+from . import _lib, model, parallel, post, scan, synth  # noqa: F401
 
-__all__ = ["_lib", "model", "parallel", "scan", "synth"]
+__all__ = ["_lib", "model", "parallel", "post", "scan", "synth"]

@@ -74,6 +74,11 @@ SIGNATURES = {
     "motifs_model_train_step": (_int, [_p, _p, _int, _p, C.POINTER(C.c_float)]),
     "motifs_model_retrieve_codes": (_int, [_p, _p, _int, _i64, _p, _i64, C.POINTER(_i64)]),
     "motifs_model_dump": (_int, [_p, C.c_char_p, _p, _i64, C.POINTER(_i64)]),
+    "motifs_fasta_read": (_int, [C.c_char_p, _i64, _p, _i64, C.POINTER(_i64), C.POINTER(C.c_int32)]),
+    "motifs_hits_minmax_dev": (_int, [_p, _p, _p, _i64, _int, _p, _p]),
+    "motifs_hits_threshold_counts_dev": (_int, [_p, _p, _p, _i64, _int, _p, _int, _p]),
+    "motifs_hits_filter_dev": (_int, [_p, _p, _p, _i64, _int, _p, _p, _p, C.POINTER(_i64)]),
+    "motifs_hits_count_matrices_dev": (_int, [_p, _p, _i64, _p, _int, _i64, _p, _int, _int, _int, _p]),
     "motifs_pwm_scan": (
         _int,
         [_p, _p, _p, _int, _int, _p, _int, _i64, _int, _int, _p, _p, _i64, C.POINTER(_i64), _p],
@@ -196,6 +201,25 @@ class Context:
         check(code)
         return n_out.value
 
+    # ---- consumers of the hit records ----
+    def hits_minmax_dev(self, hits_ptr, scores_ptr, n, K, min_ptr, max_ptr):
+        check(lib().motifs_hits_minmax_dev(self._h, _p(hits_ptr), _p(scores_ptr), int(n), int(K), _p(min_ptr), _p(max_ptr)))
+
+    def hits_threshold_counts_dev(self, hits_ptr, scores_ptr, n, K, thr_ptr, T, counts_ptr):
+        check(lib().motifs_hits_threshold_counts_dev(self._h, _p(hits_ptr), _p(scores_ptr), int(n), int(K), _p(thr_ptr), int(T),
+                                                     _p(counts_ptr)))
+
+    def hits_filter_dev(self, hits_ptr, scores_ptr, n, K, thresh_ptr, out_hits_ptr, out_scores_ptr):
+        n_out = _i64(0)
+        check(lib().motifs_hits_filter_dev(self._h, _p(hits_ptr), _p(scores_ptr), int(n), int(K), _p(thresh_ptr), _p(out_hits_ptr),
+                                           _p(out_scores_ptr), C.byref(n_out)))
+        return n_out.value
+
+    def hits_count_matrices_dev(self, hits_ptr, n, codes_ptr, L, n0, lens, K, maxlen, comp, counts_ptr):
+        lens = np.ascontiguousarray(lens, dtype=np.int64)
+        check(lib().motifs_hits_count_matrices_dev(self._h, _p(hits_ptr), int(n), _p(codes_ptr), int(L), int(n0), _np_ptr(lens), int(K),
+                                                   int(maxlen), int(bool(comp)), _p(counts_ptr)))
+
     def pwm_scan(self, pwms, lens, data, kind, N, L, rc, cap=None, want_counts=False):
         """Host-buffer scan (the entry Julia's ccall binds).  cap=None sizes the
         buffers with a count-only first call."""
@@ -217,6 +241,15 @@ class Context:
         n = n_out.value
         out = (hits[:n], scores[:n].view(np.float16))
         return out + (counts,) if want_counts else out
+
+
+def fasta_read(path, max_entries=100000):
+    """read_fasta (loadfasta/helpers.jl:102-108) + base coding: (N, L) uint8 codes.  Host only, no GPU needed."""
+    n, L = _i64(0), C.c_int32(0)
+    check(lib().motifs_fasta_read(os.fsencode(path), int(max_entries), None, 0, C.byref(n), C.byref(L)))
+    out = np.zeros((n.value, L.value), dtype=np.uint8)
+    check(lib().motifs_fasta_read(os.fsencode(path), int(max_entries), _np_ptr(out), out.size, C.byref(n), C.byref(L)))
+    return out
 
 
 def _bank(pwms, lens):

@@ -1,0 +1,332 @@
+// post_kernels.hip — the consumers and the producer on either side of the scan:
+//   * FASTA text -> base codes                      (src/loadfasta/helpers.jl:83-139)
+//   * per-PWM score range, threshold sweep counts and threshold filtering of hit records
+//                                                   (src/inference/_s2_filter_pos_w_scores.jl:3-35, :103-125)
+//   * hit positions -> count matrices                (src/inference/_h6_positions2countmat.jl:26-55)
+// The device parts work on the record arrays motifs_pwm_scan_hits_dev leaves in HBM.
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "api_common.h"
+#include "scan_kernels.h"
+
+using namespace motifs;
+
+static __device__ __forceinline__ float h2f(uint16_t h) { return __half2float(__ushort_as_half(h)); }
+
+// ---- score range ----------------------------------------------------------------------------------
+// order-preserving 16-bit key of a binary16 value (so integer atomicMin/Max follow the float order)
+static __device__ __forceinline__ uint32_t hkey(uint16_t h) { return (h & 0x8000u) ? (uint16_t)~h : (uint16_t)(h | 0x8000u); }
+static __device__ __forceinline__ uint16_t hunkey(uint32_t k) { return (k & 0x8000u) ? (uint16_t)(k & 0x7fffu) : (uint16_t)~k; }
+
+__global__ void k_minmax_init(uint32_t* kmin, uint32_t* kmax, int K) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < K) {
+        kmin[i] = hkey(0x7c00u);   // +Inf: get_min_score starts there (:25)
+        kmax[i] = hkey(0xfc00u);   // -Inf: get_max_score (:12)
+    }
+}
+__global__ void k_minmax(const HitRec* hits, const uint16_t* scores, int64_t n, uint32_t* kmin, uint32_t* kmax) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t m = hits[i].m - 1, k = hkey(scores[i]);
+        if (k < kmin[m]) atomicMin(&kmin[m], k);      // plain pre-check: most records do not move the bound
+        if (k > kmax[m]) atomicMax(&kmax[m], k);
+    }
+}
+__global__ void k_minmax_out(const uint32_t* kmin, const uint32_t* kmax, int K, uint16_t* mn, uint16_t* mx) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < K) {
+        mn[i] = hunkey(kmin[i]);
+        mx[i] = hunkey(kmax[i]);
+    }
+}
+
+// ---- threshold sweep: counts[m][j] += #{records of m with score > thr[m][j]} (get_hits, :3-9) ----
+__global__ void k_thr_hist(const HitRec* hits, const uint16_t* scores, int64_t n, const uint16_t* thr, int T,
+                           unsigned long long* hist) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t m = hits[i].m - 1;
+        const float s = h2f(scores[i]);
+        const uint16_t* t = thr + (size_t)m * T;
+        int lo = 0, hi = T;                       // number of thresholds strictly below the score (thr ascending)
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (h2f(t[mid]) < s) lo = mid + 1; else hi = mid;
+        }
+        if (lo > 0) atomicAdd(&hist[(size_t)m * (T + 1) + lo], 1ull);
+    }
+}
+__global__ void k_thr_suffix(const unsigned long long* hist, int K, int T, int64_t* counts) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= K) return;
+    unsigned long long run = 0;
+    for (int j = T - 1; j >= 0; j--) {            // records whose position is > j pass threshold j
+        run += hist[(size_t)m * (T + 1) + j + 1];
+        counts[(size_t)m * T + j] += (int64_t)run;
+    }
+}
+
+// ---- threshold filter: stable compaction of records with score > thresh[m] (:116-125) ----
+constexpr int FCH = 1024;
+__global__ __launch_bounds__(256) void k_filt_count(const HitRec* hits, const uint16_t* scores, int64_t n, const uint16_t* thresh,
+                                                    uint32_t* chunk_cnt) {
+    __shared__ uint32_t red[4];
+    const int64_t c = blockIdx.x;
+    uint32_t k = 0;
+    for (int j = 0; j < FCH / 256; j++) {
+        const int64_t i = c * FCH + j * 256 + threadIdx.x;
+        if (i < n) k += h2f(scores[i]) > h2f(thresh[hits[i].m - 1]);
+    }
+    for (int d = 32; d >= 1; d >>= 1) k += __shfl_xor(k, d);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = k;
+    __syncthreads();
+    if (threadIdx.x == 0) chunk_cnt[c] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ __launch_bounds__(1024) void k_filt_scan(const uint32_t* chunk_cnt, int64_t nchunks, int64_t* chunk_base, int64_t* total) {
+    __shared__ unsigned long long part[1024];
+    const int tid = threadIdx.x;
+    const int64_t per = (nchunks + 1023) / 1024;
+    int64_t lo = tid * per, hi = lo + per;
+    if (lo > nchunks) lo = nchunks;
+    if (hi > nchunks) hi = nchunks;
+    unsigned long long s = 0;
+    for (int64_t i = lo; i < hi; i++) s += chunk_cnt[i];
+    part[tid] = s;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        unsigned long long v = tid >= d ? part[tid - d] : 0ull;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    unsigned long long run = part[tid] - s;
+    for (int64_t i = lo; i < hi; i++) {
+        chunk_base[i] = (int64_t)run;
+        run += chunk_cnt[i];
+    }
+    if (tid == 1023) *total = (int64_t)part[1023];
+}
+__global__ __launch_bounds__(256) void k_filt_write(const HitRec* hits, const uint16_t* scores, int64_t n, const uint16_t* thresh,
+                                                    const int64_t* chunk_base, HitRec* oh, uint16_t* os) {
+    __shared__ uint32_t wsum[4];
+    const int64_t c = blockIdx.x;
+    int64_t run = chunk_base[c];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int j = 0; j < FCH / 256; j++) {
+        const int64_t i = c * FCH + j * 256 + threadIdx.x;
+        const bool keep = i < n && h2f(scores[i]) > h2f(thresh[hits[i].m - 1]);
+        const uint64_t m = __builtin_amdgcn_ballot_w64(keep);
+        if (lane == 0) wsum[wv] = __builtin_popcountll(m);
+        __syncthreads();
+        uint32_t base = 0, tot = 0;
+        for (int q = 0; q < 4; q++) {
+            if (q < wv) base += wsum[q];
+            tot += wsum[q];
+        }
+        if (keep) {
+            const int64_t at = run + base + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+            oh[at] = hits[i];
+            os[at] = scores[i];
+        }
+        run += tot;
+        __syncthreads();
+    }
+}
+
+// ---- positions -> count matrices (posdicts2countmats, _h6:26-55; reverse strand = submat_comlement, _3:49-52) ----
+// counts[m][ind][a] (the bytes of Julia's (4, maxlen, K) array) += one-hot window of every hit
+__global__ __launch_bounds__(256) void k_count_mats(const HitRec* hits, int64_t n, const uint8_t* codes, int pitch, int64_t n0,
+                                                    const int32_t* lens, int K, int maxlen, int comp, int use_lds,
+                                                    unsigned int* counts) {
+    extern __shared__ unsigned int lh[];
+    const int bins = K * maxlen * 4;
+    if (use_lds) {
+        for (int i = threadIdx.x; i < bins; i += 256) lh[i] = 0;
+        __syncthreads();
+    }
+    unsigned int* dst = use_lds ? lh : counts;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const HitRec h = hits[i];
+        const int m = (int)h.m - 1, len = lens[m];
+        const uint8_t* s = codes + ((int64_t)h.n - 1 - n0) * pitch + (h.l - 1);
+        for (int ind = 0; ind < len; ind++) {
+            const int b = s[ind];
+            if (b > 3) continue;
+            const int a = comp ? 3 - b : b, pos = comp ? len - 1 - ind : ind;
+            atomicAdd(&dst[((size_t)m * maxlen + pos) * 4 + a], 1u);
+        }
+    }
+    if (use_lds) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < bins; i += 256)
+            if (lh[i]) atomicAdd(&counts[i], lh[i]);
+    }
+}
+
+static int need(motifs_ctx* c, const char* fn) {
+    if (!c) {
+        set_error("%s: null context", fn);
+        return MOTIFS_ERR_INVALID;
+    }
+    return MOTIFS_OK;
+}
+
+extern "C" {
+
+int motifs_hits_minmax_dev(motifs_ctx* c, const motifs_hit* hits_dev, const uint16_t* scores_dev, int64_t n, int K,
+                           uint16_t* min_dev, uint16_t* max_dev) {
+    int r = need(c, "motifs_hits_minmax_dev");
+    if (r) return r;
+    if (K < 1 || n < 0 || !min_dev || !max_dev || (n > 0 && (!hits_dev || !scores_dev))) return MOTIFS_ERR_INVALID;
+    MOTIFS_HIP_CHECK(hipSetDevice(c->device));
+    MOTIFS_HIP_CHECK(c->small.reserve((size_t)K * 8 + 64));
+    uint32_t* kmin = (uint32_t*)c->small.p;
+    uint32_t* kmax = kmin + K;
+    hipLaunchKernelGGL(k_minmax_init, dim3((K + 255) / 256), dim3(256), 0, c->stream, kmin, kmax, K);
+    if (n > 0)
+        hipLaunchKernelGGL(k_minmax, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 8192)), dim3(256), 0, c->stream,
+                           (const HitRec*)hits_dev, scores_dev, n, kmin, kmax);
+    hipLaunchKernelGGL(k_minmax_out, dim3((K + 255) / 256), dim3(256), 0, c->stream, kmin, kmax, K, min_dev, max_dev);
+    MOTIFS_HIP_CHECK(hipGetLastError());
+    return MOTIFS_OK;
+}
+
+int motifs_hits_threshold_counts_dev(motifs_ctx* c, const motifs_hit* hits_dev, const uint16_t* scores_dev, int64_t n, int K,
+                                     const uint16_t* thr_dev, int T, int64_t* counts_dev) {
+    int r = need(c, "motifs_hits_threshold_counts_dev");
+    if (r) return r;
+    if (K < 1 || T < 1 || n < 0 || !thr_dev || !counts_dev || (n > 0 && (!hits_dev || !scores_dev))) return MOTIFS_ERR_INVALID;
+    MOTIFS_HIP_CHECK(hipSetDevice(c->device));
+    MOTIFS_HIP_CHECK(c->tilesum.reserve((size_t)K * (T + 1) * 8));
+    unsigned long long* hist = (unsigned long long*)c->tilesum.p;
+    MOTIFS_HIP_CHECK(hipMemsetAsync(hist, 0, (size_t)K * (T + 1) * 8, c->stream));
+    if (n > 0)
+        hipLaunchKernelGGL(k_thr_hist, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 8192)), dim3(256), 0, c->stream,
+                           (const HitRec*)hits_dev, scores_dev, n, thr_dev, T, hist);
+    hipLaunchKernelGGL(k_thr_suffix, dim3((K + 63) / 64), dim3(64), 0, c->stream, hist, K, T, counts_dev);
+    MOTIFS_HIP_CHECK(hipGetLastError());
+    return MOTIFS_OK;
+}
+
+int motifs_hits_filter_dev(motifs_ctx* c, const motifs_hit* hits_dev, const uint16_t* scores_dev, int64_t n, int K,
+                           const uint16_t* thresh_dev, motifs_hit* out_hits_dev, uint16_t* out_scores_dev, int64_t* n_out) {
+    int r = need(c, "motifs_hits_filter_dev");
+    if (r) return r;
+    if (K < 1 || n < 0 || !thresh_dev || !n_out || (n > 0 && (!hits_dev || !scores_dev || !out_hits_dev || !out_scores_dev)))
+        return MOTIFS_ERR_INVALID;
+    *n_out = 0;
+    if (n == 0) return MOTIFS_OK;
+    MOTIFS_HIP_CHECK(hipSetDevice(c->device));
+    const int64_t nch = (n + FCH - 1) / FCH;
+    MOTIFS_HIP_CHECK(c->tilesum.reserve((size_t)nch * 4));
+    MOTIFS_HIP_CHECK(c->off.reserve((size_t)nch * 8 + 64));
+    uint32_t* cc = (uint32_t*)c->tilesum.p;
+    int64_t* cb = (int64_t*)c->off.p;
+    int64_t* total = cb + nch;
+    hipLaunchKernelGGL(k_filt_count, dim3((unsigned)nch), dim3(256), 0, c->stream, (const HitRec*)hits_dev, scores_dev, n, thresh_dev, cc);
+    hipLaunchKernelGGL(k_filt_scan, dim3(1), dim3(1024), 0, c->stream, cc, nch, cb, total);
+    hipLaunchKernelGGL(k_filt_write, dim3((unsigned)nch), dim3(256), 0, c->stream, (const HitRec*)hits_dev, scores_dev, n, thresh_dev, cb,
+                       (HitRec*)out_hits_dev, out_scores_dev);
+    int64_t* h_total = (int64_t*)c->pinned;
+    MOTIFS_HIP_CHECK(hipMemcpyAsync(h_total, total, 8, hipMemcpyDeviceToHost, c->stream));
+    MOTIFS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    *n_out = *h_total;
+    return MOTIFS_OK;
+}
+
+int motifs_hits_count_matrices_dev(motifs_ctx* c, const motifs_hit* hits_dev, int64_t n, const uint8_t* codes_dev, int L, int64_t n0,
+                                   const int64_t* lens, int K, int maxlen, int comp, uint32_t* counts_dev) {
+    int r = need(c, "motifs_hits_count_matrices_dev");
+    if (r) return r;
+    if (K < 1 || maxlen < 1 || n < 0 || !lens || !counts_dev || (n > 0 && (!hits_dev || !codes_dev))) return MOTIFS_ERR_INVALID;
+    if (n == 0) return MOTIFS_OK;
+    MOTIFS_HIP_CHECK(hipSetDevice(c->device));
+    std::vector<int32_t> l32(K);
+    for (int k = 0; k < K; k++) l32[k] = (int32_t)lens[k];
+    MOTIFS_HIP_CHECK(c->lim.reserve((size_t)K * 4));
+    MOTIFS_HIP_CHECK(hipMemcpyAsync(c->lim.p, l32.data(), (size_t)K * 4, hipMemcpyHostToDevice, c->stream));
+    MOTIFS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    const size_t bins = (size_t)K * maxlen * 4;
+    const int use_lds = bins * 4 <= 48 * 1024;
+    hipLaunchKernelGGL(k_count_mats, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 2048)), dim3(256), use_lds ? bins * 4 : 0, c->stream,
+                       (const HitRec*)hits_dev, n, codes_dev, motifs_codes_pitch(L), n0, (const int32_t*)c->lim.p, K, maxlen, comp,
+                       use_lds, counts_dev);
+    MOTIFS_HIP_CHECK(hipGetLastError());
+    return MOTIFS_OK;
+}
+
+// `reading` + `read_fasta` (loadfasta/helpers.jl:83-108): split at '>', drop the header line, join the rest, drop
+// reads containing N/n, keep the first max_entries, then only reads as long as the first; upper-case; A,C,G,T -> 0..3.
+// codes_out: n_reads rows of L bytes.  Query mode: codes_out == NULL returns the sizes.
+int motifs_fasta_read(const char* path, int64_t max_entries, uint8_t* codes_out, int64_t cap_bytes, int64_t* n_reads, int32_t* L) {
+    if (!path || !n_reads || !L || max_entries < 0) {
+        set_error("motifs_fasta_read: bad argument");
+        return MOTIFS_ERR_INVALID;
+    }
+    FILE* f = fopen(path, "rb");
+    if (!f) {
+        set_error("motifs_fasta_read: cannot open %s", path);
+        return MOTIFS_ERR_INVALID;
+    }
+    std::string text;
+    char buf[1 << 16];
+    size_t got;
+    while ((got = fread(buf, 1, sizeof(buf), f)) > 0) text.append(buf, got);
+    fclose(f);
+    std::vector<std::string> reads;
+    size_t pos = 0;
+    while (pos <= text.size()) {                   // records between '>' characters
+        size_t nxt = text.find('>', pos);
+        if (nxt == std::string::npos) nxt = text.size();
+        if (nxt > pos) {                           // !isempty(i)
+            const std::string rec = text.substr(pos, nxt - pos);
+            size_t nl = rec.find('\n');
+            std::string seq;
+            if (nl != std::string::npos)
+                for (size_t i = nl + 1; i < rec.size(); i++)
+                    if (rec[i] != '\n') seq.push_back(rec[i]);           // join(splits[2:end])
+            if (seq.find('N') == std::string::npos && seq.find('n') == std::string::npos) reads.push_back(seq);
+        }
+        pos = nxt + 1;
+    }
+    if ((int64_t)reads.size() > max_entries) reads.resize((size_t)max_entries);
+    if (reads.empty()) {
+        set_error("There aren't DNA strings found in the input");          // helpers.jl:131
+        return MOTIFS_ERR_INVALID;
+    }
+    const size_t len0 = reads[0].size();
+    std::vector<const std::string*> keep;
+    for (const auto& s : reads)
+        if (s.size() == len0) keep.push_back(&s);
+    *n_reads = (int64_t)keep.size();
+    *L = (int32_t)len0;
+    if (!codes_out) return MOTIFS_OK;
+    if ((int64_t)(keep.size() * len0) > cap_bytes) {
+        set_error("motifs_fasta_read: buffer too small (%zu bytes needed)", keep.size() * len0);
+        return MOTIFS_ERR_BUFFER_TOO_SMALL;
+    }
+    for (size_t i = 0; i < keep.size(); i++)
+        for (size_t p = 0; p < len0; p++) {
+            uint8_t code;
+            switch ((*keep[i])[p]) {
+                case 'A': case 'a': code = 0; break;
+                case 'C': case 'c': code = 1; break;
+                case 'G': case 'g': code = 2; break;
+                case 'T': case 't': code = 3; break;
+                default:
+                    set_error("motifs_fasta_read: read %zu has '%c' at %zu (the reference's dna2dummy raises a KeyError)", i + 1,
+                              (*keep[i])[p], p + 1);
+                    return MOTIFS_ERR_INVALID;
+            }
+            codes_out[i * len0 + p] = code;
+        }
+    return MOTIFS_OK;
+}
+
+}  // extern "C"
