@@ -173,3 +173,22 @@ def test_train_ucdl_runs_and_code_retrieval_format(ctx, pkg):
     key = list(zip(rec["seq"].tolist(), rec["fil"].tolist(), rec["position"].tolist()))
     assert key == sorted(key) and len(key) >= 30 * hp.q // 2         # findall order: position fastest, then fil, then seq
     assert (rec["mag"] > 0).all()
+
+
+def test_cfg4_shape_runs(ctx, pkg):
+    """BASELINE configs[3] shape (500 bp, 512 filters of length 20): the oracle needs hours on the CPU here, so
+    check what does not need it: finite losses, gradient of two mini-batches == sum of the two single ones."""
+    md = pkg.model
+    hp = md.Hyperparam(filter_len=20, M=512)
+    L = 500
+    cdl = md.ucdl(hp, L, ctx=ctx, seed=4, arena_bytes=24 << 30)
+    codes = pkg.synth.gen_codes(12, L, 4, n_plant=3, k=20)
+    loss, flat = gpu_loss_grad(pkg, ctx, cdl, codes, 2)
+    assert np.all(np.isfinite(loss)) and np.all(np.isfinite(flat)) and np.abs(flat).max() > 0
+    acc = np.zeros_like(flat, dtype=np.float64)
+    for g in range(2):
+        l1, f1 = gpu_loss_grad(pkg, ctx, cdl, codes[6 * g:6 * g + 6], 1)
+        assert abs(l1[0] - loss[g]) <= 1e-5 * abs(loss[g])
+        acc += f1
+    assert rel_inf(flat, acc) <= 1e-4
+    cdl.model.close()

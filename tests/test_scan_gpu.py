@@ -210,3 +210,18 @@ def test_full_size_properties(torch_cuda, ctx, pkg):
     got = {(int(a), int(b), int(c)): v for (a, b, c), v in zip(h[sel], sf[sel])}
     assert got.keys() == want.keys()
     assert all(got[k_].view(np.uint16) == want[k_].view(np.uint16) for k_ in want)
+
+
+def test_cfg5_shape_small_n(torch_cuda, ctx, pkg):
+    """BASELINE configs[4] shape (1000 bp, 2048 PWMs of length 8..20 -> 16 chunks, LEN=20 template) on a few reads."""
+    sy = pkg.synth
+    N, L, K = 4, 1000, 2048
+    codes = sy.gen_codes(N, L, sy.SEED_BASE + 5, n_plant=3, k=12)
+    pwms, lens = sy.gen_pwm_bank(K, sy.SEED_BASE + 5, len_lo=8, len_hi=20, alpha=0.3)
+    bank = sy.pad_bank(pwms, lens)
+    for rc in (False, True):
+        h, s, counts = dev_scan_hits(torch_cuda, ctx, pkg, bank, lens, codes, rc, pkg._lib.SCAN_BATCH, want_counts=True)
+        oh, os_ = oracle_hits(pkg, bank, lens, codes, rc, pkg._lib.SCAN_BATCH)
+        assert len(oh) > 1000
+        assert np.array_equal(h, oh) and np.array_equal(s, os_)
+        assert np.array_equal(counts, np.bincount(oh[:, 0] - 1, minlength=K))
