@@ -51,6 +51,7 @@ struct motifs_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     bool timing = false;
+    bool scan_valu = false;      // MOTIFS_SCAN_VALU=1: hit records through the all-VALU mask kernel (cross-check path)
     // timing: event pairs are recorded around launches without synchronising and
     // resolved when the totals are read (motifs_ctx_kernel_ms)
     struct TimedSpan {
@@ -62,7 +63,7 @@ struct motifs_ctx {
     double kernel_ms[motifs::KS_COUNT_] = {0};
     int64_t kernel_launches[motifs::KS_COUNT_] = {0};
     // scan workspaces
-    motifs::DevBuf tab, lim, cnt, off, tilesum, small, codes, hits_tmp, scores_tmp, pwmcnt, data_tmp;
+    motifs::DevBuf tab, lim, cnt, off, tilesum, small, codes, hits_tmp, scores_tmp, pwmcnt, data_tmp, afrag, cinit;
     void* pinned = nullptr;  // small pinned host block for totals / flags
 };
 

@@ -10,6 +10,8 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -80,6 +82,68 @@ static int pack_bank(const uint16_t* pwms, const int64_t* lens, int K, int maxle
     return MOTIFS_OK;
 }
 
+static float h2f_host(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, ex = (h >> 10) & 0x1fu, man = h & 0x3ffu;
+    uint32_t bits;
+    if (ex == 0) {
+        float f = std::ldexp((float)man, -24);
+        memcpy(&bits, &f, 4);
+        bits |= sign;
+    } else if (ex == 31) bits = sign | 0x7f800000u | man << 13;
+    else bits = sign | (ex + 112) << 23 | man << 13;
+    float f;
+    memcpy(&f, &bits, 4);
+    return f;
+}
+
+// Operands of the matrix-core candidate kernel (scan_mfma.hip) from the packed bank: PWM fragments in MFMA
+// A-operand order and the per-PWM slack eps_k = 2^-10 * len_k * sum_ind max_a |w| in accumulator order.
+struct MfmaBank {
+    std::vector<uint32_t> afrag;   // [tiles][T][64][4]
+    std::vector<float> cinit;      // [tiles][2][16]
+    int ntiles = 0, T = 0;
+};
+static void pack_mfma(const PackedBank& bank, const int64_t* lens, int K, MfmaBank& out) {
+    const int T = bank.lenp / 4, ntiles = bank.nch * 4;
+    out.T = T;
+    out.ntiles = ntiles;
+    out.afrag.assign((size_t)ntiles * T * 64 * 4, 0u);
+    out.cinit.assign((size_t)ntiles * 32, -1.0f);
+    auto wbits = [&](int k, int a, int ind) -> uint16_t {
+        const uint32_t cell = bank.tab[(size_t)(ind * 4 + a) * bank.KP + (k >> 1)];
+        return (uint16_t)((k & 1) ? cell >> 16 : cell);
+    };
+    for (int tile = 0; tile < ntiles; tile++) {
+        for (int t = 0; t < T; t++)
+            for (int lane = 0; lane < 64; lane++) {
+                const int rho = lane & 31, hh = lane >> 5;
+                const int q = 16 * ((rho >> 2) & 1) + (rho & 3) + 4 * (rho >> 3);   // PWM that accumulator order expects in row rho
+                const int k = tile * 32 + q;
+                uint16_t hv[8];
+                for (int j = 0; j < 8; j++) {
+                    const int kk = 16 * t + 8 * hh + j, ind = kk >> 2, a = kk & 3;
+                    hv[j] = (k < K && ind < (int)lens[k]) ? wbits(k, a, ind) : (uint16_t)0;
+                }
+                uint32_t* dst = &out.afrag[(((size_t)tile * T + t) * 64 + lane) * 4];
+                for (int u = 0; u < 4; u++) dst[u] = (uint32_t)hv[2 * u] | ((uint32_t)hv[2 * u + 1] << 16);
+            }
+        for (int q = 0; q < 32; q++) {
+            const int k = tile * 32 + q;
+            if (k >= K) continue;
+            double A = 0;
+            const int len = (int)lens[k];
+            for (int ind = 0; ind < len; ind++) {
+                double mx = 0;
+                for (int a = 0; a < 4; a++) mx = std::max(mx, (double)std::fabs(h2f_host(wbits(k, a, ind))));
+                A += mx;
+            }
+            float eps = (float)(std::ldexp(A * len, -10) + std::ldexp((double)len, -22));
+            if (A * 1.02 >= 60000.0) eps = INFINITY;          // a partial sum may overflow binary16: keep every window
+            out.cinit[((size_t)tile * 2 + (q >> 4)) * 16 + (q & 15)] = eps;
+        }
+    }
+}
+
 static int pick_cpb(int nch) {
     int cpb = 1;
     while (cpb * 2 <= nch && cpb * 2 <= SCAN_WAVES) cpb *= 2;
@@ -107,6 +171,125 @@ static int upload_bank(motifs_ctx* c, const PackedBank& bank) {
 }  // namespace motifs
 
 using namespace motifs;
+
+// Hit records through the matrix cores: candidates (scan_cand_kernel) -> exact verification + row sums ->
+// scan -> records.  The bank has already been uploaded (tab, lim).
+static int scan_hits_mfma(motifs_ctx* c, const PackedBank& bank, const int64_t* lens, int K, const uint8_t* codes_dev, int64_t N,
+                          int L, int Lout, int64_t n0, int batch, motifs_hit* hits_dev, uint16_t* hit_scores_dev, int64_t cap,
+                          int64_t* n_out, int64_t* per_pwm_counts_dev) {
+    MfmaBank mb;
+    pack_mfma(bank, lens, K, mb);
+    MOTIFS_HIP_CHECK(c->afrag.reserve(mb.afrag.size() * 4));
+    MOTIFS_HIP_CHECK(c->cinit.reserve(mb.cinit.size() * 4));
+    MOTIFS_HIP_CHECK(hipMemcpyAsync(c->afrag.p, mb.afrag.data(), mb.afrag.size() * 4, hipMemcpyHostToDevice, c->stream));
+    MOTIFS_HIP_CHECK(hipMemcpyAsync(c->cinit.p, mb.cinit.data(), mb.cinit.size() * 4, hipMemcpyHostToDevice, c->stream));
+    MOTIFS_HIP_CHECK(hipStreamSynchronize(c->stream));
+
+    const size_t per_batch = (size_t)Lout * batch * bank.nch * 16;
+    int64_t nb_max = (int64_t)((8ull << 30) / per_batch);
+    nb_max = std::max<int64_t>(1, std::min<int64_t>(nb_max, (N + batch - 1) / batch));
+    const int64_t sb = nb_max * batch;
+    const int64_t rows_max = nb_max * Lout;
+    MOTIFS_HIP_CHECK(c->cnt.reserve((size_t)nb_max * per_batch));
+    MOTIFS_HIP_CHECK(c->tilesum.reserve((size_t)rows_max * 4));
+    MOTIFS_HIP_CHECK(c->off.reserve((size_t)rows_max * 8));
+    MOTIFS_HIP_CHECK(c->small.reserve(64));
+    MOTIFS_HIP_CHECK(c->pwmcnt.reserve((size_t)2 * bank.KP * 8));
+    if (per_pwm_counts_dev) MOTIFS_HIP_CHECK(hipMemsetAsync(c->pwmcnt.p, 0, (size_t)2 * bank.KP * 8, c->stream));
+    int64_t* total_dev = (int64_t*)c->small.p;
+    int64_t* h_total = (int64_t*)c->pinned;
+    const int PG = cand_tile_group(bank.lenp);
+    const int ntile_w = (Lout + 31) / 32;
+
+    int64_t emitted = 0;
+    bool too_small = false;
+    for (int64_t s0 = 0; s0 < N; s0 += sb) {
+        const int64_t ns = std::min<int64_t>(sb, N - s0);
+        const int64_t nb = (ns + batch - 1) / batch;
+        CandArgs a{};
+        a.afrag = (const uint4*)c->afrag.p;
+        a.cinit = (const float*)c->cinit.p;
+        a.codes = codes_dev + (size_t)s0 * motifs_codes_pitch(L);
+        a.cells = (uint32_t*)c->cnt.p;
+        a.lenp = bank.lenp;
+        a.ntiles = mb.ntiles;
+        a.d.N = ns;
+        a.d.L = L;
+        a.d.pitch = motifs_codes_pitch(L);
+        a.d.Lout = Lout;
+        a.d.nch = bank.nch;
+        a.d.batch = batch;
+        a.d.ohlen = ntile_w * 32 + bank.lenp;
+        a.d.used_tiles = (K + 31) / 32;
+        {
+            int64_t spw = ns * (mb.ntiles / PG) / 16384;
+            a.d.spw = (int)std::max<int64_t>(1, std::min<int64_t>(spw, 16));
+        }
+        FillArgs f{};
+        f.masks = (const uint4*)c->cnt.p;
+        f.nrows = nb * Lout;
+        f.row_cells = (uint32_t)(batch * bank.nch);
+        f.row_sum = (uint32_t*)c->tilesum.p;
+        f.row_base = (int64_t*)c->off.p;
+        f.total = total_dev;
+        f.tab = (const uint32_t*)c->tab.p;
+        f.codes = a.codes;
+        f.hits = (HitRec*)hits_dev;
+        f.hit_scores = hit_scores_dev;
+        f.pwm_counts = per_pwm_counts_dev ? (int64_t*)c->pwmcnt.p : nullptr;
+        f.base0 = emitted;
+        f.n0 = n0 + s0;
+        f.nch = bank.nch;
+        f.batch = batch;
+        f.Lout = Lout;
+        f.LoutP = Lout;
+        f.lshift = 0;
+        f.lenp = bank.lenp;
+        f.KP = bank.KP;
+        f.pitch = a.d.pitch;
+        f.hist_bins = (per_pwm_counts_dev && 2 * bank.KP <= FILL_HIST_MAX) ? 2 * bank.KP : 0;
+        f.lim = (const int32_t*)c->lim.p;
+        f.N = ns;
+        f.K = K;
+        f.lim_min = L - bank.maxlen_true;
+        {
+            uint32_t d = (uint32_t)bank.nch, sh = 0;
+            while ((1u << sh) < d) sh++;
+            f.div_nch.d = d;
+            f.div_nch.s = sh;
+            f.div_nch.m = d == 1 ? 0u : (uint32_t)((((uint64_t)1 << 32) * (((uint64_t)1 << sh) - d)) / d + 1);
+        }
+        if (ns < nb * batch)   // cells of reads the last batch does not have are never written by the scan
+            MOTIFS_HIP_CHECK(hipMemsetAsync(c->cnt.p, 0, (size_t)f.nrows * f.row_cells * 16, c->stream));
+        {
+            KernelTimer t(c, KS_SCAN_COUNT);
+            MOTIFS_HIP_CHECK(launch_cand(a, c->stream));
+        }
+        {
+            KernelTimer t(c, KS_SCAN_OFFSETS);
+            MOTIFS_HIP_CHECK(launch_verify_row_sums(f, c->stream));
+            MOTIFS_HIP_CHECK(launch_fill_scan(f, c->stream));
+        }
+        MOTIFS_HIP_CHECK(hipMemcpyAsync(h_total, total_dev, 8, hipMemcpyDeviceToHost, c->stream));
+        MOTIFS_HIP_CHECK(hipStreamSynchronize(c->stream));
+        const int64_t sb_total = *h_total;
+        if (emitted + sb_total > cap) too_small = true;
+        if (!too_small && sb_total > 0) {
+            KernelTimer t(c, KS_SCAN_FILL);
+            MOTIFS_HIP_CHECK(launch_fill_records_plain(f, c->stream));
+        }
+        if (f.pwm_counts && (too_small || f.hist_bins == 0)) MOTIFS_HIP_CHECK(launch_cell_histogram(f, c->stream));
+        emitted += sb_total;
+    }
+    *n_out = emitted;
+    if (per_pwm_counts_dev)
+        MOTIFS_HIP_CHECK(hipMemcpyAsync(per_pwm_counts_dev, c->pwmcnt.p, (size_t)K * 8, hipMemcpyDeviceToDevice, c->stream));
+    if (too_small && !(cap == 0 && hits_dev == nullptr)) {
+        set_error("hit buffer too small: need %lld records, cap %lld", (long long)emitted, (long long)cap);
+        return MOTIFS_ERR_BUFFER_TOO_SMALL;
+    }
+    return MOTIFS_OK;
+}
 
 extern "C" {
 
@@ -142,6 +325,8 @@ int motifs_ctx_create(int device, motifs_ctx** out) {
     MOTIFS_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     c->own_stream = true;
     MOTIFS_HIP_CHECK(hipHostMalloc(&c->pinned, 256, hipHostMallocDefault));
+    const char* ev = getenv("MOTIFS_SCAN_VALU");
+    c->scan_valu = ev && ev[0] == '1';
     *out = c;
     return MOTIFS_OK;
 }
@@ -151,7 +336,7 @@ void motifs_ctx_destroy(motifs_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : {&c->tab, &c->lim, &c->cnt, &c->off, &c->tilesum, &c->small, &c->codes, &c->hits_tmp,
-                      &c->scores_tmp, &c->pwmcnt, &c->data_tmp})
+                      &c->scores_tmp, &c->pwmcnt, &c->data_tmp, &c->afrag, &c->cinit})
         b->release();
     if (c->pinned) (void)hipHostFree(c->pinned);
     resolve_timing(c);
@@ -289,6 +474,10 @@ int motifs_pwm_scan_hits_dev(motifs_ctx* c, const uint16_t* pwms_fp16, const int
     if (N == 0 || Lout <= 0) return MOTIFS_OK;
     rcode = upload_bank(c, bank);
     if (rcode) return rcode;
+
+    if (!c->scan_valu)
+        return scan_hits_mfma(c, bank, lens, K, codes_dev, N, L, Lout, n0, batch, hits_dev, hit_scores_dev, cap, n_out,
+                              per_pwm_counts_dev);
 
     const int LoutP = scan_lout_padded(Lout, bank.lenp);
     // super-batch: as many ordering batches as fit an ~8 GiB mask workspace

@@ -60,6 +60,10 @@ struct FillArgs {
     int64_t n0;               // global index offset for records
     int nch, batch, Lout, LoutP, lshift, lenp, KP, pitch;
     int hist_bins;            // 2*KP when the LDS histogram is on, else 0
+    const int32_t* lim;       // matrix-core path: last valid start per PWM
+    int64_t N;                // reads in this super-batch (cells of later reads are empty)
+    int K;
+    int lim_min;              // starts <= lim_min are valid for every PWM
     struct {
         uint32_t d, m, s;
         __device__ uint32_t div(uint32_t n) const {
@@ -69,6 +73,28 @@ struct FillArgs {
         }
     } div_nch;
 };
+
+// ---- matrix-core candidate path (scan_mfma.hip) ----
+struct CandDims {
+    int64_t N;
+    int L, pitch, Lout, nch, batch, spw;
+    int ohlen;                // positions in a read's one-hot LDS image (covers every window tile + the PWM length)
+    int used_tiles;           // tiles that hold at least one PWM: ceil(K / 32)
+};
+struct CandArgs {
+    const uint4* afrag;       // [tiles][T][64] PWM fragments (A operand)
+    const float* cinit;       // [tiles][2][16] eps per PWM in accumulator order
+    const uint8_t* codes;
+    uint32_t* cells;          // [(batch, l, n-in-batch, chunk)] x 4 words, bit i of a cell = PWM 128*chunk + i
+    CandDims d;
+    int lenp, ntiles;         // padded PWM length (multiple of 4); tiles of 32 PWMs (multiple of 4: whole chunks)
+};
+int cand_tile_group(int lenp);
+hipError_t launch_cand(const CandArgs& a, hipStream_t st);
+hipError_t launch_verify_row_sums(const FillArgs& a, hipStream_t st);      // FillArgs: LoutP = Lout, lshift = 0
+hipError_t launch_fill_records_plain(const FillArgs& a, hipStream_t st);
+hipError_t launch_cell_histogram(const FillArgs& a, hipStream_t st);
+hipError_t launch_fill_scan(const FillArgs& a, hipStream_t st);            // exclusive scan of row_sum
 
 int scan_len_padded(int maxlen);
 // positions per mask row for windows 0..Lout-1 of padded length lenp

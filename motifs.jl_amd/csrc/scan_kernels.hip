@@ -515,6 +515,11 @@ hipError_t launch_fill_sums(const FillArgs& a, hipStream_t st) {
     return hipGetLastError();
 }
 
+hipError_t launch_fill_scan(const FillArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(fill_row_scan, dim3(1), dim3(1024), 0, st, a);
+    return hipGetLastError();
+}
+
 template <int LEN>
 static hipError_t launch_fill_len(const FillArgs& a, hipStream_t st) {
     const size_t tab_bytes = (size_t)LEN * 4 * a.KP * 4;
