@@ -16,6 +16,9 @@ EXTRA = {
     # LLVM structurizes even uniform control flow by default, which turns the
     # rotating accumulators into a v_mov per add (2x the VALU work).
     "scan_kernels.hip": ["-mllvm", "-structurizecfg-skip-uniform-regions"],
+    # keep MFMA accumulators in VGPRs: the candidate kernel reads every accumulator with VALU right after the
+    # chain, and the AGPR form costs one v_accvgpr_read per register (16 extra VALU per 32x32 tile)
+    "scan_mfma.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
 }
 
 

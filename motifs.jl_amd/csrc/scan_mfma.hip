@@ -40,14 +40,19 @@ static __device__ __forceinline__ unsigned xcd_swz(unsigned b, unsigned nb) {
 //                     read as two 8-byte LDS words from the read's one-hot image;
 //   C = eps_k per PWM row, so that the sign bit of the result is "not a candidate".
 template <int T, int PG>
-__global__ __launch_bounds__(256) void scan_cand_kernel(const uint4* __restrict__ afrag, const float* __restrict__ cinit,
+__global__ __launch_bounds__(512) void scan_cand_kernel(const uint4* __restrict__ afrag, const float* __restrict__ cinit,
                                                         const uint8_t* __restrict__ codes, uint32_t* __restrict__ cells,
                                                         const CandDims d) {
     extern __shared__ uint2 oh_all[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int w = lane & 31, h = lane >> 5;
-    uint2* oh = oh_all + (size_t)wave * d.ohlen;
-    const int tg = blockIdx.y;                       // tile group: PWM tiles [tg*PG, tg*PG + PG)
+    const int swap_addr = (lane ^ 32) << 2;          // ds_bpermute byte address of the partner lane (other half)
+    uint2* oh = oh_all + (size_t)wave * ((d.ohlen + 3) & ~3);
+    // 8 waves = 4 reads x 2 tile groups: the two halves of a 128-byte line of cells (4 reads x 2 chunks) are
+    // written by the same block at about the same time
+    const int slot = wave & 3;
+    const int tg = blockIdx.y * 2 + (wave >> 2);     // tile group: PWM tiles [tg*PG, tg*PG + PG)
+    if (tg * PG >= d.used_tiles) return;
     const int tile0 = tg * PG;
     const int chunk = tile0 >> 2, word0 = tile0 & 3;
 
@@ -67,16 +72,22 @@ __global__ __launch_bounds__(256) void scan_cand_kernel(const uint4* __restrict_
     const unsigned lb = xcd_swz(blockIdx.x, gridDim.x);
     const int ntile = (d.Lout + 31) / 32;
     for (int s = 0; s < d.spw; s++) {
-        const int64_t n = ((int64_t)lb * d.spw + s) * 4 + wave;        // wave-uniform
+        const int64_t n = ((int64_t)lb * d.spw + s) * 4 + slot;        // wave-uniform
         if (n >= d.N) break;
-        // stage the read's one-hot image: 4 halves per position (1.0 at the base, all zero for code 4 / padding)
-        const uint8_t* srow = codes + n * d.pitch;
-        for (int p = lane; p < d.ohlen; p += 64) {
-            const uint32_t c = p < d.L ? srow[p] : 4u;
-            uint2 v = make_uint2(0u, 0u);
-            if (c < 2) v.x = 0x3c00u << (16 * c);
-            else if (c < 4) v.y = 0x3c00u << (16 * (c - 2));
-            oh[p] = v;
+        // stage the read's one-hot image: 4 halves per position (1.0 at the base, all zero for code 4 / padding);
+        // one dword (4 bases) per lane and round
+        const uint32_t* srow = (const uint32_t*)(codes + n * d.pitch);
+        for (int p4 = lane; p4 * 4 < d.ohlen; p4 += 64) {
+            const uint32_t wv = p4 * 4 < d.L ? srow[p4] : 0x04040404u;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int p = p4 * 4 + u;
+                const uint32_t c = p < d.L ? (wv >> (8 * u)) & 0xffu : 4u;
+                uint2 v = make_uint2(0u, 0u);
+                if (c < 2) v.x = 0x3c00u << (16 * c);
+                else if (c < 4) v.y = 0x3c00u << (16 * (c - 2));
+                if (p < d.ohlen) oh[p] = v;
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -104,7 +115,7 @@ __global__ __launch_bounds__(256) void scan_cand_kernel(const uint4* __restrict_
 #pragma unroll
                     for (int r = 15; r >= 0; r--) m = __builtin_amdgcn_alignbit(m, __float_as_uint(acc[r]), 31);
                     m = ~m & 0xffffu;
-                    const uint32_t other = __shfl_xor(m, 32);
+                    const uint32_t other = (uint32_t)__builtin_amdgcn_ds_bpermute(swap_addr, (int)m);   // the other 16 PWMs
                     word[g] = h ? (other | (m << 16)) : (m | (other << 16));
                 }
             }
@@ -124,17 +135,24 @@ __global__ __launch_bounds__(256) void scan_cand_kernel(const uint4* __restrict_
 template <int LEN>
 struct WindowBases {
     uint32_t rowofs[LEN];     // (ind*4 + b) * KP, or ~0 for an all-zero column
-    __device__ __forceinline__ void load(const uint8_t* codes, int64_t n, int pitch, int l, int KP) {
+    // raw words: issued for every cell BEFORE its mask is known, so the two loads overlap
+    static __device__ __forceinline__ void fetch(const uint8_t* codes, int64_t n, int pitch, int l, uint32_t (&W)[LEN / 4 + 1]) {
         const uint32_t* sw = (const uint32_t*)(codes + n * pitch + (l & ~3));
-        uint32_t W[LEN / 4 + 1];
 #pragma unroll
         for (int q = 0; q <= LEN / 4; q++) W[q] = sw[q];
+    }
+    __device__ __forceinline__ void decode(const uint32_t (&W)[LEN / 4 + 1], int l, int KP) {
 #pragma unroll
         for (int ind = 0; ind < LEN; ind++) {
             const uint32_t al = __builtin_amdgcn_alignbyte(W[ind / 4 + 1], W[ind / 4], (uint32_t)(l & 3));
             const uint32_t b = (al >> (8 * (ind % 4))) & 0xffu;
             rowofs[ind] = b < 4 ? (uint32_t)(ind * 4 + b) * KP : 0xffffffffu;
         }
+    }
+    __device__ __forceinline__ void load(const uint8_t* codes, int64_t n, int pitch, int l, int KP) {
+        uint32_t W[LEN / 4 + 1];
+        fetch(codes, n, pitch, l, W);
+        decode(W, l, KP);
     }
     // sequential binary16 sum of PWM k over the window (zero-padded table: entries beyond lens[k] add +0)
     __device__ __forceinline__ uint16_t score(const uint32_t* tab, uint32_t k) const {
@@ -169,17 +187,19 @@ __global__ __launch_bounds__(FILL_THREADS) void fill_verify_row_sums(FillArgs a)
         const bool all_valid = l <= a.lim_min;   // every PWM fits at this start
         uint32_t s = 0;
         for (uint32_t idx = tid; idx < a.row_cells; idx += FILL_THREADS) {
-            uint4 m = row[idx];
-            if ((m.x | m.y | m.z | m.w) == 0u) continue;
             const uint32_t nin = a.div_nch.div(idx);
             const int ch = (int)(idx - nin * a.nch);
             const int64_t n = bq * a.batch + nin;
+            uint32_t W[LEN / 4 + 1];
+            WindowBases<LEN>::fetch(a.codes, n < a.N ? n : 0, a.pitch, l, W);
+            uint4 m = row[idx];
+            if ((m.x | m.y | m.z | m.w) == 0u) continue;
             if (n >= a.N) {                      // the tail of the last batch was never scanned
                 row[idx] = make_uint4(0u, 0u, 0u, 0u);
                 continue;
             }
             WindowBases<LEN> wb;
-            wb.load(a.codes, n, a.pitch, l, a.KP);
+            wb.decode(W, l, a.KP);
             uint32_t wd[4] = {m.x, m.y, m.z, m.w};
             bool changed = false;
 #pragma unroll
@@ -253,19 +273,22 @@ __global__ __launch_bounds__(FILL_THREADS) void fill_records_plain(FillArgs a) {
         int64_t run = a.base0 + a.row_base[r];
         for (uint32_t i0 = 0; i0 < a.row_cells; i0 += FILL_THREADS) {
             const uint32_t idx = i0 + tid;
-            uint4 m = make_uint4(0u, 0u, 0u, 0u);
-            if (idx < a.row_cells) m = row[idx];
+            const uint32_t idc = idx < a.row_cells ? idx : a.row_cells - 1;
+            const uint32_t nin = a.div_nch.div(idc);
+            const int ch = (int)(idc - nin * a.nch);
+            const int64_t n = bq * a.batch + nin;
+            uint32_t W[LEN / 4 + 1];
+            WindowBases<LEN>::fetch(a.codes, n < a.N ? n : 0, a.pitch, l, W);
+            uint4 m = row[idc];
+            if (idx >= a.row_cells) m = make_uint4(0u, 0u, 0u, 0u);
             const uint32_t pc = __builtin_popcount(m.x) + __builtin_popcount(m.y) + __builtin_popcount(m.z) + __builtin_popcount(m.w);
             uint32_t tot;
             const uint32_t ex = excl_scan_256(pc, wsum, tot);
             int64_t at = run + ex;
             run += tot;
             if (pc) {
-                const uint32_t nin = a.div_nch.div(idx);
-                const int ch = (int)(idx - nin * a.nch);
-                const int64_t n = bq * a.batch + nin;
                 WindowBases<LEN> wb;
-                wb.load(a.codes, n, a.pitch, l, a.KP);
+                wb.decode(W, l, a.KP);
                 const uint32_t nn = (uint32_t)(n + a.n0 + 1), ll = (uint32_t)(l + 1);
                 const uint32_t wd[4] = {m.x, m.y, m.z, m.w};
 #pragma unroll
@@ -313,8 +336,9 @@ __global__ __launch_bounds__(FILL_THREADS) void cell_histogram(FillArgs a) {
 template <int T, int PG>
 static hipError_t launch_cand_tp(const CandArgs& a, hipStream_t st) {
     const int64_t per_block = (int64_t)4 * a.d.spw;
-    dim3 grid((unsigned)((a.d.N + per_block - 1) / per_block), (unsigned)(a.ntiles / PG), 1);
-    hipLaunchKernelGGL((scan_cand_kernel<T, PG>), grid, dim3(256), (size_t)4 * a.d.ohlen * 8, st, a.afrag, a.cinit, a.codes, a.cells,
+    const int ntg = a.ntiles / PG;
+    dim3 grid((unsigned)((a.d.N + per_block - 1) / per_block), (unsigned)((ntg + 1) / 2), 1);
+    hipLaunchKernelGGL((scan_cand_kernel<T, PG>), grid, dim3(512), (size_t)8 * ((a.d.ohlen + 3) & ~3) * 8, st, a.afrag, a.cinit, a.codes, a.cells,
                        a.d);
     return hipGetLastError();
 }
