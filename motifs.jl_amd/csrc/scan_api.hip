@@ -189,7 +189,9 @@ static int scan_hits_mfma(motifs_ctx* c, const PackedBank& bank, const int64_t* 
     int64_t nb_max = (int64_t)((8ull << 30) / per_batch);
     nb_max = std::max<int64_t>(1, std::min<int64_t>(nb_max, (N + batch - 1) / batch));
     const int64_t sb = nb_max * batch;
-    const int64_t rows_max = nb_max * Lout;
+    int parts = 1;                 // rows of ~1000-2500 cells balance the blocks better than whole (batch, l) lines
+    while (parts < 8 && batch % (parts * 2) == 0 && (int64_t)batch / (parts * 2) * bank.nch >= 1024) parts *= 2;
+    const int64_t rows_max = nb_max * Lout * parts;
     MOTIFS_HIP_CHECK(c->cnt.reserve((size_t)nb_max * per_batch));
     MOTIFS_HIP_CHECK(c->tilesum.reserve((size_t)rows_max * 4));
     MOTIFS_HIP_CHECK(c->off.reserve((size_t)rows_max * 8));
@@ -227,8 +229,9 @@ static int scan_hits_mfma(motifs_ctx* c, const PackedBank& bank, const int64_t* 
         }
         FillArgs f{};
         f.masks = (const uint4*)c->cnt.p;
-        f.nrows = nb * Lout;
-        f.row_cells = (uint32_t)(batch * bank.nch);
+        f.parts = parts;
+        f.nrows = nb * Lout * parts;
+        f.row_cells = (uint32_t)(batch / parts * bank.nch);
         f.row_sum = (uint32_t*)c->tilesum.p;
         f.row_base = (int64_t*)c->off.p;
         f.total = total_dev;

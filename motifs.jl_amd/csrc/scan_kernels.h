@@ -64,6 +64,7 @@ struct FillArgs {
     int64_t N;                // reads in this super-batch (cells of later reads are empty)
     int K;
     int lim_min;              // starts <= lim_min are valid for every PWM
+    int parts;                // matrix-core path: a (batch, l) line of cells is split into this many rows
     struct {
         uint32_t d, m, s;
         __device__ uint32_t div(uint32_t n) const {

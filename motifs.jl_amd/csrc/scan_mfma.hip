@@ -131,185 +131,236 @@ __global__ __launch_bounds__(512) void scan_cand_kernel(const uint4* __restrict_
     }
 }
 
-// ---- exact re-scoring of one (PWM, window) in the reference's arithmetic --------------------------------
+// ---- exact re-scoring in the reference's arithmetic, load-balanced over a wave ---------------------------
+// Each lane owns one cell (its mask words and the table row offsets of its window's bases); the set bits of
+// the 64 cells are queued in LDS and then taken round-robin by all 64 lanes, so a cell with five candidates
+// does not hold up 63 lanes with none.
+constexpr uint32_t NOROW = 0xffffffffu;
+
+// table row offsets of the LEN bases of a window from its raw code words (all-zero column: column 4 of the
+// 5-column LDS table, or NOROW for the 4-column global table)
+template <int LEN, bool LDS_TAB>
+static __device__ __forceinline__ void window_offsets(const uint32_t (&W)[LEN / 4 + 1], int l, int KP, uint32_t* dst) {
+#pragma unroll
+    for (int ind = 0; ind < LEN; ind++) {
+        const uint32_t al = __builtin_amdgcn_alignbyte(W[ind / 4 + 1], W[ind / 4], (uint32_t)(l & 3));
+        const uint32_t bb = (al >> (8 * (ind % 4))) & 0xffu;
+        if (LDS_TAB) dst[ind] = (uint32_t)(ind * 5 + (bb < 4 ? bb : 4)) * KP;
+        else dst[ind] = bb < 4 ? (uint32_t)(ind * 4 + bb) * KP : NOROW;
+    }
+}
 template <int LEN>
-struct WindowBases {
-    uint32_t rowofs[LEN];     // (ind*4 + b) * KP, or ~0 for an all-zero column
-    // raw words: issued for every cell BEFORE its mask is known, so the two loads overlap
-    static __device__ __forceinline__ void fetch(const uint8_t* codes, int64_t n, int pitch, int l, uint32_t (&W)[LEN / 4 + 1]) {
-        const uint32_t* sw = (const uint32_t*)(codes + n * pitch + (l & ~3));
+static __device__ __forceinline__ void fetch_codes(const uint8_t* codes, int64_t n, int pitch, int l, uint32_t (&W)[LEN / 4 + 1]) {
+    const uint32_t* sw = (const uint32_t*)(codes + n * pitch + (l & ~3));
 #pragma unroll
-        for (int q = 0; q <= LEN / 4; q++) W[q] = sw[q];
-    }
-    __device__ __forceinline__ void decode(const uint32_t (&W)[LEN / 4 + 1], int l, int KP) {
+    for (int q = 0; q <= LEN / 4; q++) W[q] = sw[q];
+}
+// sequential binary16 sum of PWM k over the owner's window (table entries beyond lens[k] are +0)
+template <int LEN, bool LDS_TAB>
+static __device__ __forceinline__ uint16_t exact_score(const uint32_t* tb, const uint32_t* rofs, uint32_t k) {
+    const uint32_t kp = k >> 1, sh = (k & 1u) * 16;
+    uint32_t t[LEN];
 #pragma unroll
-        for (int ind = 0; ind < LEN; ind++) {
-            const uint32_t al = __builtin_amdgcn_alignbyte(W[ind / 4 + 1], W[ind / 4], (uint32_t)(l & 3));
-            const uint32_t b = (al >> (8 * (ind % 4))) & 0xffu;
-            rowofs[ind] = b < 4 ? (uint32_t)(ind * 4 + b) * KP : 0xffffffffu;
-        }
+    for (int ind = 0; ind < LEN; ind++) {
+        const uint32_t o = rofs[ind];
+        t[ind] = (!LDS_TAB && o == NOROW) ? 0u : tb[o + kp];
     }
-    __device__ __forceinline__ void load(const uint8_t* codes, int64_t n, int pitch, int l, int KP) {
-        uint32_t W[LEN / 4 + 1];
-        fetch(codes, n, pitch, l, W);
-        decode(W, l, KP);
-    }
-    // sequential binary16 sum of PWM k over the window (zero-padded table: entries beyond lens[k] add +0)
-    __device__ __forceinline__ uint16_t score(const uint32_t* tab, uint32_t k) const {
-        const uint32_t kp = k >> 1, sh = (k & 1u) * 16;
-        uint32_t t[LEN];
+    _Float16 acc = __builtin_bit_cast(_Float16, (uint16_t)(t[0] >> sh));
 #pragma unroll
-        for (int ind = 0; ind < LEN; ind++) t[ind] = rowofs[ind] == 0xffffffffu ? 0u : tab[rowofs[ind] + kp];
-        _Float16 acc = __builtin_bit_cast(_Float16, (uint16_t)(t[0] >> sh));
-#pragma unroll
-        for (int ind = 1; ind < LEN; ind++) acc = acc + __builtin_bit_cast(_Float16, (uint16_t)(t[ind] >> sh));
-        return __builtin_bit_cast(uint16_t, acc);
-    }
-};
+    for (int ind = 1; ind < LEN; ind++) acc = acc + __builtin_bit_cast(_Float16, (uint16_t)(t[ind] >> sh));
+    return __builtin_bit_cast(uint16_t, acc);
+}
 static __device__ __forceinline__ bool half_pos(uint16_t h) { return (int16_t)h > 0; }   // > 0 (finite inputs: no NaN)
 
-// V1: candidates -> hits, in place, plus hits per cell row (one row = all (n, chunk) cells of one (batch, l)).
-template <int LEN, bool LDS_TAB>
-__global__ __launch_bounds__(FILL_THREADS) void fill_verify_row_sums(FillArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    uint32_t* red = smem;                        // [FILL_THREADS/64]
-    uint32_t* ltab = smem + 16;
-    const int tid = threadIdx.x;
-    if (LDS_TAB)
-        for (int i = tid; i < LEN * 4 * a.KP; i += FILL_THREADS) ltab[i] = a.tab[i];
+// the packed bank into LDS; with room, as 5 columns per position (column 4 = zeros for all-zero data columns)
+template <int LEN, bool LDS_TAB, int THREADS>
+static __device__ __forceinline__ const uint32_t* stage_table(const uint32_t* tab, int KP, uint32_t* ltab) {
+    if (!LDS_TAB) return tab;
+    for (int i = threadIdx.x; i < LEN * 5 * KP; i += THREADS) {
+        const int kp = i % KP, cb = i / KP, b = cb % 5, ind = cb / 5;
+        ltab[i] = b < 4 ? tab[(size_t)(ind * 4 + b) * KP + kp] : 0u;
+    }
     __syncthreads();
-    const uint32_t* tb = LDS_TAB ? ltab : a.tab;
-    uint4* cells = const_cast<uint4*>(a.masks);
-    for (int64_t r = blockIdx.x; r < a.nrows; r += gridDim.x) {
-        const int l = (int)(r % a.LoutP);
-        const int64_t bq = r / a.LoutP;
-        uint4* row = cells + r * a.row_cells;
-        const bool all_valid = l <= a.lim_min;   // every PWM fits at this start
-        uint32_t s = 0;
-        for (uint32_t idx = tid; idx < a.row_cells; idx += FILL_THREADS) {
-            const uint32_t nin = a.div_nch.div(idx);
-            const int ch = (int)(idx - nin * a.nch);
-            const int64_t n = bq * a.batch + nin;
-            uint32_t W[LEN / 4 + 1];
-            WindowBases<LEN>::fetch(a.codes, n < a.N ? n : 0, a.pitch, l, W);
-            uint4 m = row[idx];
-            if ((m.x | m.y | m.z | m.w) == 0u) continue;
-            if (n >= a.N) {                      // the tail of the last batch was never scanned
-                row[idx] = make_uint4(0u, 0u, 0u, 0u);
-                continue;
-            }
-            WindowBases<LEN> wb;
-            wb.decode(W, l, a.KP);
-            uint32_t wd[4] = {m.x, m.y, m.z, m.w};
-            bool changed = false;
+    return ltab;
+}
+
+static __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                uint32_t bits = wd[q];
-                while (bits) {
-                    const int i = __builtin_ctz(bits);
-                    bits &= bits - 1;
-                    const uint32_t k = (uint32_t)(ch * 4 + q) * 32 + i;
-                    const bool hit = (int)k < a.K && (all_valid || l <= a.lim[k]) && half_pos(wb.score(tb, k));
-                    if (!hit) {
-                        wd[q] &= ~(1u << i);
-                        changed = true;
-                    }
-                }
-                s += __builtin_popcount(wd[q]);
+    for (int dd = 1; dd < 64; dd <<= 1) {
+        const uint32_t t = __shfl_up(v, dd);
+        if (lane >= dd) v += t;
+    }
+    return v;
+}
+// LDS traffic between lanes of one wave: program order is execution order, the fence stops the compiler
+static __device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Both kernels below give every WAVE its own rows of cells and its own LDS queue: a wave walks a row 64 cells
+// at a time, pushes every set bit into the queue, and scores the queue 64 candidates at a time with all lanes
+// busy (a cell with five candidates does not stall the 63 lanes beside it; cells without candidates cost a
+// load and a popcount).  No block barriers after the table is staged, so the waves of a CU hide each other's
+// load latency.
+constexpr int VF_THREADS = 512;
+constexpr int VF_WAVES = VF_THREADS / 64;
+constexpr int QN = 256;           // ring slots per wave (power of two); fewer than 64 stay behind after a push round
+
+// the candidates of one 64-cell slab into the wave's FIFO ring, draining full batches of 64 through
+// fn(candidate word, ordinal of the candidate in the row).  head = candidates of this row drained so far.
+// candidate word = cell index in the row << 7 | word << 5 | bit
+template <typename F>
+static __device__ __forceinline__ void push_and_drain(uint32_t* queue, uint32_t& head, uint32_t& qlen, const uint32_t (&wd)[4],
+                                                      uint32_t idx, uint32_t ex, uint32_t tot, F&& fn) {
+    const int lane = threadIdx.x & 63;
+    uint32_t done = 0;
+    while (true) {                                                    // wave-uniform
+        const uint32_t room = QN - qlen;
+        const uint32_t take = tot - done < room ? tot - done : room;
+        uint32_t g = ex;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            uint32_t bits = wd[q];
+            while (bits) {
+                const int i = __builtin_ctz(bits);
+                bits &= bits - 1;
+                if (g >= done && g < done + take)
+                    queue[(head + qlen + g - done) & (QN - 1)] = (idx << 7) | ((uint32_t)q << 5) | (uint32_t)i;
+                g++;
             }
-            if (changed) row[idx] = make_uint4(wd[0], wd[1], wd[2], wd[3]);
         }
-        for (int dd = 32; dd >= 1; dd >>= 1) s += __shfl_xor(s, dd);
-        if ((tid & 63) == 0) red[tid >> 6] = s;
-        __syncthreads();
-        if (tid == 0) {
-            uint32_t t = 0;
-            for (int i = 0; i < FILL_THREADS / 64; i++) t += red[i];
-            a.row_sum[r] = t;
+        qlen += take;
+        done += take;
+        wave_lds_sync();
+        while (qlen >= 64) {
+            fn(queue[(head + lane) & (QN - 1)], head + lane);
+            head += 64;
+            qlen -= 64;
         }
-        __syncthreads();
+        wave_lds_sync();
+        if (done >= tot) break;
     }
 }
 
-static __device__ __forceinline__ uint32_t excl_scan_256(uint32_t v, uint32_t* wsum, uint32_t& total) {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    uint32_t inc = v;
-#pragma unroll
-    for (int dd = 1; dd < 64; dd <<= 1) {
-        const uint32_t t = __shfl_up(inc, dd);
-        if (lane >= dd) inc += t;
+// V1: candidates -> hits, in place, plus hits per cell row (one row = the (n, chunk) cells of one (batch, l, part)).
+template <int LEN, bool LDS_TAB>
+__global__ __launch_bounds__(VF_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void fill_verify_row_sums(FillArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    uint32_t* queue = smem + wv * QN;                                 // [VF_WAVES][QN]
+    uint32_t* ltab = smem + VF_WAVES * QN;
+    const uint32_t* tb = stage_table<LEN, LDS_TAB, VF_THREADS>(a.tab, a.KP, ltab);
+    uint32_t* cells = (uint32_t*)const_cast<uint4*>(a.masks);
+    const uint32_t part_reads = (uint32_t)(a.batch / a.parts);
+    const int64_t nwaves = (int64_t)gridDim.x * VF_WAVES;
+    for (int64_t r = (int64_t)wv * gridDim.x + blockIdx.x; r < a.nrows; r += nwaves) {
+        const int part = (int)(r % a.parts);
+        const int64_t rl = r / a.parts;
+        const int l = (int)(rl % a.LoutP);
+        const int64_t bq = rl / a.LoutP;
+        uint32_t* row = cells + (size_t)r * a.row_cells * 4;
+        const bool all_valid = l <= a.lim_min;                        // every PWM fits at this start
+        const int64_t nrow0 = bq * a.batch + (int64_t)part * part_reads;
+        uint32_t qlen = 0, head = 0, nhit = 0;                        // wave-uniform
+        auto score = [&](const uint32_t cw) {                         // one candidate per lane
+            const uint32_t idx = cw >> 7, q = (cw >> 5) & 3u, i = cw & 31u;
+            const uint32_t nin = a.div_nch.div(idx);
+            const uint32_t ch = idx - nin * a.nch;
+            const int64_t n = nrow0 + nin;
+            const uint32_t k = (ch * 4 + q) * 32 + i;
+            bool hit = false;
+            if (n < a.N && (int)k < a.K && (all_valid || l <= a.lim[k])) {
+                uint32_t W[LEN / 4 + 1], rofs[LEN];
+                fetch_codes<LEN>(a.codes, n, a.pitch, l, W);
+                window_offsets<LEN, LDS_TAB>(W, l, a.KP, rofs);
+                hit = half_pos(exact_score<LEN, LDS_TAB>(tb, rofs, k));
+            }
+            if (!hit) atomicAnd(&row[idx * 4 + q], ~(1u << i));
+            return hit;
+        };
+        auto score_count = [&](const uint32_t cw, uint32_t) { nhit += (uint32_t)__builtin_popcountll(__ballot(score(cw))); };
+        uint4 m_next = make_uint4(0u, 0u, 0u, 0u);
+        if ((uint32_t)lane < a.row_cells) m_next = ((const uint4*)row)[lane];
+        for (uint32_t i0 = 0; i0 < a.row_cells; i0 += 64) {           // wave-uniform trip count
+            const uint32_t idx = i0 + lane;
+            const uint4 m = m_next;
+            m_next = make_uint4(0u, 0u, 0u, 0u);
+            if (idx + 64 < a.row_cells) m_next = ((const uint4*)row)[idx + 64];
+            const uint32_t wd[4] = {m.x, m.y, m.z, m.w};
+            const uint32_t pc = __builtin_popcount(m.x) + __builtin_popcount(m.y) + __builtin_popcount(m.z) + __builtin_popcount(m.w);
+            const uint32_t inc = wave_incl_scan(pc, lane);
+            const uint32_t tot = __shfl(inc, 63);
+            if (tot) push_and_drain(queue, head, qlen, wd, idx, inc - pc, tot, score_count);
+        }
+        {                                                             // the remainder (< 64)
+            bool hit = false;
+            if ((uint32_t)lane < qlen) hit = score(queue[(head + lane) & (QN - 1)]);
+            nhit += (uint32_t)__builtin_popcountll(__ballot(hit));
+        }
+        wave_lds_sync();
+        if (lane == 0) a.row_sum[r] = nhit;
     }
-    if (lane == 63) wsum[wv] = inc;
-    __syncthreads();
-    uint32_t wbase = 0, tot = 0;
-#pragma unroll
-    for (int q = 0; q < FILL_THREADS / 64; q++) {
-        if (q < wv) wbase += wsum[q];
-        tot += wsum[q];
-    }
-    __syncthreads();
-    total = tot;
-    return wbase + inc - v;
 }
 
 // V2: every (verified) bit becomes a record: (m, n, l) 1-based + the fp16 score, reference order.
 template <int LEN, bool LDS_TAB>
-__global__ __launch_bounds__(FILL_THREADS) void fill_records_plain(FillArgs a) {
+__global__ __launch_bounds__(VF_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void fill_records_plain(FillArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    uint32_t* wsum = smem;                       // [FILL_THREADS/64]
-    uint32_t* hist = smem + 16;                  // [hist_bins]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    uint32_t* queue = smem + wv * QN;                                 // [VF_WAVES][QN]
+    uint32_t* hist = smem + VF_WAVES * QN;                            // [hist_bins]
     uint32_t* ltab = hist + a.hist_bins;
-    const int tid = threadIdx.x;
-    for (int i = tid; i < a.hist_bins; i += FILL_THREADS) hist[i] = 0;
-    if (LDS_TAB)
-        for (int i = tid; i < LEN * 4 * a.KP; i += FILL_THREADS) ltab[i] = a.tab[i];
+    for (int i = tid; i < a.hist_bins; i += VF_THREADS) hist[i] = 0;
+    const uint32_t* tb = stage_table<LEN, LDS_TAB, VF_THREADS>(a.tab, a.KP, ltab);
     __syncthreads();
-    const uint32_t* tb = LDS_TAB ? ltab : a.tab;
-    for (int64_t r = blockIdx.x; r < a.nrows; r += gridDim.x) {
-        if (a.row_sum[r] == 0) continue;         // block-uniform
-        const int l = (int)(r % a.LoutP);
-        const int64_t bq = r / a.LoutP;
-        const uint4* row = a.masks + r * a.row_cells;
-        int64_t run = a.base0 + a.row_base[r];
-        for (uint32_t i0 = 0; i0 < a.row_cells; i0 += FILL_THREADS) {
-            const uint32_t idx = i0 + tid;
-            const uint32_t idc = idx < a.row_cells ? idx : a.row_cells - 1;
-            const uint32_t nin = a.div_nch.div(idc);
-            const int ch = (int)(idc - nin * a.nch);
-            const int64_t n = bq * a.batch + nin;
-            uint32_t W[LEN / 4 + 1];
-            WindowBases<LEN>::fetch(a.codes, n < a.N ? n : 0, a.pitch, l, W);
-            uint4 m = row[idc];
-            if (idx >= a.row_cells) m = make_uint4(0u, 0u, 0u, 0u);
+    const uint32_t* cells = (const uint32_t*)a.masks;
+    const uint32_t part_reads = (uint32_t)(a.batch / a.parts);
+    const int64_t nwaves = (int64_t)gridDim.x * VF_WAVES;
+    for (int64_t r = (int64_t)wv * gridDim.x + blockIdx.x; r < a.nrows; r += nwaves) {
+        if (a.row_sum[r] == 0) continue;                              // wave-uniform
+        const int part = (int)(r % a.parts);
+        const int64_t rl = r / a.parts;
+        const int l = (int)(rl % a.LoutP);
+        const int64_t bq = rl / a.LoutP;
+        const uint4* row = (const uint4*)(cells + (size_t)r * a.row_cells * 4);
+        const int64_t row_at = a.base0 + a.row_base[r];
+        const int64_t nrow0 = bq * a.batch + (int64_t)part * part_reads;
+        uint32_t qlen = 0, head = 0;                                  // wave-uniform
+        auto emit = [&](const uint32_t cw, const uint32_t ord) {      // ord-th bit of the row = ord-th record
+            const uint32_t idx = cw >> 7, q = (cw >> 5) & 3u, i = cw & 31u;
+            const uint32_t nin = a.div_nch.div(idx);
+            const uint32_t ch = idx - nin * a.nch;
+            const int64_t n = nrow0 + nin;
+            const uint32_t k = (ch * 4 + q) * 32 + i;
+            uint32_t W[LEN / 4 + 1], rofs[LEN];
+            fetch_codes<LEN>(a.codes, n, a.pitch, l, W);
+            window_offsets<LEN, LDS_TAB>(W, l, a.KP, rofs);
+            const int64_t at = row_at + ord;
+            a.hits[at] = HitRec{k + 1, (uint32_t)(n + a.n0 + 1), (uint32_t)(l + 1)};
+            a.hit_scores[at] = exact_score<LEN, LDS_TAB>(tb, rofs, k);
+            if (a.hist_bins) atomicAdd(&hist[k], 1u);
+        };
+        uint4 m_next = make_uint4(0u, 0u, 0u, 0u);
+        if ((uint32_t)lane < a.row_cells) m_next = row[lane];
+        for (uint32_t i0 = 0; i0 < a.row_cells; i0 += 64) {
+            const uint32_t idx = i0 + lane;
+            const uint4 m = m_next;
+            m_next = make_uint4(0u, 0u, 0u, 0u);
+            if (idx + 64 < a.row_cells) m_next = row[idx + 64];
+            const uint32_t wd[4] = {m.x, m.y, m.z, m.w};
             const uint32_t pc = __builtin_popcount(m.x) + __builtin_popcount(m.y) + __builtin_popcount(m.z) + __builtin_popcount(m.w);
-            uint32_t tot;
-            const uint32_t ex = excl_scan_256(pc, wsum, tot);
-            int64_t at = run + ex;
-            run += tot;
-            if (pc) {
-                WindowBases<LEN> wb;
-                wb.decode(W, l, a.KP);
-                const uint32_t nn = (uint32_t)(n + a.n0 + 1), ll = (uint32_t)(l + 1);
-                const uint32_t wd[4] = {m.x, m.y, m.z, m.w};
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    uint32_t bits = wd[q];
-                    while (bits) {
-                        const int i = __builtin_ctz(bits);
-                        bits &= bits - 1;
-                        const uint32_t k = (uint32_t)(ch * 4 + q) * 32 + i;
-                        a.hits[at] = HitRec{k + 1, nn, ll};
-                        a.hit_scores[at] = wb.score(tb, k);
-                        at++;
-                        if (a.hist_bins) atomicAdd(&hist[k], 1u);
-                    }
-                }
-            }
+            const uint32_t inc = wave_incl_scan(pc, lane);            // hits up to and with this cell inside the slab
+            const uint32_t tot = __shfl(inc, 63);
+            if (tot) push_and_drain(queue, head, qlen, wd, idx, inc - pc, tot, emit);
         }
+        if ((uint32_t)lane < qlen) emit(queue[(head + lane) & (QN - 1)], head + lane);
+        wave_lds_sync();
     }
     if (a.hist_bins) {
         __syncthreads();
-        for (int i = tid; i < a.hist_bins; i += FILL_THREADS)
+        for (int i = tid; i < a.hist_bins; i += VF_THREADS)
             if (hist[i]) atomicAdd((unsigned long long*)&a.pwm_counts[i], (unsigned long long)hist[i]);
     }
 }
@@ -357,27 +408,26 @@ hipError_t launch_cand(const CandArgs& a, hipStream_t st) {
     }
 }
 
-static unsigned fill_grid2(int64_t nrows) { return (unsigned)std::min<int64_t>(nrows, 256 * 8); }
+static unsigned fill_grid2(int64_t nrows) { return (unsigned)std::min<int64_t>((nrows + VF_WAVES - 1) / VF_WAVES, 256 * 4); }
 
 template <int LEN>
 static hipError_t launch_verify_len(const FillArgs& a, hipStream_t st) {
-    const size_t tab_bytes = (size_t)LEN * 4 * a.KP * 4;
-    const bool lds_tab = 64 + tab_bytes <= 64 * 1024;
-    if (lds_tab)
-        hipLaunchKernelGGL((fill_verify_row_sums<LEN, true>), dim3(fill_grid2(a.nrows)), dim3(FILL_THREADS), 64 + tab_bytes, st, a);
+    const size_t base = (size_t)VF_WAVES * QN * 4;
+    const size_t tab_bytes = (size_t)LEN * 5 * a.KP * 4;
+    if (base + tab_bytes <= 64 * 1024)
+        hipLaunchKernelGGL((fill_verify_row_sums<LEN, true>), dim3(fill_grid2(a.nrows)), dim3(VF_THREADS), base + tab_bytes, st, a);
     else
-        hipLaunchKernelGGL((fill_verify_row_sums<LEN, false>), dim3(fill_grid2(a.nrows)), dim3(FILL_THREADS), 64, st, a);
+        hipLaunchKernelGGL((fill_verify_row_sums<LEN, false>), dim3(fill_grid2(a.nrows)), dim3(VF_THREADS), base, st, a);
     return hipGetLastError();
 }
 template <int LEN>
 static hipError_t launch_records_len(const FillArgs& a, hipStream_t st) {
-    const size_t tab_bytes = (size_t)LEN * 4 * a.KP * 4;
-    const size_t base = (16 + (size_t)a.hist_bins) * 4;
-    const bool lds_tab = base + tab_bytes <= 64 * 1024;
-    if (lds_tab)
-        hipLaunchKernelGGL((fill_records_plain<LEN, true>), dim3(fill_grid2(a.nrows)), dim3(FILL_THREADS), base + tab_bytes, st, a);
+    const size_t base = (size_t)VF_WAVES * QN * 4 + (size_t)a.hist_bins * 4;
+    const size_t tab_bytes = (size_t)LEN * 5 * a.KP * 4;
+    if (base + tab_bytes <= 64 * 1024)
+        hipLaunchKernelGGL((fill_records_plain<LEN, true>), dim3(fill_grid2(a.nrows)), dim3(VF_THREADS), base + tab_bytes, st, a);
     else
-        hipLaunchKernelGGL((fill_records_plain<LEN, false>), dim3(fill_grid2(a.nrows)), dim3(FILL_THREADS), base, st, a);
+        hipLaunchKernelGGL((fill_records_plain<LEN, false>), dim3(fill_grid2(a.nrows)), dim3(VF_THREADS), base, st, a);
     return hipGetLastError();
 }
 
