@@ -64,6 +64,7 @@ struct motifs_ctx {
     int64_t kernel_launches[motifs::KS_COUNT_] = {0};
     // scan workspaces
     motifs::DevBuf tab, lim, cnt, off, tilesum, small, codes, hits_tmp, scores_tmp, pwmcnt, data_tmp, afrag, cinit;
+    motifs::DevBuf staging, rowx;   // matrix-core scan: staged hit words, per-row offsets
     void* pinned = nullptr;  // small pinned host block for totals / flags
 };
 

@@ -130,14 +130,18 @@ static void pack_mfma(const PackedBank& bank, const int64_t* lens, int K, MfmaBa
         for (int q = 0; q < 32; q++) {
             const int k = tile * 32 + q;
             if (k >= K) continue;
-            double A = 0;
+            // |s - S| <= sum over the adds of half an ulp of the running sum.  After i positions the running sum
+            // is at most P_i = sum_{j<=i} max_a |w_j| (times (1 + 2^-11)^i), so the i-th add rounds by at most
+            // 2^-11 P_i, or 2^-25 in the subnormal range; 1.02 covers the compounding.
+            double A = 0, E = 0;
             const int len = (int)lens[k];
             for (int ind = 0; ind < len; ind++) {
                 double mx = 0;
                 for (int a = 0; a < 4; a++) mx = std::max(mx, (double)std::fabs(h2f_host(wbits(k, a, ind))));
                 A += mx;
+                if (ind > 0) E += A;                          // the first add (0 + w) is exact
             }
-            float eps = (float)(std::ldexp(A * len, -10) + std::ldexp((double)len, -22));
+            float eps = (float)(1.02 * std::ldexp(E, -11) + std::ldexp((double)len, -24) + std::ldexp(A, -20));
             if (A * 1.02 >= 60000.0) eps = INFINITY;          // a partial sum may overflow binary16: keep every window
             out.cinit[((size_t)tile * 2 + (q >> 4)) * 16 + (q & 15)] = eps;
         }
@@ -172,8 +176,8 @@ static int upload_bank(motifs_ctx* c, const PackedBank& bank) {
 
 using namespace motifs;
 
-// Hit records through the matrix cores: candidates (scan_cand_kernel) -> exact verification + row sums ->
-// scan -> records.  The bank has already been uploaded (tab, lim).
+// Hit records through the matrix cores: candidates (scan_cand_kernel) -> exact verification, staged hits and
+// row counts (stage_hits) -> scan -> records (emit_records); no host round trip in between.  The bank has already been uploaded (tab, lim).
 static int scan_hits_mfma(motifs_ctx* c, const PackedBank& bank, const int64_t* lens, int K, const uint8_t* codes_dev, int64_t N,
                           int L, int Lout, int64_t n0, int batch, motifs_hit* hits_dev, uint16_t* hit_scores_dev, int64_t cap,
                           int64_t* n_out, int64_t* per_pwm_counts_dev) {
@@ -185,27 +189,33 @@ static int scan_hits_mfma(motifs_ctx* c, const PackedBank& bank, const int64_t* 
     MOTIFS_HIP_CHECK(hipMemcpyAsync(c->cinit.p, mb.cinit.data(), mb.cinit.size() * 4, hipMemcpyHostToDevice, c->stream));
     MOTIFS_HIP_CHECK(hipStreamSynchronize(c->stream));
 
+    const bool emit = hits_dev != nullptr && cap > 0;
+    const int rpr = stage_row_reads(bank.nch);                       // reads per row of cells
+    const int parts = (batch + rpr - 1) / rpr;
+    const int row_slots = 2 * rpr * bank.nch;                        // staged hits per row before the slow path
     const size_t per_batch = (size_t)Lout * batch * bank.nch * 16;
-    int64_t nb_max = (int64_t)((8ull << 30) / per_batch);
+    const size_t stage_per_batch = emit ? (size_t)Lout * parts * row_slots * 4 : 0;
+    int64_t nb_max = (int64_t)((8ull << 30) / (per_batch + stage_per_batch));
     nb_max = std::max<int64_t>(1, std::min<int64_t>(nb_max, (N + batch - 1) / batch));
     const int64_t sb = nb_max * batch;
-    int parts = 1;                 // rows of ~1000-2500 cells balance the blocks better than whole (batch, l) lines
-    while (parts < 8 && batch % (parts * 2) == 0 && (int64_t)batch / (parts * 2) * bank.nch >= 1024) parts *= 2;
     const int64_t rows_max = nb_max * Lout * parts;
     MOTIFS_HIP_CHECK(c->cnt.reserve((size_t)nb_max * per_batch));
     MOTIFS_HIP_CHECK(c->tilesum.reserve((size_t)rows_max * 4));
-    MOTIFS_HIP_CHECK(c->off.reserve((size_t)rows_max * 8));
+    MOTIFS_HIP_CHECK(c->off.reserve((size_t)((rows_max + 1023) / 1024) * 8));
+    MOTIFS_HIP_CHECK(c->rowx.reserve((size_t)rows_max * 4));
+    if (emit) MOTIFS_HIP_CHECK(c->staging.reserve((size_t)nb_max * stage_per_batch));
     MOTIFS_HIP_CHECK(c->small.reserve(64));
     MOTIFS_HIP_CHECK(c->pwmcnt.reserve((size_t)2 * bank.KP * 8));
     if (per_pwm_counts_dev) MOTIFS_HIP_CHECK(hipMemsetAsync(c->pwmcnt.p, 0, (size_t)2 * bank.KP * 8, c->stream));
-    int64_t* total_dev = (int64_t*)c->small.p;
+    // small: [0], [1] record totals (ping-pong between super-batches)
+    int64_t* totals = (int64_t*)c->small.p;
+    MOTIFS_HIP_CHECK(hipMemsetAsync(c->small.p, 0, 64, c->stream));
     int64_t* h_total = (int64_t*)c->pinned;
     const int PG = cand_tile_group(bank.lenp);
     const int ntile_w = (Lout + 31) / 32;
 
-    int64_t emitted = 0;
-    bool too_small = false;
-    for (int64_t s0 = 0; s0 < N; s0 += sb) {
+    int launch_no = 0;
+    for (int64_t s0 = 0; s0 < N; s0 += sb, launch_no++) {
         const int64_t ns = std::min<int64_t>(sb, N - s0);
         const int64_t nb = (ns + batch - 1) / batch;
         CandArgs a{};
@@ -230,23 +240,26 @@ static int scan_hits_mfma(motifs_ctx* c, const PackedBank& bank, const int64_t* 
         FillArgs f{};
         f.masks = (const uint4*)c->cnt.p;
         f.parts = parts;
+        f.rpr = rpr;
         f.nrows = nb * Lout * parts;
-        f.row_cells = (uint32_t)(batch / parts * bank.nch);
         f.row_sum = (uint32_t*)c->tilesum.p;
-        f.row_base = (int64_t*)c->off.p;
-        f.total = total_dev;
+        f.blk_base = (unsigned long long*)c->off.p;
+        f.staging = (uint32_t*)c->staging.p;
+        f.row_slots = row_slots;
+        f.row_excl = (uint32_t*)c->rowx.p;
+        f.base_in = totals + (launch_no & 1);
+        f.total = totals + ((launch_no + 1) & 1);
+        f.cap = cap;
         f.tab = (const uint32_t*)c->tab.p;
         f.codes = a.codes;
         f.hits = (HitRec*)hits_dev;
         f.hit_scores = hit_scores_dev;
         f.pwm_counts = per_pwm_counts_dev ? (int64_t*)c->pwmcnt.p : nullptr;
-        f.base0 = emitted;
         f.n0 = n0 + s0;
         f.nch = bank.nch;
         f.batch = batch;
         f.Lout = Lout;
         f.LoutP = Lout;
-        f.lshift = 0;
         f.lenp = bank.lenp;
         f.KP = bank.KP;
         f.pitch = a.d.pitch;
@@ -263,27 +276,26 @@ static int scan_hits_mfma(motifs_ctx* c, const PackedBank& bank, const int64_t* 
             f.div_nch.m = d == 1 ? 0u : (uint32_t)((((uint64_t)1 << 32) * (((uint64_t)1 << sh) - d)) / d + 1);
         }
         if (ns < nb * batch)   // cells of reads the last batch does not have are never written by the scan
-            MOTIFS_HIP_CHECK(hipMemsetAsync(c->cnt.p, 0, (size_t)f.nrows * f.row_cells * 16, c->stream));
+            MOTIFS_HIP_CHECK(hipMemsetAsync(c->cnt.p, 0, (size_t)nb * per_batch, c->stream));
         {
             KernelTimer t(c, KS_SCAN_COUNT);
             MOTIFS_HIP_CHECK(launch_cand(a, c->stream));
         }
         {
             KernelTimer t(c, KS_SCAN_OFFSETS);
-            MOTIFS_HIP_CHECK(launch_verify_row_sums(f, c->stream));
-            MOTIFS_HIP_CHECK(launch_fill_scan(f, c->stream));
+            MOTIFS_HIP_CHECK(launch_stage_hits(f, emit, c->stream));
+            MOTIFS_HIP_CHECK(launch_row_scan(f, c->stream));
         }
-        MOTIFS_HIP_CHECK(hipMemcpyAsync(h_total, total_dev, 8, hipMemcpyDeviceToHost, c->stream));
-        MOTIFS_HIP_CHECK(hipStreamSynchronize(c->stream));
-        const int64_t sb_total = *h_total;
-        if (emitted + sb_total > cap) too_small = true;
-        if (!too_small && sb_total > 0) {
+        if (emit) {
             KernelTimer t(c, KS_SCAN_FILL);
-            MOTIFS_HIP_CHECK(launch_fill_records_plain(f, c->stream));
+            MOTIFS_HIP_CHECK(launch_emit_records(f, c->stream));
         }
-        if (f.pwm_counts && (too_small || f.hist_bins == 0)) MOTIFS_HIP_CHECK(launch_cell_histogram(f, c->stream));
-        emitted += sb_total;
     }
+    // records are written up to cap in any case; the total says whether they all fitted
+    MOTIFS_HIP_CHECK(hipMemcpyAsync(h_total, totals + (launch_no & 1), 8, hipMemcpyDeviceToHost, c->stream));
+    MOTIFS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    const int64_t emitted = *h_total;
+    const bool too_small = emitted > cap;
     *n_out = emitted;
     if (per_pwm_counts_dev)
         MOTIFS_HIP_CHECK(hipMemcpyAsync(per_pwm_counts_dev, c->pwmcnt.p, (size_t)K * 8, hipMemcpyDeviceToDevice, c->stream));
@@ -339,7 +351,7 @@ void motifs_ctx_destroy(motifs_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : {&c->tab, &c->lim, &c->cnt, &c->off, &c->tilesum, &c->small, &c->codes, &c->hits_tmp,
-                      &c->scores_tmp, &c->pwmcnt, &c->data_tmp, &c->afrag, &c->cinit})
+                      &c->scores_tmp, &c->pwmcnt, &c->data_tmp, &c->afrag, &c->cinit, &c->staging, &c->rowx})
         b->release();
     if (c->pinned) (void)hipHostFree(c->pinned);
     resolve_timing(c);

@@ -64,7 +64,14 @@ struct FillArgs {
     int64_t N;                // reads in this super-batch (cells of later reads are empty)
     int K;
     int lim_min;              // starts <= lim_min are valid for every PWM
-    int parts;                // matrix-core path: a (batch, l) line of cells is split into this many rows
+    // matrix-core path (stage_hits / emit_records): a (batch, l) line of cells is split into `parts` rows of `rpr` reads
+    int parts, rpr;
+    uint32_t* staging;            // [nrows][row_slots] staged hit words
+    int row_slots;
+    uint32_t* row_excl;           // [nrows] hits before the row inside its block of 1024 rows
+    unsigned long long* blk_base; // [ceil(nrows / 1024)] block totals, then records before the block
+    const int64_t* base_in;       // records emitted before this super-batch
+    int64_t cap;                  // records the output arrays can hold
     struct {
         uint32_t d, m, s;
         __device__ uint32_t div(uint32_t n) const {
@@ -92,9 +99,10 @@ struct CandArgs {
 };
 int cand_tile_group(int lenp);
 hipError_t launch_cand(const CandArgs& a, hipStream_t st);
-hipError_t launch_verify_row_sums(const FillArgs& a, hipStream_t st);      // FillArgs: LoutP = Lout, lshift = 0
-hipError_t launch_fill_records_plain(const FillArgs& a, hipStream_t st);
-hipError_t launch_cell_histogram(const FillArgs& a, hipStream_t st);
+int stage_row_reads(int nch);                                              // reads per row of cells
+hipError_t launch_stage_hits(const FillArgs& a, bool stage, hipStream_t st);   // candidates -> staged hits + row counts (+ histogram)
+hipError_t launch_row_scan(const FillArgs& a, hipStream_t st);             // row counts -> offsets; *total = *base_in + hits
+hipError_t launch_emit_records(const FillArgs& a, hipStream_t st);         // staged hits -> records
 hipError_t launch_fill_scan(const FillArgs& a, hipStream_t st);            // exclusive scan of row_sum
 
 int scan_len_padded(int maxlen);

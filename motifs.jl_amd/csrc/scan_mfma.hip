@@ -5,9 +5,11 @@
 // binary16 weights with 0/1 are exact), which is NOT the reference's arithmetic — greedy_search!
 // (src/inference/_h3_1_alignment.jl:26-31) adds in binary16, rounding after every add.  So the matrix
 // cores only FILTER: with S the exact sum and s the sequentially rounded one,
-//     |s - S| <= eps_k := 2^-10 * len_k * A_k,   A_k = sum_ind max_a |pwm[k, a, ind]|
-// (each of the len adds rounds by at most 2^-11 of a partial sum bounded by A_k; the factor 2 covers
-// second-order terms and binary16 subnormals), hence s > 0 implies S > -eps_k.  Every (PWM, window)
+//     |s - S| <= eps_k := 1.02 * 2^-11 * sum_{i=2..len_k} P_i,   P_i = sum_{j<=i} max_a |pwm[k, a, j]|
+// (the i-th add rounds by at most half an ulp of a running sum bounded by P_i; the first add is exact; 1.02
+// covers the compounding, and small absolute terms cover binary16 subnormals and the f32 GEMM's own rounding;
+// pack_mfma in scan_api.hip),
+// hence s > 0 implies S > -eps_k.  Every (PWM, window)
 // with S > -eps_k becomes a candidate bit; candidates (about 1 % of the pairs) are then re-scored in the
 // reference's arithmetic and only true hits survive (fill_verify_row_sums), so records and scores stay
 // bit-identical to the reference while 99 % of the pairs never touch the slow fp16 chain.
@@ -39,6 +41,58 @@ static __device__ __forceinline__ unsigned xcd_swz(unsigned b, unsigned nb) {
 //   B operand (cols): 32 consecutive windows; lane (w, h) needs the one-hot of positions l0+w+4t+2h, +1,
 //                     read as two 8-byte LDS words from the read's one-hot image;
 //   C = eps_k per PWM row, so that the sign bit of the result is "not a candidate".
+// NG = live tiles of the group (tiles past the bank hold no PWM).  The body is branch-free so that the NG
+// accumulator chains interleave: the matrix pipe works on one tile while the VALU packs the signs of another.
+template <int T, int PG, int NG>
+static __device__ __forceinline__ void cand_read(const f16x8 (&A)[PG][T], const f32x16 (&C0)[PG], const uint2* oh, uint32_t* cp0,
+                                                 size_t lstride4, int ntile, int Lout, int w, int h) {
+    for (int wt = 0; wt < ntile; wt++) {
+        const int l0 = wt * 32;
+        f16x8 B[T];
+#pragma unroll
+        for (int t = 0; t < T; t++) {
+            const int pos = l0 + w + 4 * t + 2 * h;
+            const uint2 a0 = oh[pos], a1 = oh[pos + 1];
+            B[t] = __builtin_bit_cast(f16x8, make_uint4(a0.x, a0.y, a1.x, a1.y));
+        }
+        f32x16 acc[NG];
+#pragma unroll
+        for (int g = 0; g < NG; g++) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[g][0], B[0], C0[g], 0, 0, 0);
+#pragma unroll
+        for (int t = 1; t < T; t++)
+#pragma unroll
+            for (int g = 0; g < NG; g++) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[g][t], B[t], acc[g], 0, 0, 0);
+        uint32_t m[PG];           // bit r = accumulator r is a candidate (sign clear = above -eps)
+#pragma unroll
+        for (int g = 0; g < PG; g++) {
+            m[g] = 0;
+            if (g < NG) {
+                uint32_t v = 0;
+#pragma unroll
+                for (int r = 15; r >= 0; r--) v = __builtin_amdgcn_alignbit(v, __float_as_uint(acc[g][r]), 31);
+                m[g] = ~v & 0xffffu;
+            }
+        }
+        // the other 16 PWMs of a tile sit in the other half of the wave: v_permlane32_swap hands lane (w, 0) both
+        // halves of one tile and lane (w, 1) both halves of another, so all 64 lanes store
+        const int l = l0 + w;
+        uint32_t* cp = cp0 + (size_t)l * lstride4;
+        if (PG == 4) {
+            const auto s02 = __builtin_amdgcn_permlane32_swap(m[0], m[2], false, false);
+            const auto s13 = __builtin_amdgcn_permlane32_swap(m[1], m[3], false, false);
+            const uint32_t wa = s02[0] | (s02[1] << 16), wb = s13[0] | (s13[1] << 16);   // h=0: words 0,1; h=1: words 2,3
+            if (l < Lout && (NG > 2 || h == 0)) *(uint2*)(cp + 2 * h) = make_uint2(wa, wb);
+        } else if (PG == 2) {
+            const auto s01 = __builtin_amdgcn_permlane32_swap(m[0], m[1 % PG], false, false);
+            const uint32_t wa = s01[0] | (s01[1] << 16);                                  // h=0: word 0; h=1: word 1
+            if (l < Lout) cp[h] = wa;
+        } else {
+            const auto s00 = __builtin_amdgcn_permlane32_swap(m[0], m[0], false, false);
+            if (l < Lout && h == 0) cp[0] = s00[0] | (s00[1] << 16);
+        }
+    }
+}
+
 template <int T, int PG>
 __global__ __launch_bounds__(512) void scan_cand_kernel(const uint4* __restrict__ afrag, const float* __restrict__ cinit,
                                                         const uint8_t* __restrict__ codes, uint32_t* __restrict__ cells,
@@ -46,7 +100,6 @@ __global__ __launch_bounds__(512) void scan_cand_kernel(const uint4* __restrict_
     extern __shared__ uint2 oh_all[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int w = lane & 31, h = lane >> 5;
-    const int swap_addr = (lane ^ 32) << 2;          // ds_bpermute byte address of the partner lane (other half)
     uint2* oh = oh_all + (size_t)wave * ((d.ohlen + 3) & ~3);
     // 8 waves = 4 reads x 2 tile groups: the two halves of a 128-byte line of cells (4 reads x 2 chunks) are
     // written by the same block at about the same time
@@ -55,6 +108,7 @@ __global__ __launch_bounds__(512) void scan_cand_kernel(const uint4* __restrict_
     if (tg * PG >= d.used_tiles) return;
     const int tile0 = tg * PG;
     const int chunk = tile0 >> 2, word0 = tile0 & 3;
+    const int ng = d.used_tiles - tile0 < PG ? d.used_tiles - tile0 : PG;   // wave-uniform
 
     f16x8 A[PG][T];
     f32x16 C0[PG];
@@ -71,6 +125,7 @@ __global__ __launch_bounds__(512) void scan_cand_kernel(const uint4* __restrict_
 
     const unsigned lb = xcd_swz(blockIdx.x, gridDim.x);
     const int ntile = (d.Lout + 31) / 32;
+    const size_t lstride4 = (size_t)d.batch * d.nch * 4;
     for (int s = 0; s < d.spw; s++) {
         const int64_t n = ((int64_t)lb * d.spw + s) * 4 + slot;        // wave-uniform
         if (n >= d.N) break;
@@ -83,59 +138,38 @@ __global__ __launch_bounds__(512) void scan_cand_kernel(const uint4* __restrict_
             for (int u = 0; u < 4; u++) {
                 const int p = p4 * 4 + u;
                 const uint32_t c = p < d.L ? (wv >> (8 * u)) & 0xffu : 4u;
-                uint2 v = make_uint2(0u, 0u);
-                if (c < 2) v.x = 0x3c00u << (16 * c);
-                else if (c < 4) v.y = 0x3c00u << (16 * (c - 2));
-                if (p < d.ohlen) oh[p] = v;
+                const uint64_t one = c < 4 ? (uint64_t)0x3c00u << (16 * c) : 0ull;
+                if (p < d.ohlen) oh[p] = make_uint2((uint32_t)one, (uint32_t)(one >> 32));
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const int64_t bq = n / d.batch;
         const size_t cell0 = ((size_t)bq * d.Lout * d.batch + (size_t)(n - bq * d.batch)) * d.nch + chunk;   // l = 0
-        const size_t lstride = (size_t)d.batch * d.nch;
-        for (int wt = 0; wt < ntile; wt++) {
-            const int l0 = wt * 32;
-            f16x8 B[T];
-#pragma unroll
-            for (int t = 0; t < T; t++) {
-                const int pos = l0 + w + 4 * t + 2 * h;
-                const uint2 a0 = oh[pos], a1 = oh[pos + 1];
-                B[t] = __builtin_bit_cast(f16x8, make_uint4(a0.x, a0.y, a1.x, a1.y));
-            }
-            uint32_t word[PG];
-#pragma unroll
-            for (int g = 0; g < PG; g++) {
-                word[g] = 0;
-                if (tile0 + g < d.used_tiles) {                        // wave-uniform: tiles past K hold no PWM
-                    f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[g][0], B[0], C0[g], 0, 0, 0);
-#pragma unroll
-                    for (int t = 1; t < T; t++) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[g][t], B[t], acc, 0, 0, 0);
-                    uint32_t m = 0;           // bit r = sign of accumulator r (set = below -eps = no candidate)
-#pragma unroll
-                    for (int r = 15; r >= 0; r--) m = __builtin_amdgcn_alignbit(m, __float_as_uint(acc[r]), 31);
-                    m = ~m & 0xffffu;
-                    const uint32_t other = (uint32_t)__builtin_amdgcn_ds_bpermute(swap_addr, (int)m);   // the other 16 PWMs
-                    word[g] = h ? (other | (m << 16)) : (m | (other << 16));
-                }
-            }
-            const int l = l0 + w;
-            if (h == 0 && l < d.Lout) {
-                uint32_t* cp = cells + (cell0 + (size_t)l * lstride) * 4 + word0;
-                if (PG == 4) *(uint4*)cp = make_uint4(word[0], word[1 % PG], word[2 % PG], word[3 % PG]);
-                else if (PG == 2) *(uint2*)cp = make_uint2(word[0], word[1 % PG]);
-                else cp[0] = word[0];
-            }
+        uint32_t* cp0 = cells + cell0 * 4 + word0;
+        switch (ng) {
+            case 1: cand_read<T, PG, 1>(A, C0, oh, cp0, lstride4, ntile, d.Lout, w, h); break;
+            case 2: cand_read<T, PG, (PG >= 2 ? 2 : PG)>(A, C0, oh, cp0, lstride4, ntile, d.Lout, w, h); break;
+            case 3: cand_read<T, PG, (PG >= 3 ? 3 : PG)>(A, C0, oh, cp0, lstride4, ntile, d.Lout, w, h); break;
+            default: cand_read<T, PG, PG>(A, C0, oh, cp0, lstride4, ntile, d.Lout, w, h); break;
         }
         __builtin_amdgcn_wave_barrier();
     }
 }
 
-// ---- exact re-scoring in the reference's arithmetic, load-balanced over a wave ---------------------------
-// Each lane owns one cell (its mask words and the table row offsets of its window's bases); the set bits of
-// the 64 cells are queued in LDS and then taken round-robin by all 64 lanes, so a cell with five candidates
-// does not hold up 63 lanes with none.
+// ---- candidates -> records ---------------------------------------------------------------------------------
+// stage_hits: every WAVE takes rows of cells (a row = the (read, chunk) cells of a few reads at one start l),
+// pushes the set bits of a row into an LDS ring and re-scores the ring 64 candidates at a time in the
+// reference's arithmetic with all lanes busy; a hit becomes one packed word (cell, bit, score) in the row's
+// staging slots and the row's hit count is stored.  No block barriers after the table is staged and no
+// traffic between waves.  After an exclusive scan of the row counts, emit_records turns the staged words
+// into (m, n, l, score) records at their final offsets; a row with more hits than staging slots is re-scored
+// from its cells there (rare: more than two hits per cell on average).
 constexpr uint32_t NOROW = 0xffffffffu;
+constexpr int VF_THREADS = 512;
+constexpr int VF_WAVES = VF_THREADS / 64;
+constexpr int QN = 128;           // candidate ring slots per wave (power of two); fewer than 64 stay behind after a push
+constexpr int ROW_CELLS_MAX = 512;
 
 // table row offsets of the LEN bases of a window from its raw code words (all-zero column: column 4 of the
 // 5-column LDS table, or NOROW for the 4-column global table)
@@ -155,7 +189,7 @@ static __device__ __forceinline__ void fetch_codes(const uint8_t* codes, int64_t
 #pragma unroll
     for (int q = 0; q <= LEN / 4; q++) W[q] = sw[q];
 }
-// sequential binary16 sum of PWM k over the owner's window (table entries beyond lens[k] are +0)
+// sequential binary16 sum of PWM k over the window (table entries beyond lens[k] are +0)
 template <int LEN, bool LDS_TAB>
 static __device__ __forceinline__ uint16_t exact_score(const uint32_t* tb, const uint32_t* rofs, uint32_t k) {
     const uint32_t kp = k >> 1, sh = (k & 1u) * 16;
@@ -192,27 +226,17 @@ static __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) 
     }
     return v;
 }
-// LDS traffic between lanes of one wave: program order is execution order, the fence stops the compiler
+// LDS traffic between lanes of one wave: program order is execution order, the fences stop the compiler
 static __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Both kernels below give every WAVE its own rows of cells and its own LDS queue: a wave walks a row 64 cells
-// at a time, pushes every set bit into the queue, and scores the queue 64 candidates at a time with all lanes
-// busy (a cell with five candidates does not stall the 63 lanes beside it; cells without candidates cost a
-// load and a popcount).  No block barriers after the table is staged, so the waves of a CU hide each other's
-// load latency.
-constexpr int VF_THREADS = 512;
-constexpr int VF_WAVES = VF_THREADS / 64;
-constexpr int QN = 256;           // ring slots per wave (power of two); fewer than 64 stay behind after a push round
-
-// the candidates of one 64-cell slab into the wave's FIFO ring, draining full batches of 64 through
-// fn(candidate word, ordinal of the candidate in the row).  head = candidates of this row drained so far.
+// the candidates of one 64-cell slab into the wave's FIFO ring, draining full batches of 64 through fn(word)
 // candidate word = cell index in the row << 7 | word << 5 | bit
 template <typename F>
-static __device__ __forceinline__ void push_and_drain(uint32_t* queue, uint32_t& head, uint32_t& qlen, const uint32_t (&wd)[4],
+static __device__ __forceinline__ void push_and_drain(uint16_t* queue, uint32_t& head, uint32_t& qlen, const uint32_t (&wd)[4],
                                                       uint32_t idx, uint32_t ex, uint32_t tot, F&& fn) {
     const int lane = threadIdx.x & 63;
     uint32_t done = 0;
@@ -227,7 +251,7 @@ static __device__ __forceinline__ void push_and_drain(uint32_t* queue, uint32_t&
                 const int i = __builtin_ctz(bits);
                 bits &= bits - 1;
                 if (g >= done && g < done + take)
-                    queue[(head + qlen + g - done) & (QN - 1)] = (idx << 7) | ((uint32_t)q << 5) | (uint32_t)i;
+                    queue[(head + qlen + g - done) & (QN - 1)] = (uint16_t)((idx << 7) | ((uint32_t)q << 5) | (uint32_t)i);
                 g++;
             }
         }
@@ -235,7 +259,7 @@ static __device__ __forceinline__ void push_and_drain(uint32_t* queue, uint32_t&
         done += take;
         wave_lds_sync();
         while (qlen >= 64) {
-            fn(queue[(head + lane) & (QN - 1)], head + lane);
+            fn((uint32_t)queue[(head + lane) & (QN - 1)], true);
             head += 64;
             qlen -= 64;
         }
@@ -244,119 +268,99 @@ static __device__ __forceinline__ void push_and_drain(uint32_t* queue, uint32_t&
     }
 }
 
-// V1: candidates -> hits, in place, plus hits per cell row (one row = the (n, chunk) cells of one (batch, l, part)).
-template <int LEN, bool LDS_TAB>
-__global__ __launch_bounds__(VF_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void fill_verify_row_sums(FillArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    uint32_t* queue = smem + wv * QN;                                 // [VF_WAVES][QN]
-    uint32_t* ltab = smem + VF_WAVES * QN;
-    const uint32_t* tb = stage_table<LEN, LDS_TAB, VF_THREADS>(a.tab, a.KP, ltab);
-    uint32_t* cells = (uint32_t*)const_cast<uint4*>(a.masks);
-    const uint32_t part_reads = (uint32_t)(a.batch / a.parts);
-    const int64_t nwaves = (int64_t)gridDim.x * VF_WAVES;
-    for (int64_t r = (int64_t)wv * gridDim.x + blockIdx.x; r < a.nrows; r += nwaves) {
-        const int part = (int)(r % a.parts);
-        const int64_t rl = r / a.parts;
-        const int l = (int)(rl % a.LoutP);
-        const int64_t bq = rl / a.LoutP;
-        uint32_t* row = cells + (size_t)r * a.row_cells * 4;
-        const bool all_valid = l <= a.lim_min;                        // every PWM fits at this start
-        const int64_t nrow0 = bq * a.batch + (int64_t)part * part_reads;
-        uint32_t qlen = 0, head = 0, nhit = 0;                        // wave-uniform
-        auto score = [&](const uint32_t cw) {                         // one candidate per lane
-            const uint32_t idx = cw >> 7, q = (cw >> 5) & 3u, i = cw & 31u;
-            const uint32_t nin = a.div_nch.div(idx);
-            const uint32_t ch = idx - nin * a.nch;
-            const int64_t n = nrow0 + nin;
-            const uint32_t k = (ch * 4 + q) * 32 + i;
-            bool hit = false;
-            if (n < a.N && (int)k < a.K && (all_valid || l <= a.lim[k])) {
-                uint32_t W[LEN / 4 + 1], rofs[LEN];
-                fetch_codes<LEN>(a.codes, n, a.pitch, l, W);
-                window_offsets<LEN, LDS_TAB>(W, l, a.KP, rofs);
-                hit = half_pos(exact_score<LEN, LDS_TAB>(tb, rofs, k));
-            }
-            if (!hit) atomicAnd(&row[idx * 4 + q], ~(1u << i));
-            return hit;
-        };
-        auto score_count = [&](const uint32_t cw, uint32_t) { nhit += (uint32_t)__builtin_popcountll(__ballot(score(cw))); };
-        uint4 m_next = make_uint4(0u, 0u, 0u, 0u);
-        if ((uint32_t)lane < a.row_cells) m_next = ((const uint4*)row)[lane];
-        for (uint32_t i0 = 0; i0 < a.row_cells; i0 += 64) {           // wave-uniform trip count
-            const uint32_t idx = i0 + lane;
-            const uint4 m = m_next;
-            m_next = make_uint4(0u, 0u, 0u, 0u);
-            if (idx + 64 < a.row_cells) m_next = ((const uint4*)row)[idx + 64];
-            const uint32_t wd[4] = {m.x, m.y, m.z, m.w};
-            const uint32_t pc = __builtin_popcount(m.x) + __builtin_popcount(m.y) + __builtin_popcount(m.z) + __builtin_popcount(m.w);
-            const uint32_t inc = wave_incl_scan(pc, lane);
-            const uint32_t tot = __shfl(inc, 63);
-            if (tot) push_and_drain(queue, head, qlen, wd, idx, inc - pc, tot, score_count);
-        }
-        {                                                             // the remainder (< 64)
-            bool hit = false;
-            if ((uint32_t)lane < qlen) hit = score(queue[(head + lane) & (QN - 1)]);
-            nhit += (uint32_t)__builtin_popcountll(__ballot(hit));
-        }
-        wave_lds_sync();
-        if (lane == 0) a.row_sum[r] = nhit;
-    }
+// geometry of row r: reads [n_lo, n_lo + nreads) of batch bq at start l
+struct RowGeom {
+    int l;
+    int64_t bq, nrow0;            // nrow0 = index of the row's first read in the super-batch
+    uint32_t row_cells;
+    const uint4* cells;
+};
+static __device__ __forceinline__ RowGeom row_geom(const FillArgs& a, int64_t r) {
+    RowGeom g;
+    const uint32_t part = (uint32_t)r % (uint32_t)a.parts;
+    const uint32_t rl = (uint32_t)r / (uint32_t)a.parts;
+    g.l = (int)(rl % (uint32_t)a.Lout);
+    g.bq = rl / (uint32_t)a.Lout;
+    const uint32_t n_lo = part * (uint32_t)a.rpr;
+    const uint32_t nreads = (uint32_t)a.batch - n_lo < (uint32_t)a.rpr ? (uint32_t)a.batch - n_lo : (uint32_t)a.rpr;
+    g.row_cells = nreads * (uint32_t)a.nch;
+    g.cells = a.masks + (((size_t)g.bq * a.Lout + g.l) * a.batch + n_lo) * a.nch;
+    g.nrow0 = g.bq * a.batch + n_lo;
+    return g;
 }
 
-// V2: every (verified) bit becomes a record: (m, n, l) 1-based + the fp16 score, reference order.
+// walk a row's cells and hand every candidate to fn(candidate word, live) 64 at a time
+template <typename F>
+static __device__ __forceinline__ void for_row_candidates(const RowGeom& g, uint16_t* queue, F&& fn) {
+    const int lane = threadIdx.x & 63;
+    uint32_t qlen = 0, head = 0;                                      // wave-uniform
+    uint4 m_next = make_uint4(0u, 0u, 0u, 0u);
+    if ((uint32_t)lane < g.row_cells) m_next = g.cells[lane];
+    for (uint32_t i0 = 0; i0 < g.row_cells; i0 += 64) {               // wave-uniform trip count
+        const uint32_t idx = i0 + lane;
+        const uint4 m = m_next;
+        m_next = make_uint4(0u, 0u, 0u, 0u);
+        if (idx + 64 < g.row_cells) m_next = g.cells[idx + 64];
+        const uint32_t wd[4] = {m.x, m.y, m.z, m.w};
+        const uint32_t pc = __builtin_popcount(m.x) + __builtin_popcount(m.y) + __builtin_popcount(m.z) + __builtin_popcount(m.w);
+        const uint32_t inc = wave_incl_scan(pc, lane);
+        const uint32_t tot = __shfl(inc, 63);
+        if (tot) push_and_drain(queue, head, qlen, wd, idx, inc - pc, tot, fn);
+    }
+    if (qlen) fn((uint32_t)queue[(head + lane) & (QN - 1)], (uint32_t)lane < qlen);   // the remainder (< 64)
+    wave_lds_sync();
+}
+
+// exact score of one candidate word of row g; false if the candidate is not a hit
 template <int LEN, bool LDS_TAB>
-__global__ __launch_bounds__(VF_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void fill_records_plain(FillArgs a) {
+static __device__ __forceinline__ bool score_candidate(const FillArgs& a, const RowGeom& g, const uint32_t* tb, uint32_t cw, bool live,
+                                                       uint32_t& k, uint32_t& nin, uint16_t& sc) {
+    const uint32_t idx = cw >> 7, q = (cw >> 5) & 3u, i = cw & 31u;
+    nin = a.div_nch.div(idx);
+    const uint32_t ch = idx - nin * a.nch;
+    const int64_t n = g.nrow0 + nin;
+    k = (ch * 4 + q) * 32 + i;
+    sc = 0;
+    if (!(live && n < a.N && (int)k < a.K && (g.l <= a.lim_min || g.l <= a.lim[k]))) return false;
+    uint32_t W[LEN / 4 + 1], rofs[LEN];
+    fetch_codes<LEN>(a.codes, n, a.pitch, g.l, W);
+    window_offsets<LEN, LDS_TAB>(W, g.l, a.KP, rofs);
+    sc = exact_score<LEN, LDS_TAB>(tb, rofs, k);
+    return half_pos(sc);
+}
+
+// staged hit word: candidate word << 16 | binary16 score
+template <int LEN, bool LDS_TAB, bool STAGE>
+__global__ __launch_bounds__(VF_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void stage_hits(FillArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    uint32_t* queue = smem + wv * QN;                                 // [VF_WAVES][QN]
-    uint32_t* hist = smem + VF_WAVES * QN;                            // [hist_bins]
+    uint16_t* queue = (uint16_t*)smem + wv * QN;                      // [VF_WAVES][QN]
+    uint32_t* hist = smem + VF_WAVES * QN / 2;                        // [hist_bins]
     uint32_t* ltab = hist + a.hist_bins;
     for (int i = tid; i < a.hist_bins; i += VF_THREADS) hist[i] = 0;
     const uint32_t* tb = stage_table<LEN, LDS_TAB, VF_THREADS>(a.tab, a.KP, ltab);
     __syncthreads();
-    const uint32_t* cells = (const uint32_t*)a.masks;
-    const uint32_t part_reads = (uint32_t)(a.batch / a.parts);
     const int64_t nwaves = (int64_t)gridDim.x * VF_WAVES;
     for (int64_t r = (int64_t)wv * gridDim.x + blockIdx.x; r < a.nrows; r += nwaves) {
-        if (a.row_sum[r] == 0) continue;                              // wave-uniform
-        const int part = (int)(r % a.parts);
-        const int64_t rl = r / a.parts;
-        const int l = (int)(rl % a.LoutP);
-        const int64_t bq = rl / a.LoutP;
-        const uint4* row = (const uint4*)(cells + (size_t)r * a.row_cells * 4);
-        const int64_t row_at = a.base0 + a.row_base[r];
-        const int64_t nrow0 = bq * a.batch + (int64_t)part * part_reads;
-        uint32_t qlen = 0, head = 0;                                  // wave-uniform
-        auto emit = [&](const uint32_t cw, const uint32_t ord) {      // ord-th bit of the row = ord-th record
-            const uint32_t idx = cw >> 7, q = (cw >> 5) & 3u, i = cw & 31u;
-            const uint32_t nin = a.div_nch.div(idx);
-            const uint32_t ch = idx - nin * a.nch;
-            const int64_t n = nrow0 + nin;
-            const uint32_t k = (ch * 4 + q) * 32 + i;
-            uint32_t W[LEN / 4 + 1], rofs[LEN];
-            fetch_codes<LEN>(a.codes, n, a.pitch, l, W);
-            window_offsets<LEN, LDS_TAB>(W, l, a.KP, rofs);
-            const int64_t at = row_at + ord;
-            a.hits[at] = HitRec{k + 1, (uint32_t)(n + a.n0 + 1), (uint32_t)(l + 1)};
-            a.hit_scores[at] = exact_score<LEN, LDS_TAB>(tb, rofs, k);
-            if (a.hist_bins) atomicAdd(&hist[k], 1u);
-        };
-        uint4 m_next = make_uint4(0u, 0u, 0u, 0u);
-        if ((uint32_t)lane < a.row_cells) m_next = row[lane];
-        for (uint32_t i0 = 0; i0 < a.row_cells; i0 += 64) {
-            const uint32_t idx = i0 + lane;
-            const uint4 m = m_next;
-            m_next = make_uint4(0u, 0u, 0u, 0u);
-            if (idx + 64 < a.row_cells) m_next = row[idx + 64];
-            const uint32_t wd[4] = {m.x, m.y, m.z, m.w};
-            const uint32_t pc = __builtin_popcount(m.x) + __builtin_popcount(m.y) + __builtin_popcount(m.z) + __builtin_popcount(m.w);
-            const uint32_t inc = wave_incl_scan(pc, lane);            // hits up to and with this cell inside the slab
-            const uint32_t tot = __shfl(inc, 63);
-            if (tot) push_and_drain(queue, head, qlen, wd, idx, inc - pc, tot, emit);
-        }
-        if ((uint32_t)lane < qlen) emit(queue[(head + lane) & (QN - 1)], head + lane);
-        wave_lds_sync();
+        const RowGeom g = row_geom(a, r);
+        uint32_t* slots = a.staging + (size_t)r * a.row_slots;
+        uint32_t nhit = 0;                                            // wave-uniform
+        for_row_candidates(g, queue, [&](const uint32_t cw, const bool live) {
+            uint32_t k, nin;
+            uint16_t sc;
+            const bool hit = score_candidate<LEN, LDS_TAB>(a, g, tb, cw, live, k, nin, sc);
+            const unsigned long long hb = __ballot(hit);
+            if (hit) {
+                if (STAGE) {
+                    const uint32_t at = nhit + (uint32_t)__builtin_popcountll(hb & ((1ull << lane) - 1ull));
+                    if (at < (uint32_t)a.row_slots) slots[at] = (cw << 16) | sc;
+                }
+                if (a.hist_bins) atomicAdd(&hist[k], 1u);
+                else if (a.pwm_counts) atomicAdd((unsigned long long*)&a.pwm_counts[k], 1ull);
+            }
+            nhit += (uint32_t)__builtin_popcountll(hb);
+        });
+        if (lane == 0) a.row_sum[r] = nhit;
     }
     if (a.hist_bins) {
         __syncthreads();
@@ -365,25 +369,103 @@ __global__ __launch_bounds__(VF_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     }
 }
 
-__global__ __launch_bounds__(FILL_THREADS) void cell_histogram(FillArgs a) {
-    const int64_t ncells = a.nrows * a.row_cells;
-    for (int64_t cell = (int64_t)blockIdx.x * FILL_THREADS + threadIdx.x; cell < ncells; cell += (int64_t)gridDim.x * FILL_THREADS) {
-        const uint4 m = a.masks[cell];
-        if ((m.x | m.y | m.z | m.w) == 0u) continue;
-        const int ch = (int)(cell % a.nch);
-        const uint32_t wd[4] = {m.x, m.y, m.z, m.w};
-        for (int q = 0; q < 4; q++) {
-            uint32_t bits = wd[q];
-            while (bits) {
-                const int i = __builtin_ctz(bits);
-                bits &= bits - 1;
-                atomicAdd((unsigned long long*)&a.pwm_counts[(ch * 4 + q) * 32 + i], 1ull);
+// exclusive scan of the row counts in three small steps: per 1024 rows, over the block totals, (added back in emit_records)
+__global__ __launch_bounds__(1024) void row_scan_local(const uint32_t* __restrict__ row_sum, int64_t nrows, uint32_t* __restrict__ row_excl,
+                                                       unsigned long long* __restrict__ blk_total) {
+    __shared__ uint32_t wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 1024 + tid;
+    const uint32_t v = i < nrows ? row_sum[i] : 0u;
+    const uint32_t inc = wave_incl_scan(v, lane);
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    uint32_t wbase = 0, tot = 0;
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        if (q < wv) wbase += wsum[q];
+        tot += wsum[q];
+    }
+    if (i < nrows) row_excl[i] = wbase + inc - v;                     // < 2^32: at most 1024 rows x 65536 candidates
+    if (tid == 0) blk_total[blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(1024) void row_scan_blocks(unsigned long long* __restrict__ blk, int64_t nblk, const int64_t* __restrict__ base_in,
+                                                        int64_t* __restrict__ total_out) {
+    __shared__ unsigned long long part[1024];
+    const int tid = threadIdx.x;
+    const int64_t per = (nblk + 1023) / 1024;
+    int64_t lo = tid * per, hi = lo + per;
+    if (lo > nblk) lo = nblk;
+    if (hi > nblk) hi = nblk;
+    unsigned long long s = 0;
+    for (int64_t i = lo; i < hi; i++) s += blk[i];
+    part[tid] = s;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const unsigned long long v = tid >= d ? part[tid - d] : 0ull;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    unsigned long long run = part[tid] - s + (unsigned long long)*base_in;
+    for (int64_t i = lo; i < hi; i++) {
+        const unsigned long long v = blk[i];
+        blk[i] = run;                                                 // records before this block of rows
+        run += v;
+    }
+    if (tid == 1023) *total_out = (int64_t)(part[1023] + (unsigned long long)*base_in);
+}
+
+// staged words -> records.  One wave per row; a row that overflowed its staging slots is re-scored from its cells.
+template <int LEN, bool LDS_TAB>
+__global__ __launch_bounds__(VF_THREADS) void emit_records(FillArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    uint16_t* queue = (uint16_t*)smem + wv * QN;
+    uint32_t* ltab = smem + VF_WAVES * QN / 2;
+    const uint32_t* tb = nullptr;                                     // staged lazily: only overflowed rows need the bank
+    bool staged = !LDS_TAB;
+    if (!LDS_TAB) tb = a.tab;
+    const int64_t nwaves = (int64_t)gridDim.x * VF_WAVES;
+    // block-uniform loop bounds so that the lazy staging barrier is reached by every wave
+    for (int64_t rb = (int64_t)blockIdx.x * VF_WAVES; rb < a.nrows; rb += nwaves) {
+        const int64_t r = rb + wv;
+        const uint32_t cnt = r < a.nrows ? a.row_sum[r] : 0u;
+        const bool big = cnt > (uint32_t)a.row_slots;
+        if (__syncthreads_or(big) && !staged) {
+            tb = stage_table<LEN, LDS_TAB, VF_THREADS>(a.tab, a.KP, ltab);
+            staged = true;
+        }
+        if (cnt == 0) continue;
+        const RowGeom g = row_geom(a, r);
+        const int64_t row_at = (int64_t)a.blk_base[r >> 10] + a.row_excl[r];
+        auto put = [&](const int64_t at, const uint32_t k, const uint32_t nin, const uint16_t sc) {
+            if (at < a.cap) {
+                a.hits[at] = HitRec{k + 1, (uint32_t)(g.nrow0 + nin + a.n0 + 1), (uint32_t)(g.l + 1)};
+                a.hit_scores[at] = sc;
             }
+        };
+        if (!big) {
+            const uint32_t* slots = a.staging + (size_t)r * a.row_slots;
+            for (uint32_t j = lane; j < cnt; j += 64) {
+                const uint32_t e = slots[j];
+                const uint32_t idx = e >> 23, q = (e >> 21) & 3u, i = (e >> 16) & 31u;
+                const uint32_t nin = a.div_nch.div(idx);
+                put(row_at + j, ((idx - nin * a.nch) * 4 + q) * 32 + i, nin, (uint16_t)e);
+            }
+        } else {
+            uint32_t nhit = 0;
+            for_row_candidates(g, queue, [&](const uint32_t cw, const bool live) {
+                uint32_t k, nin;
+                uint16_t sc;
+                const bool hit = score_candidate<LEN, LDS_TAB>(a, g, tb, cw, live, k, nin, sc);
+                const unsigned long long hb = __ballot(hit);
+                if (hit) put(row_at + nhit + (uint32_t)__builtin_popcountll(hb & ((1ull << lane) - 1ull)), k, nin, sc);
+                nhit += (uint32_t)__builtin_popcountll(hb);
+            });
         }
     }
 }
 
-// ---- launchers -------------------------------------------------------------------------------------------
 template <int T, int PG>
 static hipError_t launch_cand_tp(const CandArgs& a, hipStream_t st) {
     const int64_t per_block = (int64_t)4 * a.d.spw;
@@ -408,44 +490,63 @@ hipError_t launch_cand(const CandArgs& a, hipStream_t st) {
     }
 }
 
-static unsigned fill_grid2(int64_t nrows) { return (unsigned)std::min<int64_t>((nrows + VF_WAVES - 1) / VF_WAVES, 256 * 4); }
+int stage_row_reads(int nch) { return std::max(1, 256 / nch); }
 
 template <int LEN>
-static hipError_t launch_verify_len(const FillArgs& a, hipStream_t st) {
-    const size_t base = (size_t)VF_WAVES * QN * 4;
+static hipError_t launch_stage_len(const FillArgs& a, bool stage, hipStream_t st) {
+    if ((int64_t)a.rpr * a.nch > ROW_CELLS_MAX || a.nrows >= (int64_t)1 << 31) return hipErrorInvalidValue;
+    const size_t base = (size_t)VF_WAVES * QN * 2 + (size_t)a.hist_bins * 4;
     const size_t tab_bytes = (size_t)LEN * 5 * a.KP * 4;
-    if (base + tab_bytes <= 64 * 1024)
-        hipLaunchKernelGGL((fill_verify_row_sums<LEN, true>), dim3(fill_grid2(a.nrows)), dim3(VF_THREADS), base + tab_bytes, st, a);
-    else
-        hipLaunchKernelGGL((fill_verify_row_sums<LEN, false>), dim3(fill_grid2(a.nrows)), dim3(VF_THREADS), base, st, a);
-    return hipGetLastError();
-}
-template <int LEN>
-static hipError_t launch_records_len(const FillArgs& a, hipStream_t st) {
-    const size_t base = (size_t)VF_WAVES * QN * 4 + (size_t)a.hist_bins * 4;
-    const size_t tab_bytes = (size_t)LEN * 5 * a.KP * 4;
-    if (base + tab_bytes <= 64 * 1024)
-        hipLaunchKernelGGL((fill_records_plain<LEN, true>), dim3(fill_grid2(a.nrows)), dim3(VF_THREADS), base + tab_bytes, st, a);
-    else
-        hipLaunchKernelGGL((fill_records_plain<LEN, false>), dim3(fill_grid2(a.nrows)), dim3(VF_THREADS), base, st, a);
-    return hipGetLastError();
-}
-
-#define MOTIFS_LEN_SWITCH(fn)                           \
-    switch (a.lenp) {                                   \
-        case 8: return fn<8>(a, st);                    \
-        case 12: return fn<12>(a, st);                  \
-        case 16: return fn<16>(a, st);                  \
-        case 20: return fn<20>(a, st);                  \
-        case 24: return fn<24>(a, st);                  \
-        case 32: return fn<32>(a, st);                  \
-        default: return hipErrorInvalidValue;           \
+    const bool lds_tab = base + tab_bytes <= 64 * 1024;
+    const unsigned grid = (unsigned)std::min<int64_t>((a.nrows + VF_WAVES - 1) / VF_WAVES, 256 * 4);
+    const size_t lds = lds_tab ? base + tab_bytes : base;
+    if (lds_tab) {
+        if (stage) hipLaunchKernelGGL((stage_hits<LEN, true, true>), dim3(grid), dim3(VF_THREADS), lds, st, a);
+        else hipLaunchKernelGGL((stage_hits<LEN, true, false>), dim3(grid), dim3(VF_THREADS), lds, st, a);
+    } else {
+        if (stage) hipLaunchKernelGGL((stage_hits<LEN, false, true>), dim3(grid), dim3(VF_THREADS), lds, st, a);
+        else hipLaunchKernelGGL((stage_hits<LEN, false, false>), dim3(grid), dim3(VF_THREADS), lds, st, a);
     }
-hipError_t launch_verify_row_sums(const FillArgs& a, hipStream_t st) { MOTIFS_LEN_SWITCH(launch_verify_len) }
-hipError_t launch_fill_records_plain(const FillArgs& a, hipStream_t st) { MOTIFS_LEN_SWITCH(launch_records_len) }
-hipError_t launch_cell_histogram(const FillArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(cell_histogram, dim3(256 * 8), dim3(FILL_THREADS), 0, st, a);
     return hipGetLastError();
+}
+template <int LEN>
+static hipError_t launch_emit_len(const FillArgs& a, hipStream_t st) {
+    const size_t base = (size_t)VF_WAVES * QN * 2;
+    const size_t tab_bytes = (size_t)LEN * 5 * a.KP * 4;
+    const unsigned grid = (unsigned)std::min<int64_t>((a.nrows + VF_WAVES - 1) / VF_WAVES, 256 * 8);
+    if (base + tab_bytes <= 64 * 1024)
+        hipLaunchKernelGGL((emit_records<LEN, true>), dim3(grid), dim3(VF_THREADS), base + tab_bytes, st, a);
+    else
+        hipLaunchKernelGGL((emit_records<LEN, false>), dim3(grid), dim3(VF_THREADS), base, st, a);
+    return hipGetLastError();
+}
+
+#define MOTIFS_LEN_SWITCH(lenp, CALL)       \
+    switch (lenp) {                         \
+        case 8: return CALL(8);             \
+        case 12: return CALL(12);           \
+        case 16: return CALL(16);           \
+        case 20: return CALL(20);           \
+        case 24: return CALL(24);           \
+        case 32: return CALL(32);           \
+        default: return hipErrorInvalidValue; \
+    }
+
+hipError_t launch_stage_hits(const FillArgs& a, bool stage, hipStream_t st) {
+#define CALL(LEN) launch_stage_len<LEN>(a, stage, st)
+    MOTIFS_LEN_SWITCH(a.lenp, CALL)
+#undef CALL
+}
+hipError_t launch_row_scan(const FillArgs& a, hipStream_t st) {
+    const int64_t nblk = (a.nrows + 1023) / 1024;
+    hipLaunchKernelGGL(row_scan_local, dim3((unsigned)nblk), dim3(1024), 0, st, a.row_sum, a.nrows, a.row_excl, a.blk_base);
+    hipLaunchKernelGGL(row_scan_blocks, dim3(1), dim3(1024), 0, st, a.blk_base, nblk, a.base_in, a.total);
+    return hipGetLastError();
+}
+hipError_t launch_emit_records(const FillArgs& a, hipStream_t st) {
+#define CALL(LEN) launch_emit_len<LEN>(a, st)
+    MOTIFS_LEN_SWITCH(a.lenp, CALL)
+#undef CALL
 }
 
 }  // namespace motifs

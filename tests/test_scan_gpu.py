@@ -225,3 +225,49 @@ def test_cfg5_shape_small_n(torch_cuda, ctx, pkg):
         assert len(oh) > 1000
         assert np.array_equal(h, oh) and np.array_equal(s, os_)
         assert np.array_equal(counts, np.bincount(oh[:, 0] - 1, minlength=K))
+
+
+def test_dense_rows_take_the_rescoring_path(torch_cuda, ctx, pkg):
+    """All-positive PWMs: every window of every PWM is a hit, far more per row of cells than the staging
+    slots hold, so records come from the slow path of emit_records; mixed with sparse PWMs in one bank."""
+    sy = pkg.synth
+    N, L, K = 90, 50, 150
+    codes = sy.gen_codes(N, L, 77, n_plant=2, k=8)
+    codes[3, 10] = 4
+    pwms, lens = sy.gen_pwm_bank(K, 78, len_lo=6, len_hi=12, alpha=0.4)
+    rng = np.random.default_rng(5)
+    for k in range(0, K, 2):                     # every other PWM: strictly positive log-odds
+        pwms[k] = np.abs(pwms[k]) + rng.uniform(0.01, 0.5, size=pwms[k].shape).astype(pwms[k].dtype)
+    bank = sy.pad_bank(pwms, lens)
+    for rc in (False, True):
+        h, s, counts = dev_scan_hits(torch_cuda, ctx, pkg, bank, lens, codes, rc, 40, want_counts=True)
+        oh, os_ = oracle_hits(pkg, bank, lens, codes, rc, 40)
+        assert len(oh) > N * 20 * (K // 2)
+        assert np.array_equal(h, oh) and np.array_equal(s, os_)
+        assert np.array_equal(counts, np.bincount(oh[:, 0] - 1, minlength=K))
+
+
+def test_short_buffer_reports_needed_count(torch_cuda, ctx, pkg):
+    sy = pkg.synth
+    lib = pkg._lib
+    N, L, K = 64, 60, 40
+    codes = sy.gen_codes(N, L, 9, n_plant=2, k=8)
+    pwms, lens = sy.gen_pwm_bank(K, 10, len_lo=8, len_hi=8, alpha=0.5)
+    bank = sy.pad_bank(pwms, lens)
+    h, s = dev_scan_hits(torch_cuda, ctx, pkg, bank, lens, codes, False, 16)
+    n = len(h)
+    assert n > 10
+    raw = torch_cuda.from_numpy(codes).cuda()
+    dcodes = torch_cuda.zeros(lib.Context.codes_bytes(N, L), dtype=torch_cuda.uint8, device="cuda")
+    ctx.encode_dev(raw.data_ptr(), lib.DATA_CODES_U8, N, L, dcodes.data_ptr())
+    cap = n // 2
+    hits = torch_cuda.zeros((n, 3), dtype=torch_cuda.int32, device="cuda")
+    sc = torch_cuda.zeros(n, dtype=torch_cuda.int16, device="cuda")
+    with pytest.raises(lib.MotifsError) as ei:
+        ctx.pwm_scan_hits_dev(bank, lens, dcodes.data_ptr(), N, L, False, hits.data_ptr(), sc.data_ptr(), cap, batch=16)
+    assert ei.value.code == lib.ERR_BUFFER_TOO_SMALL
+    needed = ctx.pwm_scan_hits_dev(bank, lens, dcodes.data_ptr(), N, L, False, hits.data_ptr(), sc.data_ptr(), cap, batch=16,
+                                   allow_small=True)
+    assert needed == n
+    ctx.synchronize()
+    assert not hits[cap:].any() and not sc[cap:].any(), "records past cap were written"
