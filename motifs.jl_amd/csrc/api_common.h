@@ -34,6 +34,14 @@ struct DevBuf {
     }
 };
 
+// A PWM bank packed for the device, kept between calls: scanning the same bank again (the other strand's
+// twin, the next shard, the second call of the count-then-fill protocol) skips packing and upload.
+struct BankSlot {
+    std::vector<uint8_t> key;   // the caller's bank bytes + shape; empty = nothing cached
+    DevBuf tab, lim, afrag, cinit;
+    int KP = 0, nch = 0, lenp = 0, minlen = 0, maxlen_true = 0, ntiles = 0;
+};
+
 enum KernelSlot {
     KS_ENCODE = 0,
     KS_SCAN_DENSE = 1,
@@ -65,6 +73,7 @@ struct motifs_ctx {
     // scan workspaces
     motifs::DevBuf tab, lim, cnt, off, tilesum, small, codes, hits_tmp, scores_tmp, pwmcnt, data_tmp, afrag, cinit;
     motifs::DevBuf staging, rowx;   // matrix-core scan: staged hit words, per-row offsets
+    motifs::BankSlot bank_slot[2];  // [rc]
     void* pinned = nullptr;  // small pinned host block for totals / flags
 };
 

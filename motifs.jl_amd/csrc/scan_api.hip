@@ -176,19 +176,54 @@ static int upload_bank(motifs_ctx* c, const PackedBank& bank) {
 
 using namespace motifs;
 
-// Hit records through the matrix cores: candidates (scan_cand_kernel) -> exact verification, staged hits and
-// row counts (stage_hits) -> scan -> records (emit_records); no host round trip in between.  The bank has already been uploaded (tab, lim).
-static int scan_hits_mfma(motifs_ctx* c, const PackedBank& bank, const int64_t* lens, int K, const uint8_t* codes_dev, int64_t N,
-                          int L, int Lout, int64_t n0, int batch, motifs_hit* hits_dev, uint16_t* hit_scores_dev, int64_t cap,
-                          int64_t* n_out, int64_t* per_pwm_counts_dev) {
+// The bank of this call on the device, from the context's cache when the caller passes the same bank again.
+static int cached_bank(motifs_ctx* c, const uint16_t* pwms, const int64_t* lens, int K, int maxlen, int rc, int L, BankSlot** out) {
+    BankSlot& bs = c->bank_slot[rc ? 1 : 0];
+    const size_t nb_p = (size_t)K * 4 * maxlen * 2, nb_l = (size_t)K * 8;
+    const int32_t shape[4] = {K, maxlen, rc, L};
+    std::vector<uint8_t> key(sizeof(shape) + nb_p + nb_l);
+    if (K > 0 && maxlen > 0 && pwms && lens) {
+        memcpy(key.data(), shape, sizeof(shape));
+        memcpy(key.data() + sizeof(shape), pwms, nb_p);
+        memcpy(key.data() + sizeof(shape) + nb_p, lens, nb_l);
+        if (key == bs.key) {
+            *out = &bs;
+            return MOTIFS_OK;
+        }
+    }
+    bs.key.clear();
+    PackedBank bank;
+    const int rcode = pack_bank(pwms, lens, K, maxlen, rc, L, bank);   // validates the arguments
+    if (rcode) return rcode;
     MfmaBank mb;
     pack_mfma(bank, lens, K, mb);
-    MOTIFS_HIP_CHECK(c->afrag.reserve(mb.afrag.size() * 4));
-    MOTIFS_HIP_CHECK(c->cinit.reserve(mb.cinit.size() * 4));
-    MOTIFS_HIP_CHECK(hipMemcpyAsync(c->afrag.p, mb.afrag.data(), mb.afrag.size() * 4, hipMemcpyHostToDevice, c->stream));
-    MOTIFS_HIP_CHECK(hipMemcpyAsync(c->cinit.p, mb.cinit.data(), mb.cinit.size() * 4, hipMemcpyHostToDevice, c->stream));
-    MOTIFS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    MOTIFS_HIP_CHECK(hipSetDevice(c->device));
+    MOTIFS_HIP_CHECK(bs.tab.reserve(bank.tab.size() * 4));
+    MOTIFS_HIP_CHECK(bs.lim.reserve(bank.lim.size() * 4));
+    MOTIFS_HIP_CHECK(bs.afrag.reserve(mb.afrag.size() * 4));
+    MOTIFS_HIP_CHECK(bs.cinit.reserve(mb.cinit.size() * 4));
+    // a scan that still reads the slot's old contents may be in flight on the stream: the copies queue behind it
+    MOTIFS_HIP_CHECK(hipMemcpyAsync(bs.tab.p, bank.tab.data(), bank.tab.size() * 4, hipMemcpyHostToDevice, c->stream));
+    MOTIFS_HIP_CHECK(hipMemcpyAsync(bs.lim.p, bank.lim.data(), bank.lim.size() * 4, hipMemcpyHostToDevice, c->stream));
+    MOTIFS_HIP_CHECK(hipMemcpyAsync(bs.afrag.p, mb.afrag.data(), mb.afrag.size() * 4, hipMemcpyHostToDevice, c->stream));
+    MOTIFS_HIP_CHECK(hipMemcpyAsync(bs.cinit.p, mb.cinit.data(), mb.cinit.size() * 4, hipMemcpyHostToDevice, c->stream));
+    MOTIFS_HIP_CHECK(hipStreamSynchronize(c->stream));   // the host vectors die with this frame
+    bs.KP = bank.KP;
+    bs.nch = bank.nch;
+    bs.lenp = bank.lenp;
+    bs.minlen = bank.minlen;
+    bs.maxlen_true = bank.maxlen_true;
+    bs.ntiles = mb.ntiles;
+    bs.key.swap(key);
+    *out = &bs;
+    return MOTIFS_OK;
+}
 
+// Hit records through the matrix cores: candidates (scan_cand_kernel) -> exact verification, staged hits and
+// row counts (stage_hits) -> scan -> records (emit_records); no host round trip in between.  The bank has already been uploaded (tab, lim).
+static int scan_hits_mfma(motifs_ctx* c, const BankSlot& bank, int K, const uint8_t* codes_dev, int64_t N, int L, int Lout, int64_t n0,
+                          int batch, motifs_hit* hits_dev, uint16_t* hit_scores_dev, int64_t cap, int64_t* n_out,
+                          int64_t* per_pwm_counts_dev) {
     const bool emit = hits_dev != nullptr && cap > 0;
     const int rpr = stage_row_reads(bank.nch);                       // reads per row of cells
     const int parts = (batch + rpr - 1) / rpr;
@@ -219,12 +254,12 @@ static int scan_hits_mfma(motifs_ctx* c, const PackedBank& bank, const int64_t* 
         const int64_t ns = std::min<int64_t>(sb, N - s0);
         const int64_t nb = (ns + batch - 1) / batch;
         CandArgs a{};
-        a.afrag = (const uint4*)c->afrag.p;
-        a.cinit = (const float*)c->cinit.p;
+        a.afrag = (const uint4*)bank.afrag.p;
+        a.cinit = (const float*)bank.cinit.p;
         a.codes = codes_dev + (size_t)s0 * motifs_codes_pitch(L);
         a.cells = (uint32_t*)c->cnt.p;
         a.lenp = bank.lenp;
-        a.ntiles = mb.ntiles;
+        a.ntiles = bank.ntiles;
         a.d.N = ns;
         a.d.L = L;
         a.d.pitch = motifs_codes_pitch(L);
@@ -234,7 +269,7 @@ static int scan_hits_mfma(motifs_ctx* c, const PackedBank& bank, const int64_t* 
         a.d.ohlen = ntile_w * 32 + bank.lenp;
         a.d.used_tiles = (K + 31) / 32;
         {
-            int64_t spw = ns * (mb.ntiles / PG) / 16384;
+            int64_t spw = ns * (bank.ntiles / PG) / 16384;
             a.d.spw = (int)std::max<int64_t>(1, std::min<int64_t>(spw, 16));
         }
         FillArgs f{};
@@ -250,7 +285,7 @@ static int scan_hits_mfma(motifs_ctx* c, const PackedBank& bank, const int64_t* 
         f.base_in = totals + (launch_no & 1);
         f.total = totals + ((launch_no + 1) & 1);
         f.cap = cap;
-        f.tab = (const uint32_t*)c->tab.p;
+        f.tab = (const uint32_t*)bank.tab.p;
         f.codes = a.codes;
         f.hits = (HitRec*)hits_dev;
         f.hit_scores = hit_scores_dev;
@@ -264,7 +299,7 @@ static int scan_hits_mfma(motifs_ctx* c, const PackedBank& bank, const int64_t* 
         f.KP = bank.KP;
         f.pitch = a.d.pitch;
         f.hist_bins = (per_pwm_counts_dev && 2 * bank.KP <= FILL_HIST_MAX) ? 2 * bank.KP : 0;
-        f.lim = (const int32_t*)c->lim.p;
+        f.lim = (const int32_t*)bank.lim.p;
         f.N = ns;
         f.K = K;
         f.lim_min = L - bank.maxlen_true;
@@ -353,6 +388,8 @@ void motifs_ctx_destroy(motifs_ctx* c) {
     for (DevBuf* b : {&c->tab, &c->lim, &c->cnt, &c->off, &c->tilesum, &c->small, &c->codes, &c->hits_tmp,
                       &c->scores_tmp, &c->pwmcnt, &c->data_tmp, &c->afrag, &c->cinit, &c->staging, &c->rowx})
         b->release();
+    for (BankSlot& bs : c->bank_slot)
+        for (DevBuf* b : {&bs.tab, &bs.lim, &bs.afrag, &bs.cinit}) b->release();
     if (c->pinned) (void)hipHostFree(c->pinned);
     resolve_timing(c);
     for (hipEvent_t e : c->free_events) (void)hipEventDestroy(e);
@@ -480,6 +517,16 @@ int motifs_pwm_scan_hits_dev(motifs_ctx* c, const uint16_t* pwms_fp16, const int
         return MOTIFS_ERR_INVALID;
     }
     *n_out = 0;
+    if (!c->scan_valu) {
+        BankSlot* bs = nullptr;
+        const int rcode = cached_bank(c, pwms_fp16, lens, K, maxlen, rc, L, &bs);
+        if (rcode) return rcode;
+        MOTIFS_HIP_CHECK(hipSetDevice(c->device));
+        if (per_pwm_counts_dev) MOTIFS_HIP_CHECK(hipMemsetAsync(per_pwm_counts_dev, 0, (size_t)K * 8, c->stream));
+        const int Lout = L - bs->minlen + 1;
+        if (N == 0 || Lout <= 0) return MOTIFS_OK;
+        return scan_hits_mfma(c, *bs, K, codes_dev, N, L, Lout, n0, batch, hits_dev, hit_scores_dev, cap, n_out, per_pwm_counts_dev);
+    }
     PackedBank bank;
     int rcode = pack_bank(pwms_fp16, lens, K, maxlen, rc, L, bank);
     if (rcode) return rcode;
@@ -489,10 +536,6 @@ int motifs_pwm_scan_hits_dev(motifs_ctx* c, const uint16_t* pwms_fp16, const int
     if (N == 0 || Lout <= 0) return MOTIFS_OK;
     rcode = upload_bank(c, bank);
     if (rcode) return rcode;
-
-    if (!c->scan_valu)
-        return scan_hits_mfma(c, bank, lens, K, codes_dev, N, L, Lout, n0, batch, hits_dev, hit_scores_dev, cap, n_out,
-                              per_pwm_counts_dev);
 
     const int LoutP = scan_lout_padded(Lout, bank.lenp);
     // super-batch: as many ordering batches as fit an ~8 GiB mask workspace
