@@ -27,6 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+MFMA_F16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak (no sparsity)
 
 
 def parse():
@@ -198,19 +199,26 @@ def main():
 
     bases = float(N) * L * world
     value = bases * args.steps / dt
-    # One strand pass = scan_kernel<12,MASK> (all the arithmetic: every window of every PWM, `> 0`
-    # test, 128-bit hit masks) -> row sums + scan -> fill_records (records + scores, reference order).
-    # Algorithmic bytes per strand pass, fused-hits contract: N*L codes in, 14 B per hit
-    # out, K counters.  The dominant kernel is the MASK scan; it is bound by packed fp16 adds
-    # (v_pk_add_f16 issues at 4 cycles per wave on gfx950, measured: tools/ubench/valu_rate.hip).
+    # One strand pass = scan_cand_kernel (the GEMM of the PWM bank with the one-hot windows on the matrix
+    # cores: every window of every PWM, thresholded at -eps_k into 128-bit candidate cells) -> stage_hits
+    # (exact binary16 re-scoring of the ~1 % candidates, staged hit words, row counts) -> row scan ->
+    # emit_records ((m, n, l) + score records in the reference's order).
+    # Dominant kernel: scan_cand_kernel, bound by the matrix cores.  Algorithmic flops per launch (SURVEY
+    # 8d, GEMM form): 2 * 4*len * K flop per window, N * (L - len + 1) windows per strand launch.
+    # The whole pass is also quoted against HBM on the fused-hits contract (N*L codes in, 14 B per hit out).
     hits_per_pass = nhits / 2.0
     n_pass = max(kms["count"][1], 1)
-    mask_ms = kms["count"][0] / n_pass
+    cand_ms = kms["count"][0] / n_pass
     pass_ms = (kms["count"][0] + kms["offsets"][0] + kms["fill"][0]) / n_pass
     alg_bytes = N * L + hits_per_pass * 14 + K * 8
-    achieved = alg_bytes / (pass_ms * 1e-3) / 1e9
-    adds = float(N) * Lout * PL * K                      # useful sequential fp16 adds per strand pass
-    valu_peak = 256 * 4 * 128 / 4.0 * 2.4e9              # adds/s: 1024 SIMDs x 128 adds per 4-cycle v_pk_add_f16
+    pass_gbs = alg_bytes / (pass_ms * 1e-3) / 1e9
+    cand_flops = 2.0 * 4 * PL * K * float(N) * Lout
+    cand_tflops = cand_flops / (cand_ms * 1e-3) / 1e12
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_scan_hbm_traffic.json")       # separate --pmc passes (tools/pmc_scan.sh)
+    if os.path.exists(tpath) and (N, L, K, PL) == (100_000, 200, 200, 12):
+        with open(tpath) as fh:
+            traffic = json.load(fh).get("scan_cand_kernel", {}).get("hbm_bytes_per_launch")
     out = {
         "metric": "bases scanned/sec",
         "value": value,
@@ -231,22 +239,22 @@ def main():
             "parallelism": f"sequence shards x{world}, all-reduce of the {K}-entry hit histogram only",
         },
         "roofline": {
-            "kernel": "scan_kernel<12,MASK> + fill_row_sums/scan + fill_records (one strand pass)",
-            "bound": "hbm",
-            "achieved": achieved,
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None,
-            "avg_launch_ms": pass_ms,
-            "dominant_kernel_ms": mask_ms,
-            "note": "fused-hits contract (no dense score tensor): the pass is bound by fp16 adds, not HBM; "
-                    "see valu_roofline for the dominant kernel and dense_kernel for the a17 dense-score contract",
+            "kernel": "scan_cand_kernel<3,4> (v_mfma_f32_32x32x16_f16 candidate filter, one strand of the shard per launch)",
+            "bound": "mfma",
+            "achieved": cand_tflops,
+            "peak": MFMA_F16_PEAK_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": cand_tflops / MFMA_F16_PEAK_TFLOPS,
+            "traffic": traffic,
+            "flops_per_launch": cand_flops,
+            "avg_launch_ms": cand_ms,
         },
-        "valu_roofline": {
-            "kernel": "scan_kernel<12,MASK>", "bound": "valu", "achieved": adds / (mask_ms * 1e-3) / 1e12,
-            "peak": valu_peak / 1e12, "unit": "T fp16-add/s", "frac": adds / (mask_ms * 1e-3) / valu_peak,
-            "avg_launch_ms": mask_ms,
+        "pass_hbm": {
+            "kernels": "scan_cand_kernel + stage_hits + row scan + emit_records (one strand pass)",
+            "bound": "hbm", "achieved": pass_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": pass_gbs / HBM_PEAK_GBS,
+            "algorithmic_bytes": alg_bytes, "avg_pass_ms": pass_ms,
+            "note": "fused-hits contract (N*L codes in, 14 B per hit out, no dense score tensor): the pass is bound "
+                    "by the matrix cores and the exact re-scoring, not by HBM; dense_kernel is the a17 dense-score contract",
         },
         "dense_kernel": {
             "kernel": "scan_kernel<12,DENSE> (a17 greedy_search! drop-in, writes (K,nb,L-len+1) fp16)",
@@ -254,8 +262,8 @@ def main():
             "frac": dense_gbs / HBM_PEAK_GBS, "avg_launch_ms": dense_ms / dense_n, "seqs_per_launch": nb,
             "bases_per_s_one_strand": nb * L / (dense_ms / dense_n * 1e-3),
         },
-        "kernel_ms_per_step": {"mask_scan": kms["count"][0] / args.steps, "row_sums_scan": kms["offsets"][0] / args.steps,
-                               "fill_records": kms["fill"][0] / args.steps},
+        "kernel_ms_per_step": {"scan_cand": kms["count"][0] / args.steps, "stage_hits_row_scan": kms["offsets"][0] / args.steps,
+                               "emit_records": kms["fill"][0] / args.steps},
     }
 
     if train is not None:
