@@ -58,10 +58,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU: the product path has no CPU fallback"
+    # MOTIFS_BENCH_REHEARSE=1: every rank on device 0 over gloo — a rehearsal of the N > 1 control flow on a
+    # one-GPU box (numbers meaningless); the real N > 1 run is one rank per GPU over RCCL.
+    rehearse = os.environ.get("MOTIFS_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from _pkg import load_pkg
@@ -83,7 +91,7 @@ def main():
     raw = torch.from_numpy(codes).cuda()
     dcodes = torch.zeros(lib.Context.codes_bytes(N, L), dtype=torch.uint8, device="cuda")
     ctx.encode_dev(raw.data_ptr(), lib.DATA_CODES_U8, N, L, dcodes.data_ptr())
-    counts = [torch.zeros(K, dtype=torch.int64, device="cuda") for _ in range(2)]
+    counts = torch.zeros((2, K), dtype=torch.int64, device="cuda")      # per-strand hit histograms
     # size the record buffers once (count-only pass), with head-room
     need = [ctx.pwm_scan_hits_dev(bank, lens, dcodes.data_ptr(), N, L, rc, None, None, 0, n0=rank * N) for rc in (0, 1)]
     cap = int(max(need) * 1.05) + 1024
@@ -96,9 +104,8 @@ def main():
         for rc in (0, 1):
             tot += ctx.pwm_scan_hits_dev(bank, lens, dcodes.data_ptr(), N, L, rc, hits[rc].data_ptr(), hsc[rc].data_ptr(),
                                          cap, n0=rank * N, counts_ptr=counts[rc].data_ptr())
-        if world > 1:  # the one real exchange of the scan: K int64 hit counts
-            for rc in (0, 1):
-                dist.all_reduce(counts[rc])
+        if world > 1:  # the one real exchange of the scan: the K int64 hit counts of both strands
+            dist.all_reduce(counts)
         return tot
 
     for _ in range(args.warmup):

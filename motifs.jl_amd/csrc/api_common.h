@@ -38,8 +38,9 @@ struct DevBuf {
 // twin, the next shard, the second call of the count-then-fill protocol) skips packing and upload.
 struct BankSlot {
     std::vector<uint8_t> key;   // the caller's bank bytes + shape; empty = nothing cached
-    DevBuf tab, lim, afrag, cinit;
-    int KP = 0, nch = 0, lenp = 0, minlen = 0, maxlen_true = 0, ntiles = 0;
+    DevBuf tab, lim, afrag, cinit, tabk;
+    int tabk_stride = 0;
+    int KP = 0, nch = 0, lenp = 0, minlen = 0, maxlen_true = 0, ntiles = 0, uniform_eps = 0;
 };
 
 enum KernelSlot {

@@ -102,7 +102,18 @@ struct MfmaBank {
     std::vector<uint32_t> afrag;   // [tiles][T][64][4]
     std::vector<float> cinit;      // [tiles][2][16]
     int ntiles = 0, T = 0;
+    int uniform_eps = 0;           // afrag scaled by a power of two so that the slack is the constant 4.0 for every PWM
 };
+static uint16_t f2h_exact_scaled(uint16_t h, int e) {   // h * 2^e for a finite binary16 h; the caller guarantees exactness
+    if ((h & 0x7fffu) == 0) return h;
+    const float f = std::ldexp(h2f_host(h), e);
+    // exact conversion: |f| is a binary16 value times a power of two inside the normal range
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u, ex = (x >> 23) & 0xffu, man = x & 0x7fffffu;
+    return (uint16_t)(sign | ((ex - 112) << 10) | (man >> 13));
+}
+
 static void pack_mfma(const PackedBank& bank, const int64_t* lens, int K, MfmaBank& out) {
     const int T = bank.lenp / 4, ntiles = bank.nch * 4;
     out.T = T;
@@ -113,6 +124,40 @@ static void pack_mfma(const PackedBank& bank, const int64_t* lens, int K, MfmaBa
         const uint32_t cell = bank.tab[(size_t)(ind * 4 + a) * bank.KP + (k >> 1)];
         return (uint16_t)((k & 1) ? cell >> 16 : cell);
     };
+    // |s - S| <= sum over the adds of half an ulp of the running sum.  After i positions the running sum
+    // is at most P_i = sum_{j<=i} max_a |w_j| (times (1 + 2^-11)^i), so the i-th add rounds by at most
+    // 2^-11 P_i, or 2^-25 in the subnormal range; 1.02 covers the compounding.
+    std::vector<float> eps(K);
+    float eps_max = 0.f, wmax = 0.f, wmin_nz = INFINITY;
+    for (int k = 0; k < K; k++) {
+        double A = 0, E = 0;
+        const int len = (int)lens[k];
+        for (int ind = 0; ind < len; ind++) {
+            double mx = 0;
+            for (int a = 0; a < 4; a++) {
+                const double w = std::fabs(h2f_host(wbits(k, a, ind)));
+                mx = std::max(mx, w);
+                if (w > 0) wmin_nz = std::min(wmin_nz, (float)w);
+            }
+            A += mx;
+            wmax = std::max(wmax, (float)mx);
+            if (ind > 0) E += A;                          // the first add (0 + w) is exact
+        }
+        eps[k] = (float)(1.02 * std::ldexp(E, -11) + std::ldexp((double)len, -24) + std::ldexp(A, -20));
+        if (A * 1.02 >= 60000.0) eps[k] = INFINITY;      // a partial sum may overflow binary16: keep every window
+        eps_max = std::max(eps_max, eps[k]);
+    }
+    // One slack for all: scale the bank by 2^e (exact in binary16) so that eps_max * 2^e <= 4.0, the MFMA's
+    // inline-constant C.  The test S * 2^e + 4 > 0 is S > -4 / 2^e with 4 / 2^e >= eps_k for every k.
+    int e = 0;
+    bool uniform = std::isfinite(eps_max) && eps_max > 0.f && eps_max <= 4.0f;
+    if (uniform) {
+        e = (int)std::floor(std::log2(4.0 / eps_max));
+        e = std::min(e, 8);
+        // scaled weights must stay normal binary16 numbers (no overflow, no bits lost at the bottom)
+        if (wmax * std::ldexp(1.0f, e) >= 32768.0f || (std::isfinite(wmin_nz) && wmin_nz < 6.2e-5f)) uniform = false;
+    }
+    out.uniform_eps = uniform ? 1 : 0;
     for (int tile = 0; tile < ntiles; tile++) {
         for (int t = 0; t < T; t++)
             for (int lane = 0; lane < 64; lane++) {
@@ -123,27 +168,17 @@ static void pack_mfma(const PackedBank& bank, const int64_t* lens, int K, MfmaBa
                 for (int j = 0; j < 8; j++) {
                     const int kk = 16 * t + 8 * hh + j, ind = kk >> 2, a = kk & 3;
                     hv[j] = (k < K && ind < (int)lens[k]) ? wbits(k, a, ind) : (uint16_t)0;
+                    if (uniform) {
+                        if (k < K) hv[j] = f2h_exact_scaled(hv[j], e);
+                        else if (ind == 0) hv[j] = 0xec00u;   // -4096: a row without a PWM never becomes a candidate
+                    }
                 }
                 uint32_t* dst = &out.afrag[(((size_t)tile * T + t) * 64 + lane) * 4];
                 for (int u = 0; u < 4; u++) dst[u] = (uint32_t)hv[2 * u] | ((uint32_t)hv[2 * u + 1] << 16);
             }
         for (int q = 0; q < 32; q++) {
             const int k = tile * 32 + q;
-            if (k >= K) continue;
-            // |s - S| <= sum over the adds of half an ulp of the running sum.  After i positions the running sum
-            // is at most P_i = sum_{j<=i} max_a |w_j| (times (1 + 2^-11)^i), so the i-th add rounds by at most
-            // 2^-11 P_i, or 2^-25 in the subnormal range; 1.02 covers the compounding.
-            double A = 0, E = 0;
-            const int len = (int)lens[k];
-            for (int ind = 0; ind < len; ind++) {
-                double mx = 0;
-                for (int a = 0; a < 4; a++) mx = std::max(mx, (double)std::fabs(h2f_host(wbits(k, a, ind))));
-                A += mx;
-                if (ind > 0) E += A;                          // the first add (0 + w) is exact
-            }
-            float eps = (float)(1.02 * std::ldexp(E, -11) + std::ldexp((double)len, -24) + std::ldexp(A, -20));
-            if (A * 1.02 >= 60000.0) eps = INFINITY;          // a partial sum may overflow binary16: keep every window
-            out.cinit[((size_t)tile * 2 + (q >> 4)) * 16 + (q & 15)] = eps;
+            if (k < K) out.cinit[((size_t)tile * 2 + (q >> 4)) * 16 + (q & 15)] = eps[k];
         }
     }
 }
@@ -207,6 +242,18 @@ static int cached_bank(motifs_ctx* c, const uint16_t* pwms, const int64_t* lens,
     MOTIFS_HIP_CHECK(hipMemcpyAsync(bs.lim.p, bank.lim.data(), bank.lim.size() * 4, hipMemcpyHostToDevice, c->stream));
     MOTIFS_HIP_CHECK(hipMemcpyAsync(bs.afrag.p, mb.afrag.data(), mb.afrag.size() * 4, hipMemcpyHostToDevice, c->stream));
     MOTIFS_HIP_CHECK(hipMemcpyAsync(bs.cinit.p, mb.cinit.data(), mb.cinit.size() * 4, hipMemcpyHostToDevice, c->stream));
+    // re-scoring table for stage_hits: [k][ind][5] halves, rows padded to an odd dword count
+    const int rs_dw = ((bank.lenp * 5 + 1) / 2) | 1;
+    bs.tabk_stride = rs_dw * 2;
+    std::vector<uint16_t> tabk((size_t)K * bs.tabk_stride + 2, 0);
+    for (int k = 0; k < K; k++)
+        for (int ind = 0; ind < (int)lens[k]; ind++)
+            for (int b = 0; b < 4; b++) {
+                const uint32_t cell = bank.tab[(size_t)(ind * 4 + b) * bank.KP + (k >> 1)];
+                tabk[(size_t)k * bs.tabk_stride + ind * 5 + b] = (uint16_t)((k & 1) ? cell >> 16 : cell);
+            }
+    MOTIFS_HIP_CHECK(bs.tabk.reserve(tabk.size() * 2));
+    MOTIFS_HIP_CHECK(hipMemcpyAsync(bs.tabk.p, tabk.data(), tabk.size() * 2, hipMemcpyHostToDevice, c->stream));
     MOTIFS_HIP_CHECK(hipStreamSynchronize(c->stream));   // the host vectors die with this frame
     bs.KP = bank.KP;
     bs.nch = bank.nch;
@@ -214,6 +261,7 @@ static int cached_bank(motifs_ctx* c, const uint16_t* pwms, const int64_t* lens,
     bs.minlen = bank.minlen;
     bs.maxlen_true = bank.maxlen_true;
     bs.ntiles = mb.ntiles;
+    bs.uniform_eps = mb.uniform_eps;
     bs.key.swap(key);
     *out = &bs;
     return MOTIFS_OK;
@@ -260,6 +308,7 @@ static int scan_hits_mfma(motifs_ctx* c, const BankSlot& bank, int K, const uint
         a.cells = (uint32_t*)c->cnt.p;
         a.lenp = bank.lenp;
         a.ntiles = bank.ntiles;
+        a.uniform_eps = bank.uniform_eps;
         a.d.N = ns;
         a.d.L = L;
         a.d.pitch = motifs_codes_pitch(L);
@@ -286,6 +335,8 @@ static int scan_hits_mfma(motifs_ctx* c, const BankSlot& bank, int K, const uint
         f.total = totals + ((launch_no + 1) & 1);
         f.cap = cap;
         f.tab = (const uint32_t*)bank.tab.p;
+        f.tabk = (const uint16_t*)bank.tabk.p;
+        f.tabk_stride = bank.tabk_stride;
         f.codes = a.codes;
         f.hits = (HitRec*)hits_dev;
         f.hit_scores = hit_scores_dev;
@@ -389,7 +440,7 @@ void motifs_ctx_destroy(motifs_ctx* c) {
                       &c->scores_tmp, &c->pwmcnt, &c->data_tmp, &c->afrag, &c->cinit, &c->staging, &c->rowx})
         b->release();
     for (BankSlot& bs : c->bank_slot)
-        for (DevBuf* b : {&bs.tab, &bs.lim, &bs.afrag, &bs.cinit}) b->release();
+        for (DevBuf* b : {&bs.tab, &bs.lim, &bs.afrag, &bs.cinit, &bs.tabk}) b->release();
     if (c->pinned) (void)hipHostFree(c->pinned);
     resolve_timing(c);
     for (hipEvent_t e : c->free_events) (void)hipEventDestroy(e);

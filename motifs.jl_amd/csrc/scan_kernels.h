@@ -66,6 +66,8 @@ struct FillArgs {
     int lim_min;              // starts <= lim_min are valid for every PWM
     // matrix-core path (stage_hits / emit_records): a (batch, l) line of cells is split into `parts` rows of `rpr` reads
     int parts, rpr;
+    const uint16_t* tabk;         // [K][tabk_stride] binary16 re-scoring table: [ind][5] per PWM, column 4 = +0
+    int tabk_stride;              // halves per PWM row (an odd number of dwords)
     uint32_t* staging;            // [nrows][row_slots] staged hit words
     int row_slots;
     uint32_t* row_excl;           // [nrows] hits before the row inside its block of 1024 rows
@@ -96,6 +98,7 @@ struct CandArgs {
     uint32_t* cells;          // [(batch, l, n-in-batch, chunk)] x 4 words, bit i of a cell = PWM 128*chunk + i
     CandDims d;
     int lenp, ntiles;         // padded PWM length (multiple of 4); tiles of 32 PWMs (multiple of 4: whole chunks)
+    int uniform_eps;          // afrag holds the bank scaled so that the slack is 4.0 for every PWM (cinit unused)
 };
 int cand_tile_group(int lenp);
 hipError_t launch_cand(const CandArgs& a, hipStream_t st);

@@ -43,8 +43,8 @@ static __device__ __forceinline__ unsigned xcd_swz(unsigned b, unsigned nb) {
 //   C = eps_k per PWM row, so that the sign bit of the result is "not a candidate".
 // NG = live tiles of the group (tiles past the bank hold no PWM).  The body is branch-free so that the NG
 // accumulator chains interleave: the matrix pipe works on one tile while the VALU packs the signs of another.
-template <int T, int PG, int NG>
-static __device__ __forceinline__ void cand_read(const f16x8 (&A)[PG][T], const f32x16 (&C0)[PG], const uint2* oh, uint32_t* cp0,
+template <int T, int PG, int NG, int NC>
+static __device__ __forceinline__ void cand_read(const f16x8 (&A)[PG][T], const f32x16 (&C0)[NC], const uint2* oh, uint32_t* cp0,
                                                  size_t lstride4, int ntile, int Lout, int w, int h) {
     for (int wt = 0; wt < ntile; wt++) {
         const int l0 = wt * 32;
@@ -57,7 +57,7 @@ static __device__ __forceinline__ void cand_read(const f16x8 (&A)[PG][T], const 
         }
         f32x16 acc[NG];
 #pragma unroll
-        for (int g = 0; g < NG; g++) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[g][0], B[0], C0[g], 0, 0, 0);
+        for (int g = 0; g < NG; g++) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[g][0], B[0], C0[NC == 1 ? 0 : g], 0, 0, 0);
 #pragma unroll
         for (int t = 1; t < T; t++)
 #pragma unroll
@@ -93,25 +93,28 @@ static __device__ __forceinline__ void cand_read(const f16x8 (&A)[PG][T], const 
     }
 }
 
-template <int T, int PG>
-__global__ __launch_bounds__(512) void scan_cand_kernel(const uint4* __restrict__ afrag, const float* __restrict__ cinit,
-                                                        const uint8_t* __restrict__ codes, uint32_t* __restrict__ cells,
-                                                        const CandDims d) {
+// UEPS: the bank was scaled by a power of two on the host so that one slack, the inline constant 4.0, serves
+// every PWM (C is then not a register operand and the wave needs 64 VGPRs fewer); otherwise C = eps_k from cinit.
+template <int T, int PG, bool UEPS, int RPB>
+static __device__ __forceinline__ void scan_cand_body(const uint4* __restrict__ afrag, const float* __restrict__ cinit,
+                                                      const uint8_t* __restrict__ codes, uint32_t* __restrict__ cells,
+                                                      const CandDims& d) {
     extern __shared__ uint2 oh_all[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int w = lane & 31, h = lane >> 5;
     uint2* oh = oh_all + (size_t)wave * ((d.ohlen + 3) & ~3);
-    // 8 waves = 4 reads x 2 tile groups: the two halves of a 128-byte line of cells (4 reads x 2 chunks) are
+    // a block = RPB reads x 2 tile groups: the two halves of a 128-byte line of cells (4 reads x 2 chunks) are
     // written by the same block at about the same time
-    const int slot = wave & 3;
-    const int tg = blockIdx.y * 2 + (wave >> 2);     // tile group: PWM tiles [tg*PG, tg*PG + PG)
+    const int slot = wave % RPB;
+    const int tg = blockIdx.y * 2 + wave / RPB;      // tile group: PWM tiles [tg*PG, tg*PG + PG)
     if (tg * PG >= d.used_tiles) return;
     const int tile0 = tg * PG;
     const int chunk = tile0 >> 2, word0 = tile0 & 3;
     const int ng = d.used_tiles - tile0 < PG ? d.used_tiles - tile0 : PG;   // wave-uniform
 
+    constexpr int NC = UEPS ? 1 : PG;
     f16x8 A[PG][T];
-    f32x16 C0[PG];
+    f32x16 C0[NC];
 #pragma unroll
     for (int g = 0; g < PG; g++) {
 #pragma unroll
@@ -119,15 +122,21 @@ __global__ __launch_bounds__(512) void scan_cand_kernel(const uint4* __restrict_
             const uint4 v = afrag[((size_t)(tile0 + g) * T + t) * 64 + lane];
             A[g][t] = __builtin_bit_cast(f16x8, v);
         }
+        if (!UEPS) {
 #pragma unroll
-        for (int r = 0; r < 16; r++) C0[g][r] = cinit[((size_t)(tile0 + g) * 2 + h) * 16 + r];
+            for (int r = 0; r < 16; r++) C0[g][r] = cinit[((size_t)(tile0 + g) * 2 + h) * 16 + r];
+        }
+    }
+    if (UEPS) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) C0[0][r] = 4.0f;
     }
 
     const unsigned lb = xcd_swz(blockIdx.x, gridDim.x);
     const int ntile = (d.Lout + 31) / 32;
     const size_t lstride4 = (size_t)d.batch * d.nch * 4;
     for (int s = 0; s < d.spw; s++) {
-        const int64_t n = ((int64_t)lb * d.spw + s) * 4 + slot;        // wave-uniform
+        const int64_t n = ((int64_t)lb * d.spw + s) * RPB + slot;      // wave-uniform
         if (n >= d.N) break;
         // stage the read's one-hot image: 4 halves per position (1.0 at the base, all zero for code 4 / padding);
         // one dword (4 bases) per lane and round
@@ -148,13 +157,26 @@ __global__ __launch_bounds__(512) void scan_cand_kernel(const uint4* __restrict_
         const size_t cell0 = ((size_t)bq * d.Lout * d.batch + (size_t)(n - bq * d.batch)) * d.nch + chunk;   // l = 0
         uint32_t* cp0 = cells + cell0 * 4 + word0;
         switch (ng) {
-            case 1: cand_read<T, PG, 1>(A, C0, oh, cp0, lstride4, ntile, d.Lout, w, h); break;
-            case 2: cand_read<T, PG, (PG >= 2 ? 2 : PG)>(A, C0, oh, cp0, lstride4, ntile, d.Lout, w, h); break;
-            case 3: cand_read<T, PG, (PG >= 3 ? 3 : PG)>(A, C0, oh, cp0, lstride4, ntile, d.Lout, w, h); break;
-            default: cand_read<T, PG, PG>(A, C0, oh, cp0, lstride4, ntile, d.Lout, w, h); break;
+            case 1: cand_read<T, PG, 1, NC>(A, C0, oh, cp0, lstride4, ntile, d.Lout, w, h); break;
+            case 2: cand_read<T, PG, (PG >= 2 ? 2 : PG), NC>(A, C0, oh, cp0, lstride4, ntile, d.Lout, w, h); break;
+            case 3: cand_read<T, PG, (PG >= 3 ? 3 : PG), NC>(A, C0, oh, cp0, lstride4, ntile, d.Lout, w, h); break;
+            default: cand_read<T, PG, PG, NC>(A, C0, oh, cp0, lstride4, ntile, d.Lout, w, h); break;
         }
         __builtin_amdgcn_wave_barrier();
     }
+}
+
+template <int T, int PG>
+__global__ __launch_bounds__(512) void scan_cand_kernel(const uint4* __restrict__ afrag, const float* __restrict__ cinit,
+                                                        const uint8_t* __restrict__ codes, uint32_t* __restrict__ cells,
+                                                        const CandDims d) {
+    scan_cand_body<T, PG, false, 4>(afrag, cinit, codes, cells, d);
+}
+// uniform slack: the wave fits 168 VGPRs, so three 4-wave blocks (2 reads x 2 tile groups) share a CU
+template <int T, int PG>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(T * PG <= 16 ? 3 : 2, 4))) void scan_cand_kernel_u(
+    const uint4* __restrict__ afrag, const uint8_t* __restrict__ codes, uint32_t* __restrict__ cells, const CandDims d) {
+    scan_cand_body<T, PG, true, 2>(afrag, nullptr, codes, cells, d);
 }
 
 // ---- candidates -> records ---------------------------------------------------------------------------------
@@ -171,51 +193,42 @@ constexpr int VF_WAVES = VF_THREADS / 64;
 constexpr int QN = 128;           // candidate ring slots per wave (power of two); fewer than 64 stay behind after a push
 constexpr int ROW_CELLS_MAX = 512;
 
-// table row offsets of the LEN bases of a window from its raw code words (all-zero column: column 4 of the
-// 5-column LDS table, or NOROW for the 4-column global table)
-template <int LEN, bool LDS_TAB>
-static __device__ __forceinline__ void window_offsets(const uint32_t (&W)[LEN / 4 + 1], int l, int KP, uint32_t* dst) {
-#pragma unroll
-    for (int ind = 0; ind < LEN; ind++) {
-        const uint32_t al = __builtin_amdgcn_alignbyte(W[ind / 4 + 1], W[ind / 4], (uint32_t)(l & 3));
-        const uint32_t bb = (al >> (8 * (ind % 4))) & 0xffu;
-        if (LDS_TAB) dst[ind] = (uint32_t)(ind * 5 + (bb < 4 ? bb : 4)) * KP;
-        else dst[ind] = bb < 4 ? (uint32_t)(ind * 4 + bb) * KP : NOROW;
-    }
-}
+// The re-scoring table: one row of binary16 weights per PWM, [k][ind][5] with column 4 = +0 for an all-zero data
+// column and +0 beyond lens[k]; rows are padded to an odd number of dwords (a.tabk_stride halves) so that lanes
+// scoring different PWMs hit different LDS banks.  One weight = v_bfe (the base) + v_lshl_add (the address) +
+// ds_read_u16 + v_add_f16.
 template <int LEN>
 static __device__ __forceinline__ void fetch_codes(const uint8_t* codes, int64_t n, int pitch, int l, uint32_t (&W)[LEN / 4 + 1]) {
     const uint32_t* sw = (const uint32_t*)(codes + n * pitch + (l & ~3));
 #pragma unroll
     for (int q = 0; q <= LEN / 4; q++) W[q] = sw[q];
 }
-// sequential binary16 sum of PWM k over the window (table entries beyond lens[k] are +0)
-template <int LEN, bool LDS_TAB>
-static __device__ __forceinline__ uint16_t exact_score(const uint32_t* tb, const uint32_t* rofs, uint32_t k) {
-    const uint32_t kp = k >> 1, sh = (k & 1u) * 16;
-    uint32_t t[LEN];
+// sequential binary16 sum of a PWM's row over the window whose raw code words are W (reference order, one rounding per add)
+template <int LEN>
+static __device__ __forceinline__ uint16_t exact_score(const _Float16* row, const uint32_t (&W)[LEN / 4 + 1], int l) {
+    uint32_t al[LEN / 4];
 #pragma unroll
-    for (int ind = 0; ind < LEN; ind++) {
-        const uint32_t o = rofs[ind];
-        t[ind] = (!LDS_TAB && o == NOROW) ? 0u : tb[o + kp];
-    }
-    _Float16 acc = __builtin_bit_cast(_Float16, (uint16_t)(t[0] >> sh));
+    for (int j = 0; j < LEN / 4; j++) al[j] = __builtin_amdgcn_alignbyte(W[j + 1], W[j], (uint32_t)(l & 3));
+    _Float16 t[LEN];
 #pragma unroll
-    for (int ind = 1; ind < LEN; ind++) acc = acc + __builtin_bit_cast(_Float16, (uint16_t)(t[ind] >> sh));
+    for (int ind = 0; ind < LEN; ind++) t[ind] = row[ind * 5 + ((al[ind / 4] >> (8 * (ind % 4))) & 0xffu)];
+    __builtin_amdgcn_sched_barrier(0);        // all LEN reads in flight before the dependent chain of adds starts
+    _Float16 acc = t[0];
+#pragma unroll
+    for (int ind = 1; ind < LEN; ind++) acc = acc + t[ind];
     return __builtin_bit_cast(uint16_t, acc);
 }
 static __device__ __forceinline__ bool half_pos(uint16_t h) { return (int16_t)h > 0; }   // > 0 (finite inputs: no NaN)
 
-// the packed bank into LDS; with room, as 5 columns per position (column 4 = zeros for all-zero data columns)
-template <int LEN, bool LDS_TAB, int THREADS>
-static __device__ __forceinline__ const uint32_t* stage_table(const uint32_t* tab, int KP, uint32_t* ltab) {
-    if (!LDS_TAB) return tab;
-    for (int i = threadIdx.x; i < LEN * 5 * KP; i += THREADS) {
-        const int kp = i % KP, cb = i / KP, b = cb % 5, ind = cb / 5;
-        ltab[i] = b < 4 ? tab[(size_t)(ind * 4 + b) * KP + kp] : 0u;
-    }
+// the table into LDS when it fits (a straight copy)
+template <bool LDS_TAB, int THREADS>
+static __device__ __forceinline__ const _Float16* stage_table(const FillArgs& a, uint32_t* ltab) {
+    if (!LDS_TAB) return (const _Float16*)a.tabk;
+    const int ndw = (a.K * a.tabk_stride + 1) / 2;
+    const uint32_t* src = (const uint32_t*)a.tabk;
+    for (int i = threadIdx.x; i < ndw; i += THREADS) ltab[i] = src[i];
     __syncthreads();
-    return ltab;
+    return (const _Float16*)ltab;
 }
 
 static __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
@@ -312,8 +325,8 @@ static __device__ __forceinline__ void for_row_candidates(const RowGeom& g, uint
 }
 
 // exact score of one candidate word of row g; false if the candidate is not a hit
-template <int LEN, bool LDS_TAB>
-static __device__ __forceinline__ bool score_candidate(const FillArgs& a, const RowGeom& g, const uint32_t* tb, uint32_t cw, bool live,
+template <int LEN>
+static __device__ __forceinline__ bool score_candidate(const FillArgs& a, const RowGeom& g, const _Float16* tb, uint32_t cw, bool live,
                                                        uint32_t& k, uint32_t& nin, uint16_t& sc) {
     const uint32_t idx = cw >> 7, q = (cw >> 5) & 3u, i = cw & 31u;
     nin = a.div_nch.div(idx);
@@ -322,10 +335,9 @@ static __device__ __forceinline__ bool score_candidate(const FillArgs& a, const 
     k = (ch * 4 + q) * 32 + i;
     sc = 0;
     if (!(live && n < a.N && (int)k < a.K && (g.l <= a.lim_min || g.l <= a.lim[k]))) return false;
-    uint32_t W[LEN / 4 + 1], rofs[LEN];
+    uint32_t W[LEN / 4 + 1];
     fetch_codes<LEN>(a.codes, n, a.pitch, g.l, W);
-    window_offsets<LEN, LDS_TAB>(W, g.l, a.KP, rofs);
-    sc = exact_score<LEN, LDS_TAB>(tb, rofs, k);
+    sc = exact_score<LEN>(tb + (size_t)k * a.tabk_stride, W, g.l);
     return half_pos(sc);
 }
 
@@ -338,7 +350,7 @@ __global__ __launch_bounds__(VF_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     uint32_t* hist = smem + VF_WAVES * QN / 2;                        // [hist_bins]
     uint32_t* ltab = hist + a.hist_bins;
     for (int i = tid; i < a.hist_bins; i += VF_THREADS) hist[i] = 0;
-    const uint32_t* tb = stage_table<LEN, LDS_TAB, VF_THREADS>(a.tab, a.KP, ltab);
+    const _Float16* tb = stage_table<LDS_TAB, VF_THREADS>(a, ltab);
     __syncthreads();
     const int64_t nwaves = (int64_t)gridDim.x * VF_WAVES;
     for (int64_t r = (int64_t)wv * gridDim.x + blockIdx.x; r < a.nrows; r += nwaves) {
@@ -348,7 +360,7 @@ __global__ __launch_bounds__(VF_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
         for_row_candidates(g, queue, [&](const uint32_t cw, const bool live) {
             uint32_t k, nin;
             uint16_t sc;
-            const bool hit = score_candidate<LEN, LDS_TAB>(a, g, tb, cw, live, k, nin, sc);
+            const bool hit = score_candidate<LEN>(a, g, tb, cw, live, k, nin, sc);
             const unsigned long long hb = __ballot(hit);
             if (hit) {
                 if (STAGE) {
@@ -422,9 +434,9 @@ __global__ __launch_bounds__(VF_THREADS) void emit_records(FillArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     uint16_t* queue = (uint16_t*)smem + wv * QN;
     uint32_t* ltab = smem + VF_WAVES * QN / 2;
-    const uint32_t* tb = nullptr;                                     // staged lazily: only overflowed rows need the bank
+    const _Float16* tb = nullptr;                                     // staged lazily: only overflowed rows need the bank
     bool staged = !LDS_TAB;
-    if (!LDS_TAB) tb = a.tab;
+    if (!LDS_TAB) tb = (const _Float16*)a.tabk;
     const int64_t nwaves = (int64_t)gridDim.x * VF_WAVES;
     // block-uniform loop bounds so that the lazy staging barrier is reached by every wave
     for (int64_t rb = (int64_t)blockIdx.x * VF_WAVES; rb < a.nrows; rb += nwaves) {
@@ -432,7 +444,7 @@ __global__ __launch_bounds__(VF_THREADS) void emit_records(FillArgs a) {
         const uint32_t cnt = r < a.nrows ? a.row_sum[r] : 0u;
         const bool big = cnt > (uint32_t)a.row_slots;
         if (__syncthreads_or(big) && !staged) {
-            tb = stage_table<LEN, LDS_TAB, VF_THREADS>(a.tab, a.KP, ltab);
+            tb = stage_table<LDS_TAB, VF_THREADS>(a, ltab);
             staged = true;
         }
         if (cnt == 0) continue;
@@ -457,7 +469,7 @@ __global__ __launch_bounds__(VF_THREADS) void emit_records(FillArgs a) {
             for_row_candidates(g, queue, [&](const uint32_t cw, const bool live) {
                 uint32_t k, nin;
                 uint16_t sc;
-                const bool hit = score_candidate<LEN, LDS_TAB>(a, g, tb, cw, live, k, nin, sc);
+                const bool hit = score_candidate<LEN>(a, g, tb, cw, live, k, nin, sc);
                 const unsigned long long hb = __ballot(hit);
                 if (hit) put(row_at + nhit + (uint32_t)__builtin_popcountll(hb & ((1ull << lane) - 1ull)), k, nin, sc);
                 nhit += (uint32_t)__builtin_popcountll(hb);
@@ -468,11 +480,13 @@ __global__ __launch_bounds__(VF_THREADS) void emit_records(FillArgs a) {
 
 template <int T, int PG>
 static hipError_t launch_cand_tp(const CandArgs& a, hipStream_t st) {
-    const int64_t per_block = (int64_t)4 * a.d.spw;
+    const int rpb = a.uniform_eps ? 2 : 4;
+    const int64_t per_block = (int64_t)rpb * a.d.spw;
     const int ntg = a.ntiles / PG;
     dim3 grid((unsigned)((a.d.N + per_block - 1) / per_block), (unsigned)((ntg + 1) / 2), 1);
-    hipLaunchKernelGGL((scan_cand_kernel<T, PG>), grid, dim3(512), (size_t)8 * ((a.d.ohlen + 3) & ~3) * 8, st, a.afrag, a.cinit, a.codes, a.cells,
-                       a.d);
+    const size_t lds = (size_t)2 * rpb * ((a.d.ohlen + 3) & ~3) * 8;
+    if (a.uniform_eps) hipLaunchKernelGGL((scan_cand_kernel_u<T, PG>), grid, dim3(256), lds, st, a.afrag, a.codes, a.cells, a.d);
+    else hipLaunchKernelGGL((scan_cand_kernel<T, PG>), grid, dim3(512), lds, st, a.afrag, a.cinit, a.codes, a.cells, a.d);
     return hipGetLastError();
 }
 
@@ -496,7 +510,7 @@ template <int LEN>
 static hipError_t launch_stage_len(const FillArgs& a, bool stage, hipStream_t st) {
     if ((int64_t)a.rpr * a.nch > ROW_CELLS_MAX || a.nrows >= (int64_t)1 << 31) return hipErrorInvalidValue;
     const size_t base = (size_t)VF_WAVES * QN * 2 + (size_t)a.hist_bins * 4;
-    const size_t tab_bytes = (size_t)LEN * 5 * a.KP * 4;
+    const size_t tab_bytes = ((size_t)a.K * a.tabk_stride * 2 + 3) & ~(size_t)3;
     const bool lds_tab = base + tab_bytes <= 64 * 1024;
     const unsigned grid = (unsigned)std::min<int64_t>((a.nrows + VF_WAVES - 1) / VF_WAVES, 256 * 4);
     const size_t lds = lds_tab ? base + tab_bytes : base;
@@ -512,7 +526,7 @@ static hipError_t launch_stage_len(const FillArgs& a, bool stage, hipStream_t st
 template <int LEN>
 static hipError_t launch_emit_len(const FillArgs& a, hipStream_t st) {
     const size_t base = (size_t)VF_WAVES * QN * 2;
-    const size_t tab_bytes = (size_t)LEN * 5 * a.KP * 4;
+    const size_t tab_bytes = ((size_t)a.K * a.tabk_stride * 2 + 3) & ~(size_t)3;
     const unsigned grid = (unsigned)std::min<int64_t>((a.nrows + VF_WAVES - 1) / VF_WAVES, 256 * 8);
     if (base + tab_bytes <= 64 * 1024)
         hipLaunchKernelGGL((emit_records<LEN, true>), dim3(grid), dim3(VF_THREADS), base + tab_bytes, st, a);
