@@ -197,12 +197,6 @@ constexpr int ROW_CELLS_MAX = 512;
 // column and +0 beyond lens[k]; rows are padded to an odd number of dwords (a.tabk_stride halves) so that lanes
 // scoring different PWMs hit different LDS banks.  One weight = v_bfe (the base) + v_lshl_add (the address) +
 // ds_read_u16 + v_add_f16.
-template <int LEN>
-static __device__ __forceinline__ void fetch_codes(const uint8_t* codes, int64_t n, int pitch, int l, uint32_t (&W)[LEN / 4 + 1]) {
-    const uint32_t* sw = (const uint32_t*)(codes + n * pitch + (l & ~3));
-#pragma unroll
-    for (int q = 0; q <= LEN / 4; q++) W[q] = sw[q];
-}
 // sequential binary16 sum of a PWM's row over the window whose raw code words are W (reference order, one rounding per add)
 template <int LEN>
 static __device__ __forceinline__ uint16_t exact_score(const _Float16* row, const uint32_t (&W)[LEN / 4 + 1], int l) {
@@ -231,12 +225,17 @@ static __device__ __forceinline__ const _Float16* stage_table(const FillArgs& a,
     return (const _Float16*)ltab;
 }
 
-static __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
-#pragma unroll
-    for (int dd = 1; dd < 64; dd <<= 1) {
-        const uint32_t t = __shfl_up(v, dd);
-        if (lane >= dd) v += t;
-    }
+// inclusive prefix sum over the 64 lanes with DPP moves (no LDS round trips): within rows of 16 by row_shr, then
+// row_bcast:15 / row_bcast:31 carry the row totals forward
+static __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x) {
+    uint32_t v = x;
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x113, 0xf, 0xf, false);   // row_shr:3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xe, false);   // row_shr:4, banks 1-3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xc, false);   // row_shr:8, banks 2-3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2, 3
     return v;
 }
 // LDS traffic between lanes of one wave: program order is execution order, the fences stop the compiler
@@ -286,7 +285,9 @@ struct RowGeom {
     int l;
     int64_t bq, nrow0;            // nrow0 = index of the row's first read in the super-batch
     uint32_t row_cells;
+    uint32_t nvalid;              // reads of the row that exist (the last batch may be short)
     const uint4* cells;
+    const uint8_t* codes;         // the row's first read, advanced to the dword that holds start l
 };
 static __device__ __forceinline__ RowGeom row_geom(const FillArgs& a, int64_t r) {
     RowGeom g;
@@ -299,6 +300,9 @@ static __device__ __forceinline__ RowGeom row_geom(const FillArgs& a, int64_t r)
     g.row_cells = nreads * (uint32_t)a.nch;
     g.cells = a.masks + (((size_t)g.bq * a.Lout + g.l) * a.batch + n_lo) * a.nch;
     g.nrow0 = g.bq * a.batch + n_lo;
+    const int64_t left = a.N - g.nrow0;
+    g.nvalid = left <= 0 ? 0u : (left < (int64_t)nreads ? (uint32_t)left : nreads);
+    g.codes = a.codes + g.nrow0 * a.pitch + (g.l & ~3);
     return g;
 }
 
@@ -316,8 +320,8 @@ static __device__ __forceinline__ void for_row_candidates(const RowGeom& g, uint
         if (idx + 64 < g.row_cells) m_next = g.cells[idx + 64];
         const uint32_t wd[4] = {m.x, m.y, m.z, m.w};
         const uint32_t pc = __builtin_popcount(m.x) + __builtin_popcount(m.y) + __builtin_popcount(m.z) + __builtin_popcount(m.w);
-        const uint32_t inc = wave_incl_scan(pc, lane);
-        const uint32_t tot = __shfl(inc, 63);
+        const uint32_t inc = wave_incl_scan(pc);
+        const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
         if (tot) push_and_drain(queue, head, qlen, wd, idx, inc - pc, tot, fn);
     }
     if (qlen) fn((uint32_t)queue[(head + lane) & (QN - 1)], (uint32_t)lane < qlen);   // the remainder (< 64)
@@ -331,12 +335,13 @@ static __device__ __forceinline__ bool score_candidate(const FillArgs& a, const 
     const uint32_t idx = cw >> 7, q = (cw >> 5) & 3u, i = cw & 31u;
     nin = a.div_nch.div(idx);
     const uint32_t ch = idx - nin * a.nch;
-    const int64_t n = g.nrow0 + nin;
     k = (ch * 4 + q) * 32 + i;
     sc = 0;
-    if (!(live && n < a.N && (int)k < a.K && (g.l <= a.lim_min || g.l <= a.lim[k]))) return false;
+    if (!(live && nin < g.nvalid && (int)k < a.K && (g.l <= a.lim_min || g.l <= a.lim[k]))) return false;
     uint32_t W[LEN / 4 + 1];
-    fetch_codes<LEN>(a.codes, n, a.pitch, g.l, W);
+    const uint32_t* sw = (const uint32_t*)(g.codes + nin * (uint32_t)a.pitch);
+#pragma unroll
+    for (int j = 0; j <= LEN / 4; j++) W[j] = sw[j];
     sc = exact_score<LEN>(tb + (size_t)k * a.tabk_stride, W, g.l);
     return half_pos(sc);
 }
@@ -388,7 +393,7 @@ __global__ __launch_bounds__(1024) void row_scan_local(const uint32_t* __restric
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int64_t i = (int64_t)blockIdx.x * 1024 + tid;
     const uint32_t v = i < nrows ? row_sum[i] : 0u;
-    const uint32_t inc = wave_incl_scan(v, lane);
+    const uint32_t inc = wave_incl_scan(v);
     if (lane == 63) wsum[wv] = inc;
     __syncthreads();
     uint32_t wbase = 0, tot = 0;
@@ -504,7 +509,7 @@ hipError_t launch_cand(const CandArgs& a, hipStream_t st) {
     }
 }
 
-int stage_row_reads(int nch) { return std::max(1, 256 / nch); }
+int stage_row_reads(int nch) { return std::max(1, ROW_CELLS_MAX / nch); }
 
 template <int LEN>
 static hipError_t launch_stage_len(const FillArgs& a, bool stage, hipStream_t st) {
