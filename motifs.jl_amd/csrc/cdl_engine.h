@@ -90,6 +90,7 @@ struct Engine {
     Tensor make(size_t n, bool needs_grad);
     Tensor wrap(float* v, float* g, size_t n, bool needs_grad);   // external storage (parameters)
     float* grad(Tensor t);         // allocate + zero on first use
+    float* grad_first(Tensor t, int& acc);   // allocate on first use without the zero fill (acc = 0: overwrite)
     NzView nz_build(const float* data, int S, int n_per);   // non-zero list of [S][n_per] values (memory order)
     NzView nz_of(Tensor t, int S);                           // cached list of t's values
     NzView nz_of_mask(Tensor t, int S);                      // cached list of t->gmask

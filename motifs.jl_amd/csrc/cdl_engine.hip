@@ -57,6 +57,19 @@ float* Engine::grad(Tensor t) {
     return t->g;
 }
 
+// The gradient buffer of t for a kernel that can either overwrite or accumulate: acc = 0 on first use (no zero fill).
+float* Engine::grad_first(Tensor t, int& acc) {
+    acc = 1;
+    if (t->g) return t->g;
+    t->g = arena.alloc(t->n);
+    if (!t->g) {
+        failed = true;
+        return nullptr;
+    }
+    acc = 0;
+    return t->g;
+}
+
 void Engine::backward() {
     for (auto it = tape.rbegin(); it != tape.rend(); ++it) {
         if (failed) break;
@@ -72,17 +85,19 @@ __global__ void k_lin(const float* x, float a, const float* y, float b, float cs
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         out[i] = a * x[i] + (y ? b * y[i % yn] : 0.0f) + cst;
 }
-__global__ void k_axpy(const float* go, float a, size_t n, float* dx) {   // dx += a * go
+// The backward kernels below take `acc`: 1 adds into dx, 0 overwrites it (the first contribution to a gradient
+// buffer, which then needs no zero fill: Engine::grad_first).
+__global__ void k_axpy(const float* go, float a, size_t n, float* dx, int acc) {   // dx (+)= a * go
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        dx[i] += a * go[i];
+        dx[i] = (acc ? dx[i] : 0.0f) + a * go[i];
 }
 __global__ void k_mul(const float* x, const float* y, size_t n, size_t yn, float* out) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         out[i] = x[i] * y[i % yn];
 }
-__global__ void k_mul_bwd_x(const float* go, const float* y, size_t n, size_t yn, float* dx) {
+__global__ void k_mul_bwd_x(const float* go, const float* y, size_t n, size_t yn, float* dx, int acc) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        dx[i] += go[i] * y[i % yn];
+        dx[i] = (acc ? dx[i] : 0.0f) + go[i] * y[i % yn];
 }
 // dy[j] += coef * sum_{i == j mod yn} go[i] * (x ? x[i] : 1): yn == 1 -> block reduction; else one thread per j
 __global__ void k_bcast_reduce_all(const float* go, const float* x, size_t n, float coef, float* dy) {
@@ -108,8 +123,8 @@ __global__ void k_bcast_reduce_mod(const float* go, const float* x, size_t n, si
 }
 static void bcast_reduce(hipStream_t st, const float* go, const float* x, size_t n, size_t yn, float coef, float* dy) {
     if (yn == n) {
-        if (x) hipLaunchKernelGGL(k_mul_bwd_x, dim3(nblocks(n)), dim3(256), 0, st, go, x, n, n, dy);  // coef == 1 there
-        else hipLaunchKernelGGL(k_axpy, dim3(nblocks(n)), dim3(256), 0, st, go, coef, n, dy);
+        if (x) hipLaunchKernelGGL(k_mul_bwd_x, dim3(nblocks(n)), dim3(256), 0, st, go, x, n, n, dy, 1);  // coef == 1 there
+        else hipLaunchKernelGGL(k_axpy, dim3(nblocks(n)), dim3(256), 0, st, go, coef, n, dy, 1);
     } else if (yn == 1) {
         hipLaunchKernelGGL(k_bcast_reduce_all, dim3(nblocks(n, 256, 1024)), dim3(256), 0, st, go, x, n, coef, dy);
     } else {
@@ -120,9 +135,9 @@ __global__ void k_relu(const float* x, size_t n, float* out) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         out[i] = x[i] > 0.0f ? x[i] : 0.0f;
 }
-__global__ void k_relu_bwd(const float* go, const float* x, size_t n, float* dx) {
+__global__ void k_relu_bwd(const float* go, const float* x, size_t n, float* dx, int acc) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        dx[i] += x[i] > 0.0f ? go[i] : 0.0f;
+        dx[i] = (acc ? dx[i] : 0.0f) + (x[i] > 0.0f ? go[i] : 0.0f);
 }
 __global__ void k_maskmul(const float* x, const float* m, float c, size_t n, float* out, int acc) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -208,9 +223,9 @@ __global__ void k_sumsq_groups(const float* x, size_t per_group, float coef, flo
         atomicAdd(&out[g], (float)(coef * t));
     }
 }
-__global__ void k_sumsq_groups_bwd(const float* gout, const float* x, size_t per_group, size_t n, float coef2, float* dx) {
+__global__ void k_sumsq_groups_bwd(const float* gout, const float* x, size_t per_group, size_t n, float coef2, float* dx, int acc) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        dx[i] += coef2 * x[i] * gout[i / per_group];
+        dx[i] = (acc ? dx[i] : 0.0f) + coef2 * x[i] * gout[i / per_group];
 }
 
 #define EW(kern, n, ...) hipLaunchKernelGGL(kern, dim3(nblocks(n)), dim3(256), 0, st, __VA_ARGS__)
@@ -222,7 +237,11 @@ Tensor Engine::lin(Tensor x, float a, Tensor y, float b, float cst) {
     if (recording && out->needs_grad)
         tape.push_back([this, out, x, y, a, b]() {
             if (!out->g) return;
-            if (x->needs_grad) EW(k_axpy, out->n, out->g, a, out->n, grad(x));
+            if (x->needs_grad) {
+                int acc;
+                float* dx = grad_first(x, acc);
+                if (dx) EW(k_axpy, out->n, out->g, a, out->n, dx, acc);
+            }
             if (y && y->needs_grad) bcast_reduce(st, out->g, nullptr, out->n, y->n, b, grad(y));
         });
     return out;
@@ -235,7 +254,11 @@ Tensor Engine::mul(Tensor x, Tensor y) {
     if (recording && out->needs_grad)
         tape.push_back([this, out, x, y]() {
             if (!out->g) return;
-            if (x->needs_grad) EW(k_mul_bwd_x, out->n, out->g, y->v, out->n, y->n, grad(x));
+            if (x->needs_grad) {
+                int acc;
+                float* dx = grad_first(x, acc);
+                if (dx) EW(k_mul_bwd_x, out->n, out->g, y->v, out->n, y->n, dx, acc);
+            }
             if (y->needs_grad) bcast_reduce(st, out->g, x->v, out->n, y->n, 1.0f, grad(y));
         });
     return out;
@@ -247,7 +270,9 @@ Tensor Engine::relu(Tensor x) {
     EW(k_relu, x->n, x->v, x->n, out->v);
     if (recording && out->needs_grad)
         tape.push_back([this, out, x]() {
-            if (out->g) EW(k_relu_bwd, out->n, out->g, x->v, out->n, grad(x));
+            int acc;
+            float* dx = out->g ? grad_first(x, acc) : nullptr;
+            if (dx) EW(k_relu_bwd, out->n, out->g, x->v, out->n, dx, acc);
         });
     return out;
 }
@@ -258,7 +283,9 @@ Tensor Engine::maskmul(Tensor x, const float* mask, float c) {
     EW(k_maskmul, x->n, x->v, mask, c, x->n, out->v, 0);
     if (recording && out->needs_grad)
         tape.push_back([this, out, x, mask, c]() {
-            if (out->g) EW(k_maskmul, out->n, out->g, mask, c, out->n, grad(x), 1);
+            int acc;
+            float* dx = out->g ? grad_first(x, acc) : nullptr;
+            if (dx) EW(k_maskmul, out->n, out->g, mask, c, out->n, dx, acc);
         });
     return out;
 }
@@ -269,7 +296,9 @@ Tensor Engine::expo(Tensor x) {
     EW(k_exp, x->n, x->v, x->n, out->v);
     if (recording && out->needs_grad)
         tape.push_back([this, out, x]() {
-            if (out->g) EW(k_mul_bwd_x, out->n, out->g, out->v, out->n, out->n, grad(x));
+            int acc;
+            float* dx = out->g ? grad_first(x, acc) : nullptr;
+            if (dx) EW(k_mul_bwd_x, out->n, out->g, out->v, out->n, out->n, dx, acc);
         });
     return out;
 }
@@ -306,7 +335,9 @@ Tensor Engine::sumsq_groups(Tensor x, float coef, int groups) {
     hipLaunchKernelGGL(k_sumsq_groups, dim3(nblocks(per, 256, 64), groups), dim3(256), 0, st, x->v, per, coef, out->v);
     if (recording && out->needs_grad)
         tape.push_back([this, out, x, per, coef]() {
-            if (out->g) EW(k_sumsq_groups_bwd, x->n, out->g, x->v, per, x->n, 2.0f * coef, grad(x));
+            int acc;
+            float* dx = out->g ? grad_first(x, acc) : nullptr;
+            if (dx) EW(k_sumsq_groups_bwd, x->n, out->g, x->v, per, x->n, 2.0f * coef, dx, acc);
         });
     return out;
 }
@@ -1033,7 +1064,9 @@ Tensor Engine::expandD(Tensor D, int g, int M, int fl) {
     EW(k_expandD, out->n, D->v, g, M, fl, out->v, 0);
     if (recording && out->needs_grad)
         tape.push_back([this, out, D, g, M, fl]() {
-            if (out->g) EW(k_collapseD, D->n, out->g, g, M, fl, grad(D), 1);
+            int acc;
+            float* dx = out->g ? grad_first(D, acc) : nullptr;
+            if (dx) EW(k_collapseD, D->n, out->g, g, M, fl, dx, acc);
         });
     return out;
 }
@@ -1043,7 +1076,9 @@ Tensor Engine::collapseD(Tensor GA, int g, int M, int fl) {
     EW(k_collapseD, out->n, GA->v, g, M, fl, out->v, 0);
     if (recording && out->needs_grad)
         tape.push_back([this, out, GA, g, M, fl]() {
-            if (out->g) EW(k_expandD, GA->n, out->g, g, M, fl, grad(GA), 1);
+            int acc;
+            float* dx = out->g ? grad_first(GA, acc) : nullptr;
+            if (dx) EW(k_expandD, GA->n, out->g, g, M, fl, dx, acc);
         });
     return out;
 }
@@ -1064,7 +1099,9 @@ Tensor Engine::swap02(Tensor x, int g, int d0, int d1, int d2) {
     EW(k_swap02, x->n, x->v, g, d0, d1, d2, out->v, 0);
     if (recording && out->needs_grad)
         tape.push_back([this, out, x, g, d0, d1, d2]() {
-            if (out->g) EW(k_swap02, x->n, out->g, g, d2, d1, d0, grad(x), 1);
+            int acc;
+            float* dx = out->g ? grad_first(x, acc) : nullptr;
+            if (dx) EW(k_swap02, x->n, out->g, g, d2, d1, d0, dx, acc);
         });
     return out;
 }
@@ -1076,7 +1113,9 @@ Tensor Engine::flipT(Tensor Bm, int g, int H, int W, int N) {
     if (recording && out->needs_grad)
         tape.push_back([this, out, Bm, g, H, W, N]() {
             // adjoint: dIn[i][j][n] += dOut[H-1-i][n][j]  == flipT with the roles of W and N exchanged
-            if (out->g) EW(k_flipT, Bm->n, out->g, g, H, N, W, grad(Bm), 1);
+            int acc;
+            float* dx = out->g ? grad_first(Bm, acc) : nullptr;
+            if (dx) EW(k_flipT, Bm->n, out->g, g, H, N, W, dx, acc);
         });
     return out;
 }
