@@ -228,6 +228,63 @@ __global__ void k_sumsq_groups_bwd(const float* gout, const float* x, size_t per
         dx[i] = (acc ? dx[i] : 0.0f) + coef2 * x[i] * gout[i / per_group];
 }
 
+// a*x + b*y + c*z in one pass (z optional)
+__global__ void k_lin3(const float* x, float a, const float* y, float b, const float* z, float c, size_t n, float* out) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = a * x[i] + b * y[i] + (z ? c * z[i] : 0.0f);
+}
+// The ISTA step of update_ZY (model.jl:240-244) on the compact image, fused:
+//   out = relu(ZY - lst * (g1 + pen * (ZY - FX - ab)) - ls * lst)          (ab optional; pen, lst, ls device scalars)
+__global__ void k_zy_step(const float* ZY, const float* g1, const float* FX, const float* ab, const float* pen, const float* lst,
+                          const float* ls, size_t n, float* out) {
+    const float p = *pen, s = *lst, l = *ls;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float inner = ZY[i] - (FX[i] + (ab ? ab[i] : 0.0f));
+        const float grad = g1[i] + inner * p;
+        const float u = (ZY[i] - grad * s) - l * s;
+        out[i] = u > 0.0f ? u : 0.0f;
+    }
+}
+// its VJP: one pass over the image for the four tensor gradients and the three scalar gradients
+// (dsc[0..2] = d pen, d lst, d ls; block sums in double, one float atomic each per block)
+__global__ void k_zy_step_bwd(const float* go, const float* out, const float* ZY, const float* g1, const float* FX, const float* ab,
+                              const float* pen, const float* lst, const float* ls, size_t n, float* dZY, int aZY, float* dg1, int ag1,
+                              float* dFX, int aFX, float* dab, int aab, float* dpen, float* dlst, float* dls) {
+    const float p = *pen, s = *lst, l = *ls;
+    double sp = 0, ss = 0, sl = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float du = out[i] > 0.0f ? go[i] : 0.0f;
+        const float inner = ZY[i] - (FX[i] + (ab ? ab[i] : 0.0f));
+        const float grad = g1[i] + inner * p;
+        if (dZY) dZY[i] = (aZY ? dZY[i] : 0.0f) + du * (1.0f - s * p);
+        if (dg1) dg1[i] = (ag1 ? dg1[i] : 0.0f) - s * du;
+        const float dfx = s * p * du;
+        if (dFX) dFX[i] = (aFX ? dFX[i] : 0.0f) + dfx;
+        if (dab) dab[i] = (aab ? dab[i] : 0.0f) + dfx;
+        sp -= (double)du * (double)(s * inner);
+        ss -= (double)du * (double)(grad + l);
+        sl -= (double)du * (double)s;
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+        sp += __shfl_xor(sp, d);
+        ss += __shfl_xor(ss, d);
+        sl += __shfl_xor(sl, d);
+    }
+    __shared__ double red[3][4];
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        red[0][wv] = sp;
+        red[1][wv] = ss;
+        red[2][wv] = sl;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (dpen) atomicAdd(dpen, (float)(red[0][0] + red[0][1] + red[0][2] + red[0][3]));
+        if (dlst) atomicAdd(dlst, (float)(red[1][0] + red[1][1] + red[1][2] + red[1][3]));
+        if (dls) atomicAdd(dls, (float)(red[2][0] + red[2][1] + red[2][2] + red[2][3]));
+    }
+}
+
 #define EW(kern, n, ...) hipLaunchKernelGGL(kern, dim3(nblocks(n)), dim3(256), 0, st, __VA_ARGS__)
 
 Tensor Engine::lin(Tensor x, float a, Tensor y, float b, float cst) {
@@ -243,6 +300,49 @@ Tensor Engine::lin(Tensor x, float a, Tensor y, float b, float cst) {
                 if (dx) EW(k_axpy, out->n, out->g, a, out->n, dx, acc);
             }
             if (y && y->needs_grad) bcast_reduce(st, out->g, nullptr, out->n, y->n, b, grad(y));
+        });
+    return out;
+}
+
+Tensor Engine::lin3(Tensor x, float a, Tensor y, float b, Tensor z, float c) {
+    Tensor out = make(x->n, x->needs_grad || y->needs_grad || (z && z->needs_grad));
+    if (failed) return out;
+    EW(k_lin3, x->n, x->v, a, y->v, b, z ? z->v : nullptr, c, x->n, out->v);
+    if (recording && out->needs_grad)
+        tape.push_back([this, out, x, y, z, a, b, c]() {
+            if (!out->g) return;
+            Tensor ts[3] = {x, y, z};
+            const float cs[3] = {a, b, c};
+            for (int i = 0; i < 3; i++) {
+                if (!ts[i] || !ts[i]->needs_grad) continue;
+                int acc;
+                float* d = grad_first(ts[i], acc);
+                if (d) EW(k_axpy, out->n, out->g, cs[i], out->n, d, acc);
+            }
+        });
+    return out;
+}
+
+Tensor Engine::zy_step(Tensor ZY, Tensor g1, Tensor FX, Tensor ab, Tensor pen, Tensor lst, Tensor ls) {
+    const bool ng = ZY->needs_grad || g1->needs_grad || FX->needs_grad || (ab && ab->needs_grad) || pen->needs_grad ||
+                    lst->needs_grad || ls->needs_grad;
+    Tensor out = make(ZY->n, ng);
+    if (failed) return out;
+    EW(k_zy_step, ZY->n, ZY->v, g1->v, FX->v, ab ? ab->v : nullptr, pen->v, lst->v, ls->v, ZY->n, out->v);
+    if (recording && out->needs_grad)
+        tape.push_back([this, out, ZY, g1, FX, ab, pen, lst, ls]() {
+            if (!out->g) return;
+            int a0 = 1, a1 = 1, a2 = 1, a3 = 1;
+            float* d0 = ZY->needs_grad ? grad_first(ZY, a0) : nullptr;
+            float* d1 = g1->needs_grad ? grad_first(g1, a1) : nullptr;
+            float* d2 = FX->needs_grad ? grad_first(FX, a2) : nullptr;
+            float* d3 = (ab && ab->needs_grad) ? grad_first(ab, a3) : nullptr;
+            float* dp = pen->needs_grad ? grad(pen) : nullptr;
+            float* ds = lst->needs_grad ? grad(lst) : nullptr;
+            float* dl = ls->needs_grad ? grad(ls) : nullptr;
+            if (failed) return;
+            hipLaunchKernelGGL(k_zy_step_bwd, dim3(nblocks(out->n, 256, 2048)), dim3(256), 0, st, out->g, out->v, ZY->v, g1->v, FX->v,
+                               ab ? ab->v : nullptr, pen->v, lst->v, ls->v, out->n, d0, a0, d1, a1, d2, a2, d3, a3, dp, ds, dl);
         });
     return out;
 }

@@ -149,20 +149,14 @@ static void admm_xyz(motifs_model* m, Graph& gr, const Scalars& sc, const Graph:
         // update_ZY (:237-245)
         Tensor diff = e.lin(gr.synD(ZY, bD), 1.0f, gr.Sone, -1.0f, 0.0f);
         Tensor g1 = gr.anaD(diff, bD);
-        Tensor FXab = ab ? e.lin(FX, 1.0f, ab, 1.0f, 0.0f) : FX;
-        Tensor inner = e.lin(ZY, 1.0f, FXab, -1.0f, 0.0f);
-        Tensor grad = e.lin(g1, 1.0f, e.mul(inner, sc.pen[t]), 1.0f, 0.0f);
-        Tensor u = e.lin(e.lin(ZY, 1.0f, e.mul(grad, sc.lst[t]), -1.0f, 0.0f), 1.0f, e.mul(sc.ls[t], sc.lst[t]), -1.0f, 0.0f);
-        ZY = e.relu(u);
+        ZY = e.zy_step(ZY, g1, FX, ab, sc.pen[t], sc.lst[t], sc.ls[t]);   // z_grad/y_grad + the shrinkage (:240-244)
         // update_X (:247-254); `sum(FX, dims=3)` is a no-op on the already summed FX
         Tensor ZYm = gr.cat_ZY(ZY);
-        Tensor rhs = ab ? e.lin(ZYm, 1.0f, ab, -1.0f, 0.0f) : ZYm;
-        Tensor xg = gr.anaF(e.lin(FX, 1.0f, rhs, -1.0f, 0.0f), bF);
+        Tensor xg = gr.anaF(e.lin3(FX, 1.0f, ZYm, -1.0f, ab, 1.0f), bF);   // FX - (ZY - [alpha beta])
         X = gr.project_X(e.lin(X, 1.0f, e.mul(xg, sc.ost[t]), -1.0f, 0.0f));
         // (:263-266)
         FX = gr.synF(X, bF);
-        Tensor ab1 = ab ? e.lin(ab, 1.0f, FX, 1.0f, 0.0f) : FX;
-        ab = e.lin(ab1, 1.0f, ZY, -1.0f, 0.0f);
+        ab = e.lin3(FX, 1.0f, ZY, -1.0f, ab, 1.0f);
     }
     e.note("ZY", ZY);
     e.note("X", X);
@@ -199,8 +193,7 @@ static Tensor forward_loss(motifs_model* m, Graph& gr, bool train) {
         bDc = gr.bankD(Dc, gD);
         // update_F (:292-308)
         Tensor FXc = gr.synF(X, bFc);
-        Tensor tgt = theta ? e.lin(ZYm, 1.0f, theta, 1.0f, 0.0f) : ZYm;
-        Tensor R = e.lin(FXc, 1.0f, tgt, -1.0f, 0.0f);
+        Tensor R = e.lin3(FXc, 1.0f, ZYm, -1.0f, theta, -1.0f);
         Tensor Fgrad = e.swap02(e.wgrad_sp(R, X, gr.spd(G)), G, m->h, m->twoM, m->K);
         Tensor t2 = e.lin(e.mul(Fgrad, sc.kst[t]), -1.0f, Fc, 1.0f, 0.0f);
         Tensor t3 = e.lin(t2, 1.0f, e.mul(sc.kst[t], sc.ks[t]), -1.0f, 0.0f);
@@ -209,8 +202,7 @@ static Tensor forward_loss(motifs_model* m, Graph& gr, bool train) {
         bFc = gr.bankF(Fc, gF);
         // theta (:370)
         Tensor FXn = gr.synF(X, bFc);
-        Tensor th1 = theta ? e.lin(theta, 1.0f, FXn, 1.0f, 0.0f) : FXn;
-        theta = e.lin(th1, 1.0f, ZYm, -1.0f, 0.0f);
+        theta = e.lin3(FXn, 1.0f, ZYm, -1.0f, theta, 1.0f);
     }
     e.note("Dfinal", Dc);
     e.note("Ffinal", Fc);
