@@ -149,7 +149,15 @@ def main():
     ctx.enable_timing(False)
     dense_bytes = nb * L + K * 4 * PL * 2 + nb * K * Lout * 2      # SURVEY §8d dense-score contract
     dense_gbs = dense_bytes / (dense_ms / dense_n * 1e-3) / 1e9
-    del dense
+    # full-size check of the dense tensor against the hit records of the same reads (forward strand): the same
+    # number of positive entries and the same sum of score bit patterns
+    nrec = ctx.pwm_scan_hits_dev(bank, lens, dcodes.data_ptr(), nb, L, 0, hits[0].data_ptr(), hsc[0].data_ptr(), cap, n0=rank * N)
+    pos = dense > 0
+    dense_pos = int(pos.sum().item())
+    dense_sum = int(dense[pos].to(torch.int64).sum().item())
+    rec_sum = int(hsc[0][:nrec].to(torch.int64).sum().item())
+    assert dense_pos == nrec and dense_sum == rec_sum, f"dense tensor disagrees with the hit records: {dense_pos} vs {nrec}"
+    del dense, pos
 
     # ---- conv-train step (BASELINE metric, second half): unrolled-ADMM forward/backward + AdaBelief ----
     train = None
@@ -264,7 +272,8 @@ def main():
                     "by the matrix cores and the exact re-scoring, not by HBM; dense_kernel is the a17 dense-score contract",
         },
         "dense_kernel": {
-            "kernel": "scan_kernel<12,DENSE> (a17 greedy_search! drop-in, writes (K,nb,L-len+1) fp16)",
+            "kernel": "scan_dense_mfma<3,4> (a17 greedy_search! drop-in, writes (K,nb,L-len+1) fp16: zeros + exact scores of the hits)",
+            "checked": "positive entries == hit records of the same reads, score checksums equal",
             "bound": "hbm", "achieved": dense_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": dense_gbs / HBM_PEAK_GBS, "avg_launch_ms": dense_ms / dense_n, "seqs_per_launch": nb,
             "bases_per_s_one_strand": nb * L / (dense_ms / dense_n * 1e-3),

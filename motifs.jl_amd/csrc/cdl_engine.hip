@@ -521,6 +521,67 @@ __global__ __launch_bounds__(256) void k_toep(const float* __restrict__ A, const
 // the FMA kernel up to summation order).  Block = 2 waves, each a 32-row x 32-column tile; LDS stages of 32.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// The same staging split in two, so that the global loads of the next reduction step are in flight while the
+// matrix cores work on the current one: load() fills registers, store() moves them to the wave's LDS tile.
+template <int ROWS>
+struct RowTile {
+    static constexpr int NJ = ROWS / 8;           // ROWS*8 float4 per tile, 64 lanes
+    const float* base[NJ];                        // sequence start of the lane's row j
+    int e0[NJ];                                   // flat offset of the row's window start + the lane's column group
+    bool rowok[NJ];
+    int cg;
+    __device__ __forceinline__ void init(const float* __restrict__ A, const ToepGeom& gm, int g, int loc0, int lane) {
+        const int grp_rows = gm.B * gm.P;
+        cg = (lane & 7) * 4;
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            const int row = (lane + j * 64) >> 3;
+            const int loc = loc0 + row;
+            rowok[j] = loc < grp_rows;
+            const int lc = rowok[j] ? loc : grp_rows - 1;
+            const int sl = lc / gm.P, p = lc - sl * gm.P;
+            base[j] = A + (size_t)(g * gm.B + sl) * gm.lda;
+            e0[j] = gm.a0 + p * gm.sa + cg;
+        }
+    }
+    __device__ __forceinline__ void load(const ToepGeom& gm, int q0, float4 (&v)[NJ]) const {
+        bool allfast = true;
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            const int e = e0[j] + q0;
+            allfast = allfast && q0 + cg + 3 < gm.Q && e >= 0 && e + 3 < gm.amax && (((uintptr_t)(base[j] + e)) & 15) == 0;
+        }
+        if (__all(allfast)) {                     // wave-uniform: the loads below are unconditional and pipeline
+#pragma unroll
+            for (int j = 0; j < NJ; j++) v[j] = *(const float4*)(base[j] + e0[j] + q0);
+        } else {
+#pragma unroll
+            for (int j = 0; j < NJ; j++) {
+                const int e = e0[j] + q0, q = q0 + cg;
+                float t[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const bool ok = q + u < gm.Q && e + u >= 0 && e + u < gm.amax;
+                    const float x = base[j][ok ? e + u : 0];
+                    t[u] = ok ? x : 0.0f;
+                }
+                v[j] = make_float4(t[0], t[1], t[2], t[3]);
+            }
+        }
+    }
+    __device__ __forceinline__ void store(const float4 (&v)[NJ], float (*As)[33], int lane) const {
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            const int row = (lane + j * 64) >> 3;
+            const float4 w = rowok[j] ? v[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+            As[row][cg + 0] = w.x;
+            As[row][cg + 1] = w.y;
+            As[row][cg + 2] = w.z;
+            As[row][cg + 3] = w.w;
+        }
+    }
+};
+
 // Stage a [ROWS][32] tile of Toeplitz rows into a wave-private LDS tile (row stride 33).  Rows are
 // (group-local) indices loc0.. of group g; lanes walk float4 columns.
 template <int ROWS>
@@ -597,9 +658,11 @@ __global__ __launch_bounds__(512) void k_toep_mfma(const float* __restrict__ A, 
     f32x16 accv;
 #pragma unroll
     for (int i = 0; i < 16; i++) accv[i] = 0.0f;
-    for (int q0 = ks * BK; q0 < gm.Q; q0 += KS * BK) {
-        stage_rows<32>(A, gm, g, loc0, q0, As[wave], lane);
-        float bt[16];
+    RowTile<32> rows;
+    rows.init(A, gm, g, loc0, lane);
+    float4 va[4];
+    float bt[16];
+    auto load_b = [&](int q0) {
 #pragma unroll
         for (int j = 0; j < 16; j++) {
             const int f = lane + j * 64, kk = f >> 5, n = f & 31;
@@ -608,6 +671,13 @@ __global__ __launch_bounds__(512) void k_toep_mfma(const float* __restrict__ A, 
             const float x = Bg[ok ? (size_t)q * gm.N + n0 + n : 0];
             bt[j] = ok ? x : 0.0f;
         }
+    };
+    if (ks * BK < gm.Q) {
+        rows.load(gm, ks * BK, va);
+        load_b(ks * BK);
+    }
+    for (int q0 = ks * BK; q0 < gm.Q; q0 += KS * BK) {
+        rows.store(va, As[wave], lane);
 #pragma unroll
         for (int j = 0; j < 16; j++) {
             const int f = lane + j * 64;
@@ -615,6 +685,10 @@ __global__ __launch_bounds__(512) void k_toep_mfma(const float* __restrict__ A, 
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        if (q0 + KS * BK < gm.Q) {                 // next step's global loads fly while the MFMAs below run
+            rows.load(gm, q0 + KS * BK, va);
+            load_b(q0 + KS * BK);
+        }
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
             const float a = As[wave][lane & 31][kk + (lane >> 5)];

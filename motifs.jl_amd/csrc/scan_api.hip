@@ -267,6 +267,57 @@ static int cached_bank(motifs_ctx* c, const uint16_t* pwms, const int64_t* lens,
     return MOTIFS_OK;
 }
 
+// The arguments the candidate kernel and the row kernels share, for `ns` reads starting at `codes` (cells in c->cnt).
+static void scan_args(motifs_ctx* c, const BankSlot& bank, int K, const uint8_t* codes, int64_t ns, int L, int Lout, int batch,
+                      int rpr, CandArgs& a, FillArgs& f) {
+    const int PG = cand_tile_group(bank.lenp);
+    const int parts = (batch + rpr - 1) / rpr;
+    const int64_t nb = (ns + batch - 1) / batch;
+    a.afrag = (const uint4*)bank.afrag.p;
+    a.cinit = (const float*)bank.cinit.p;
+    a.codes = codes;
+    a.cells = (uint32_t*)c->cnt.p;
+    a.lenp = bank.lenp;
+    a.ntiles = bank.ntiles;
+    a.uniform_eps = bank.uniform_eps;
+    a.d.N = ns;
+    a.d.L = L;
+    a.d.pitch = motifs_codes_pitch(L);
+    a.d.Lout = Lout;
+    a.d.nch = bank.nch;
+    a.d.batch = batch;
+    a.d.ohlen = (Lout + 31) / 32 * 32 + bank.lenp;
+    a.d.used_tiles = (K + 31) / 32;
+    {
+        int64_t spw = ns * (bank.ntiles / PG) / 16384;
+        a.d.spw = (int)std::max<int64_t>(1, std::min<int64_t>(spw, 16));
+    }
+    f.masks = (const uint4*)c->cnt.p;
+    f.parts = parts;
+    f.rpr = rpr;
+    f.nrows = nb * Lout * parts;
+    f.tab = (const uint32_t*)bank.tab.p;
+    f.tabk = (const uint16_t*)bank.tabk.p;
+    f.tabk_stride = bank.tabk_stride;
+    f.codes = codes;
+    f.nch = bank.nch;
+    f.batch = batch;
+    f.Lout = Lout;
+    f.LoutP = Lout;
+    f.lenp = bank.lenp;
+    f.KP = bank.KP;
+    f.pitch = a.d.pitch;
+    f.lim = (const int32_t*)bank.lim.p;
+    f.N = ns;
+    f.K = K;
+    f.lim_min = L - bank.maxlen_true;
+    uint32_t d = (uint32_t)bank.nch, sh = 0;
+    while ((1u << sh) < d) sh++;
+    f.div_nch.d = d;
+    f.div_nch.s = sh;
+    f.div_nch.m = d == 1 ? 0u : (uint32_t)((((uint64_t)1 << 32) * (((uint64_t)1 << sh) - d)) / d + 1);
+}
+
 // Hit records through the matrix cores: candidates (scan_cand_kernel) -> exact verification, staged hits and
 // row counts (stage_hits) -> scan -> records (emit_records); no host round trip in between.  The bank has already been uploaded (tab, lim).
 static int scan_hits_mfma(motifs_ctx* c, const BankSlot& bank, int K, const uint8_t* codes_dev, int64_t N, int L, int Lout, int64_t n0,
@@ -294,38 +345,14 @@ static int scan_hits_mfma(motifs_ctx* c, const BankSlot& bank, int K, const uint
     int64_t* totals = (int64_t*)c->small.p;
     MOTIFS_HIP_CHECK(hipMemsetAsync(c->small.p, 0, 64, c->stream));
     int64_t* h_total = (int64_t*)c->pinned;
-    const int PG = cand_tile_group(bank.lenp);
-    const int ntile_w = (Lout + 31) / 32;
 
     int launch_no = 0;
     for (int64_t s0 = 0; s0 < N; s0 += sb, launch_no++) {
         const int64_t ns = std::min<int64_t>(sb, N - s0);
         const int64_t nb = (ns + batch - 1) / batch;
         CandArgs a{};
-        a.afrag = (const uint4*)bank.afrag.p;
-        a.cinit = (const float*)bank.cinit.p;
-        a.codes = codes_dev + (size_t)s0 * motifs_codes_pitch(L);
-        a.cells = (uint32_t*)c->cnt.p;
-        a.lenp = bank.lenp;
-        a.ntiles = bank.ntiles;
-        a.uniform_eps = bank.uniform_eps;
-        a.d.N = ns;
-        a.d.L = L;
-        a.d.pitch = motifs_codes_pitch(L);
-        a.d.Lout = Lout;
-        a.d.nch = bank.nch;
-        a.d.batch = batch;
-        a.d.ohlen = ntile_w * 32 + bank.lenp;
-        a.d.used_tiles = (K + 31) / 32;
-        {
-            int64_t spw = ns * (bank.ntiles / PG) / 16384;
-            a.d.spw = (int)std::max<int64_t>(1, std::min<int64_t>(spw, 16));
-        }
         FillArgs f{};
-        f.masks = (const uint4*)c->cnt.p;
-        f.parts = parts;
-        f.rpr = rpr;
-        f.nrows = nb * Lout * parts;
+        scan_args(c, bank, K, codes_dev + (size_t)s0 * motifs_codes_pitch(L), ns, L, Lout, batch, rpr, a, f);
         f.row_sum = (uint32_t*)c->tilesum.p;
         f.blk_base = (unsigned long long*)c->off.p;
         f.staging = (uint32_t*)c->staging.p;
@@ -334,33 +361,11 @@ static int scan_hits_mfma(motifs_ctx* c, const BankSlot& bank, int K, const uint
         f.base_in = totals + (launch_no & 1);
         f.total = totals + ((launch_no + 1) & 1);
         f.cap = cap;
-        f.tab = (const uint32_t*)bank.tab.p;
-        f.tabk = (const uint16_t*)bank.tabk.p;
-        f.tabk_stride = bank.tabk_stride;
-        f.codes = a.codes;
         f.hits = (HitRec*)hits_dev;
         f.hit_scores = hit_scores_dev;
         f.pwm_counts = per_pwm_counts_dev ? (int64_t*)c->pwmcnt.p : nullptr;
         f.n0 = n0 + s0;
-        f.nch = bank.nch;
-        f.batch = batch;
-        f.Lout = Lout;
-        f.LoutP = Lout;
-        f.lenp = bank.lenp;
-        f.KP = bank.KP;
-        f.pitch = a.d.pitch;
         f.hist_bins = (per_pwm_counts_dev && 2 * bank.KP <= FILL_HIST_MAX) ? 2 * bank.KP : 0;
-        f.lim = (const int32_t*)bank.lim.p;
-        f.N = ns;
-        f.K = K;
-        f.lim_min = L - bank.maxlen_true;
-        {
-            uint32_t d = (uint32_t)bank.nch, sh = 0;
-            while ((1u << sh) < d) sh++;
-            f.div_nch.d = d;
-            f.div_nch.s = sh;
-            f.div_nch.m = d == 1 ? 0u : (uint32_t)((((uint64_t)1 << 32) * (((uint64_t)1 << sh) - d)) / d + 1);
-        }
         if (ns < nb * batch)   // cells of reads the last batch does not have are never written by the scan
             MOTIFS_HIP_CHECK(hipMemsetAsync(c->cnt.p, 0, (size_t)nb * per_batch, c->stream));
         {
@@ -369,7 +374,7 @@ static int scan_hits_mfma(motifs_ctx* c, const BankSlot& bank, int K, const uint
         }
         {
             KernelTimer t(c, KS_SCAN_OFFSETS);
-            MOTIFS_HIP_CHECK(launch_stage_hits(f, emit, c->stream));
+            MOTIFS_HIP_CHECK(launch_stage_hits(f, emit ? 1 : 0, c->stream));
             MOTIFS_HIP_CHECK(launch_row_scan(f, c->stream));
         }
         if (emit) {
@@ -441,6 +446,7 @@ void motifs_ctx_destroy(motifs_ctx* c) {
         b->release();
     for (BankSlot& bs : c->bank_slot)
         for (DevBuf* b : {&bs.tab, &bs.lim, &bs.afrag, &bs.cinit, &bs.tabk}) b->release();
+
     if (c->pinned) (void)hipHostFree(c->pinned);
     resolve_timing(c);
     for (hipEvent_t e : c->free_events) (void)hipEventDestroy(e);
@@ -517,6 +523,36 @@ int motifs_pwm_scan_dense_dev(motifs_ctx* c, const uint16_t* pwms_fp16, const in
     if (!c || N < 0 || L <= 0 || (N > 0 && (!codes_dev || !scores_dev))) {
         set_error("motifs_pwm_scan_dense_dev: bad argument");
         return MOTIFS_ERR_INVALID;
+    }
+    if (!c->scan_valu && K % 8 == 0) {
+        // Matrix-core path: candidates (scan_cand_kernel) -> exact scores of the hits streamed into the tensor
+        // together with the zeros around them (stage_hits, mode 2): every byte written once, in linear order.
+        BankSlot* bs = nullptr;
+        const int rcode = cached_bank(c, pwms_fp16, lens, K, maxlen, 0, L, &bs);
+        if (rcode) return rcode;
+        const int Lout = L - bs->minlen + 1;
+        if (ld_l < std::max(Lout, 0)) {
+            set_error("motifs_pwm_scan_dense_dev: ld_l=%lld < L-minlen+1=%d", (long long)ld_l, Lout);
+            return MOTIFS_ERR_INVALID;
+        }
+        if (N == 0) return MOTIFS_OK;
+        const size_t cells_bytes = (size_t)std::max(Lout, 0) * N * bs->nch * 16;
+        if (cells_bytes <= ((size_t)16 << 30) && N < ((int64_t)1 << 31) && (int64_t)Lout * ((N + dense_row_reads(bs->nch) - 1) / dense_row_reads(bs->nch)) < ((int64_t)1 << 31)) {
+            MOTIFS_HIP_CHECK(hipSetDevice(c->device));
+            const int lo = std::max(Lout, 0);
+            KernelTimer t(c, KS_SCAN_DENSE);
+            if (ld_l > lo)  // the l-planes no window reaches (the reference pre-zeroes the tensor, :75)
+                MOTIFS_HIP_CHECK(hipMemsetAsync(scores_dev + (size_t)K * N * lo, 0, (size_t)K * N * (ld_l - lo) * 2, c->stream));
+            if (Lout <= 0) return MOTIFS_OK;
+            MOTIFS_HIP_CHECK(c->cnt.reserve(cells_bytes));
+            CandArgs a{};
+            FillArgs f{};
+            scan_args(c, *bs, K, codes_dev, N, L, Lout, (int)N, dense_row_reads(bs->nch), a, f);   // one "batch": cells in (l, n, chunk) order
+            f.dense = scores_dev;
+            MOTIFS_HIP_CHECK(launch_cand(a, c->stream));
+            MOTIFS_HIP_CHECK(launch_stage_hits(f, 2, c->stream));
+            return MOTIFS_OK;
+        }
     }
     PackedBank bank;
     int rcode = pack_bank(pwms_fp16, lens, K, maxlen, 0, L, bank);

@@ -69,6 +69,7 @@ struct FillArgs {
     const uint16_t* tabk;         // [K][tabk_stride] binary16 re-scoring table: [ind][5] per PWM, column 4 = +0
     int tabk_stride;              // halves per PWM row (an odd number of dwords)
     uint32_t* staging;            // [nrows][row_slots] staged hit words
+    uint16_t* dense;              // mode 2: (K, N, ld_l) score tensor; planes l < Lout are written in full
     int row_slots;
     uint32_t* row_excl;           // [nrows] hits before the row inside its block of 1024 rows
     unsigned long long* blk_base; // [ceil(nrows / 1024)] block totals, then records before the block
@@ -103,7 +104,9 @@ struct CandArgs {
 int cand_tile_group(int lenp);
 hipError_t launch_cand(const CandArgs& a, hipStream_t st);
 int stage_row_reads(int nch);                                              // reads per row of cells
-hipError_t launch_stage_hits(const FillArgs& a, bool stage, hipStream_t st);   // candidates -> staged hits + row counts (+ histogram)
+int dense_row_reads(int nch);                                              // the same for the dense tensor (mode 2)
+// candidates -> row counts (mode 0), + staged hits (1), or a17's dense tensor, zeros included (2); + histogram
+hipError_t launch_stage_hits(const FillArgs& a, int mode, hipStream_t st);
 hipError_t launch_row_scan(const FillArgs& a, hipStream_t st);             // row counts -> offsets; *total = *base_in + hits
 hipError_t launch_emit_records(const FillArgs& a, hipStream_t st);         // staged hits -> records
 hipError_t launch_fill_scan(const FillArgs& a, hipStream_t st);            // exclusive scan of row_sum

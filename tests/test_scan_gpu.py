@@ -107,8 +107,11 @@ def test_dense_matches_greedy_search_layout(torch_cuda, ctx, pkg):
     """a17 drop-in: the (K, nb, 4L) tensor of _h3_1_alignment.jl:75-80, zeros included."""
     torch = torch_cuda
     sy = pkg.synth
-    for (N, L, K, lo, hi) in [(19, 50, 10, 6, 12), (8, 33, 7, 5, 9), (12, 64, 140, 12, 12)]:
+    # K % 8 == 0 takes the matrix-core kernel (zeros + re-scored candidates), the others the packed-add kernel
+    for (N, L, K, lo, hi) in [(19, 50, 10, 6, 12), (8, 33, 7, 5, 9), (12, 64, 140, 12, 12), (37, 70, 200, 12, 12),
+                              (21, 45, 136, 5, 12), (9, 90, 64, 17, 24), (23, 41, 8, 3, 8), (6, 120, 264, 13, 20)]:
         codes = sy.gen_codes(N, L, 9 + K)
+        codes[N // 2, L // 2] = 4                  # an all-zero column
         pwms, lens = sy.gen_pwm_bank(K, 10 + K, len_lo=lo, len_hi=hi, alpha=0.6)
         bank = sy.pad_bank(pwms, lens)
         want = so.greedy_search(bank, lens, sy.codes_to_onehot(codes).astype(np.float16))  # (4L, N, K)
