@@ -233,6 +233,42 @@ int motifs_hits_filter_dev(motifs_ctx* ctx, const motifs_hit* hits_dev, const ui
 int motifs_hits_count_matrices_dev(motifs_ctx* ctx, const motifs_hit* hits_dev, int64_t n, const uint8_t* codes_dev, int L,
                                    int64_t n0, const int64_t* lens, int K, int maxlen, int comp, uint32_t* counts_dev);
 
+/* ---- consumers of the code records (src/inference/_2_enumerate.jl) --------------------- */
+
+/* value_type (_0_const.jl:9-10): (seq_num::UInt32, pos::UInt16, comp::Bool); comp is always false here
+ * (create_value, _2_enumerate.jl:2). */
+typedef struct motifs_triplet_val {
+    uint32_t seq_num;   /* the index of the scanning range, 1-based (enumerate_triplets passes `ind`, :53) */
+    uint16_t pos;       /* position of the first component */
+    uint16_t comp;
+} motifs_triplet_val;
+/* composition_key_type (_0_const.jl:6-7) packed into 64 bits: f1 << 48 | f2 << 40 | f3 << 32 | d12 << 16 | d13
+ * (len = d13 + h is implied). */
+
+/* filter_code_components_using_quantile! (:10-13), first half: hist_dev[b] = number of records whose
+ * magnitude has the binary16 bit pattern b (65536 counters).  The caller takes the two order statistics
+ * Statistics.quantile interpolates between from it. */
+int motifs_codes_mag_histogram_dev(motifs_ctx* ctx, const motifs_code_rec* recs_dev, int64_t n, uint32_t* hist_dev);
+/* second half: keep the records with Float64(mag) > thresh, order preserved. */
+int motifs_codes_filter_dev(motifs_ctx* ctx, const motifs_code_rec* recs_dev, int64_t n, double thresh,
+                            motifs_code_rec* out_dev, int64_t* n_out);
+/* enumerate_triplets (:50-65): offsets_dev[r] = triplets of the ranges before range r (C(len, 3) each). */
+int motifs_triplets_offsets_dev(motifs_ctx* ctx, const uint32_t* range_len_dev, int64_t nranges, int64_t* offsets_dev,
+                                int64_t* total);
+/* For every scanning range (0-based start, length; at most 256 records) the records are sorted by position
+ * (stable, :57) and every i < j < k (:59-63) yields a packed key and a value at offsets_dev[r] + its rank:
+ * exactly the order in which insert_H! (:37-46) sees them.  Entries past cap are dropped. */
+int motifs_triplets_enumerate_dev(motifs_ctx* ctx, const motifs_code_rec* recs_dev, const uint32_t* range_start_dev,
+                                  const uint32_t* range_len_dev, int64_t nranges, int h, const int64_t* offsets_dev,
+                                  uint64_t* keys_dev, motifs_triplet_val* vals_dev, int64_t cap);
+/* The Dictionary those insertions build: unique keys in first-insertion order (uniq_keys_dev, first_dev =
+ * index of the first triplet with the key, counts_dev), group_off_dev = exclusive scan of the counts, and
+ * perm_dev[group_off[t] .. +counts[t]) = the triplet indices of key t in insertion order.  All outputs
+ * hold n entries at most. */
+int motifs_triplets_group_dev(motifs_ctx* ctx, const uint64_t* keys_dev, int64_t n, uint64_t* uniq_keys_dev,
+                              int64_t* first_dev, int64_t* counts_dev, int64_t* group_off_dev, int64_t* perm_dev,
+                              int64_t* n_unique);
+
 #ifdef __cplusplus
 }
 #endif

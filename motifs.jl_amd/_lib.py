@@ -20,6 +20,7 @@ SCAN_MAX_LEN = 32
 
 HIT_DTYPE = np.dtype([("m", "<u4"), ("n", "<u4"), ("l", "<u4")])
 # stored_code_component_t (_0_const.jl:3-4) with Julia's 12-byte isbits layout
+TRIPLET_VAL_DTYPE = np.dtype({"names": ["seq_num", "pos", "comp"], "formats": ["<u4", "<u2", "<u2"], "itemsize": 8})
 CODE_DTYPE = np.dtype({"names": ["position", "fil", "seq", "mag"], "formats": ["<u2", "<u2", "<u4", "<f2"],
                        "offsets": [0, 2, 4, 8], "itemsize": 12})
 
@@ -79,6 +80,11 @@ SIGNATURES = {
     "motifs_hits_threshold_counts_dev": (_int, [_p, _p, _p, _i64, _int, _p, _int, _p]),
     "motifs_hits_filter_dev": (_int, [_p, _p, _p, _i64, _int, _p, _p, _p, C.POINTER(_i64)]),
     "motifs_hits_count_matrices_dev": (_int, [_p, _p, _i64, _p, _int, _i64, _p, _int, _int, _int, _p]),
+    "motifs_codes_mag_histogram_dev": (_int, [_p, _p, _i64, _p]),
+    "motifs_codes_filter_dev": (_int, [_p, _p, _i64, C.c_double, _p, C.POINTER(_i64)]),
+    "motifs_triplets_offsets_dev": (_int, [_p, _p, _i64, _p, C.POINTER(_i64)]),
+    "motifs_triplets_enumerate_dev": (_int, [_p, _p, _p, _p, _i64, _int, _p, _p, _p, _i64]),
+    "motifs_triplets_group_dev": (_int, [_p, _p, _i64, _p, _p, _p, _p, _p, C.POINTER(_i64)]),
     "motifs_pwm_scan": (
         _int,
         [_p, _p, _p, _int, _int, _p, _int, _i64, _int, _int, _p, _p, _i64, C.POINTER(_i64), _p],
@@ -219,6 +225,30 @@ class Context:
         lens = np.ascontiguousarray(lens, dtype=np.int64)
         check(lib().motifs_hits_count_matrices_dev(self._h, _p(hits_ptr), int(n), _p(codes_ptr), int(L), int(n0), _np_ptr(lens), int(K),
                                                    int(maxlen), int(bool(comp)), _p(counts_ptr)))
+
+    # ---- consumers of the code records ----
+    def codes_mag_histogram_dev(self, recs_ptr, n, hist_ptr):
+        check(lib().motifs_codes_mag_histogram_dev(self._h, _p(recs_ptr), int(n), _p(hist_ptr)))
+
+    def codes_filter_dev(self, recs_ptr, n, thresh, out_ptr):
+        n_out = _i64(0)
+        check(lib().motifs_codes_filter_dev(self._h, _p(recs_ptr), int(n), float(thresh), _p(out_ptr), C.byref(n_out)))
+        return n_out.value
+
+    def triplets_offsets_dev(self, range_len_ptr, nranges, offsets_ptr):
+        total = _i64(0)
+        check(lib().motifs_triplets_offsets_dev(self._h, _p(range_len_ptr), int(nranges), _p(offsets_ptr), C.byref(total)))
+        return total.value
+
+    def triplets_enumerate_dev(self, recs_ptr, range_start_ptr, range_len_ptr, nranges, h, offsets_ptr, keys_ptr, vals_ptr, cap):
+        check(lib().motifs_triplets_enumerate_dev(self._h, _p(recs_ptr), _p(range_start_ptr), _p(range_len_ptr), int(nranges), int(h),
+                                                  _p(offsets_ptr), _p(keys_ptr), _p(vals_ptr), int(cap)))
+
+    def triplets_group_dev(self, keys_ptr, n, uniq_ptr, first_ptr, counts_ptr, group_off_ptr, perm_ptr):
+        nu = _i64(0)
+        check(lib().motifs_triplets_group_dev(self._h, _p(keys_ptr), int(n), _p(uniq_ptr), _p(first_ptr), _p(counts_ptr), _p(group_off_ptr),
+                                              _p(perm_ptr), C.byref(nu)))
+        return nu.value
 
     def pwm_scan(self, pwms, lens, data, kind, N, L, rc, cap=None, want_counts=False):
         """Host-buffer scan (the entry Julia's ccall binds).  cap=None sizes the

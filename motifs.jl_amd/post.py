@@ -90,3 +90,91 @@ def posdicts2countmats(ctx, strands, codes_dev_ptr, L, lens, maxlen, n0=0, ps=0.
     ctx.synchronize()
     c = counts.cpu().numpy().astype(np.float32)
     return [(c[k, : int(lens[k]), :].T + np.float32(ps)).astype(np.float16) for k in range(K)]
+
+
+# ---- consumers of the code records (src/inference/_2_enumerate.jl) ---------------------------------
+def code_quantile(ctx, recs_t, n, p):
+    """Statistics.quantile of the Float16 magnitudes (alpha = beta = 1) from the device histogram of their bit
+    patterns: the two order statistics it interpolates between, then a + gamma*(b - a) as Julia evaluates it."""
+    torch = _torch()
+    hist = torch.empty(65536, dtype=torch.int32, device=recs_t.device)
+    ctx.codes_mag_histogram_dev(recs_t.data_ptr(), n, hist.data_ptr())
+    ctx.synchronize()
+    hcnt = hist.cpu().numpy().astype(np.int64)
+    # ascending value order of the bit patterns: negative values (sign bit set) descend with their pattern
+    bits = np.concatenate([np.arange(0xFFFF, 0x7FFF, -1), np.arange(0, 0x8000)]).astype(np.uint16)
+    cum = np.cumsum(hcnt[bits])
+    aleph = n * p + (1.0 - p)
+    j = int(min(max(np.trunc(aleph), 1), max(n - 1, 1)))
+    g = float(min(max(aleph - j, 0.0), 1.0))
+
+    def kth(k):                       # k-th smallest, 1-based
+        return np.array([bits[int(np.searchsorted(cum, k, side="left"))]], dtype=np.uint16).view(np.float16)[0]
+
+    a = kth(j) if n > 1 else kth(1)
+    b = kth(j + 1) if n > 1 else a
+    return float(a) + g * float(np.float16(b - a))
+
+
+def filter_code_components(ctx, recs_t, n, p):
+    """filter_code_components_using_quantile! (:10-13) on a device record array; returns (filtered tensor, count, threshold)."""
+    torch = _torch()
+    thr = code_quantile(ctx, recs_t, n, p)
+    out = torch.empty_like(recs_t)
+    m = ctx.codes_filter_dev(recs_t.data_ptr(), n, thr, out.data_ptr())
+    return out, m, thr
+
+
+def scanning_ranges(seq):
+    """get_scanning_range_of_filtered_code_components (:25-35) on the `seq` column (host): 0-based starts and
+    lengths of the ranges the reference pushes (its counter advances by one per mismatch; the last range is
+    never pushed).  c[i+1] = min(seq[i], c[i] + 1), so the counter is a running minimum and the loop vectorises."""
+    seq = np.asarray(seq, dtype=np.int64)
+    n = len(seq)
+    if n == 0:
+        return np.zeros(0, np.uint32), np.zeros(0, np.uint32)
+    i = np.arange(n, dtype=np.int64)
+    c_next = np.minimum(np.minimum.accumulate(seq - i) + i, i + 2)          # counter after element i (it starts at 1)
+    c = np.concatenate([[1], c_next[:-1]])
+    ev = np.nonzero(seq != c)[0]                                            # pushes happen at these elements
+    starts = np.concatenate([[0], ev[:-1]]) if len(ev) else np.zeros(0, np.int64)
+    lens = ev - starts
+    return starts.astype(np.uint32), lens.astype(np.uint32)
+
+
+def enumerate_triplets(ctx, recs_t, n, h):
+    """enumerate_triplets (:50-65) on a (filtered) device record array.  Returns a dict of numpy arrays describing
+    the Dictionary the reference builds: keys (U, 6) = (f1, f2, f3, d12, d13, len) in insertion order, counts,
+    offsets, and values (seq_num, pos) grouped by key in insertion order."""
+    torch = _torch()
+    dev = recs_t.device
+    seq = recs_t.view(torch.uint8).view(-1, 12)[:n, 4:8].contiguous().view(torch.int32).cpu().numpy().ravel().astype(np.int64)
+    starts, lens = scanning_ranges(seq)
+    nr = len(starts)
+    empty = {"keys": np.zeros((0, 6), np.int64), "counts": np.zeros(0, np.int64), "offsets": np.zeros(1, np.int64),
+             "values": np.zeros(0, dtype=_lib.TRIPLET_VAL_DTYPE), "n_triplets": 0, "ranges": (starts, lens)}
+    if nr == 0:
+        return empty
+    st = torch.from_numpy(starts.view(np.int32)).to(dev)
+    ln = torch.from_numpy(lens.view(np.int32)).to(dev)
+    offs = torch.empty(nr, dtype=torch.int64, device=dev)
+    total = ctx.triplets_offsets_dev(ln.data_ptr(), nr, offs.data_ptr())
+    if total == 0:
+        return empty
+    keys = torch.empty(total, dtype=torch.int64, device=dev)
+    vals = torch.empty(total, dtype=torch.int64, device=dev)
+    ctx.triplets_enumerate_dev(recs_t.data_ptr(), st.data_ptr(), ln.data_ptr(), nr, h, offs.data_ptr(), keys.data_ptr(), vals.data_ptr(), total)
+    uniq = torch.empty(total, dtype=torch.int64, device=dev)
+    first = torch.empty(total, dtype=torch.int64, device=dev)
+    counts = torch.empty(total, dtype=torch.int64, device=dev)
+    goff = torch.empty(total, dtype=torch.int64, device=dev)
+    perm = torch.empty(total, dtype=torch.int64, device=dev)
+    U = ctx.triplets_group_dev(keys.data_ptr(), total, uniq.data_ptr(), first.data_ptr(), counts.data_ptr(), goff.data_ptr(), perm.data_ptr())
+    uk = uniq[:U].cpu().numpy().view(np.uint64)
+    d13 = (uk & 0xFFFF).astype(np.int64)
+    kk = np.stack([(uk >> 48) & 0xFF, (uk >> 40) & 0xFF, (uk >> 32) & 0xFF, (uk >> 16) & 0xFFFF, uk & 0xFFFF], axis=1).astype(np.int64)
+    kk = np.concatenate([kk, (d13 + h)[:, None]], axis=1)
+    cnt = counts[:U].cpu().numpy()
+    v = vals[perm].cpu().numpy().view(_lib.TRIPLET_VAL_DTYPE)
+    return {"keys": kk, "counts": cnt, "offsets": np.concatenate([[0], np.cumsum(cnt)]), "values": v, "n_triplets": int(total),
+            "ranges": (starts, lens)}

@@ -5,6 +5,9 @@ PARITY UNPINNED (the reference has no fixtures); pinned by tests/test_oracle_pos
   get_hits / get_min_score / get_max_score / filter_position_by_best_thresh!
                             src/inference/_s2_filter_pos_w_scores.jl:3-35, :116-125
   posdicts2countmats        src/inference/_h6_positions2countmat.jl:40-55 (+ submat_comlement, _3_make_pfms.jl:49-52)
+  filter_code_components_using_quantile!, get_scanning_range_of_filtered_code_components, insert_H!,
+  enumerate_triplets        src/inference/_2_enumerate.jl:10-13, :25-35, :37-46, :50-65
+                            (Statistics.quantile as in Julia 1.9's stdlib: alpha = beta = 1)
 """
 import numpy as np
 
@@ -78,3 +81,59 @@ def countmats(m, n, l, comp, codes, lens, K, maxlen):
             else:
                 out[mi - 1, ind, b] += 1
     return out
+
+
+# ---- src/inference/_2_enumerate.jl ---------------------------------------------------------------------------
+def julia_quantile_f16(mags, p):
+    """Statistics.quantile(v::Vector{Float16}, p::Float64) with the default alpha = beta = 1: the sorted copy,
+    aleph = n*p + (1 - p), j = clamp(trunc(aleph), 1, n-1), gamma = clamp(aleph - j, 0, 1),
+    a + gamma*(b - a) where b - a is a Float16 subtraction and the rest Float64."""
+    v = np.sort(np.asarray(mags, dtype=np.float16))
+    n = len(v)
+    m = 1.0 + p * (1.0 - 1.0 - 1.0)
+    aleph = n * p + m
+    j = int(min(max(np.trunc(aleph), 1), max(n - 1, 1)))
+    g = float(min(max(aleph - j, 0.0), 1.0))
+    if n == 1:
+        a = b = v[0]
+    else:
+        a, b = v[j - 1], v[j]
+    return float(a) + g * float(np.float16(b - a))
+
+
+def filter_code_components_using_quantile(recs, p):
+    """recs: structured array (position, fil, seq, mag).  Keeps mag > quantile (:12), order preserved."""
+    thr = julia_quantile_f16(recs["mag"], p)
+    return recs[recs["mag"].astype(np.float64) > thr], thr
+
+
+def scanning_ranges(recs):
+    """get_scanning_range_of_filtered_code_components (:25-35), literally: 1-based inclusive (start, stop) pairs.
+    Note the reference's quirks, kept: cur_seq only ever advances by one, and the last range is never pushed."""
+    cur_seq, cur_range_start, ranges = 1, 1, []
+    seq = recs["seq"]
+    for i in range(1, len(recs) + 1):
+        if int(seq[i - 1]) != cur_seq:
+            ranges.append((cur_range_start, i - 1))
+            cur_range_start = i
+            cur_seq += 1
+    return ranges
+
+
+def enumerate_triplets(recs, ranges, h):
+    """enumerate_triplets (:50-65) + insert_H! (:37-46): dict key -> list of values, both in insertion order.
+    key = (f1, f2, f3, d12, d13, len), value = (seq_num = index of the range, pos of the first component, comp=False)."""
+    H = {}
+    for ind, (lo, hi) in enumerate(ranges, start=1):
+        store = recs[lo - 1:hi]
+        order = np.argsort(store["position"], kind="stable")       # sort(by = x -> x[1]) is stable
+        cs = store[order]
+        n = len(cs)
+        for i in range(n - 2):
+            for j in range(i + 1, n - 1):
+                for k in range(j + 1, n):
+                    d12 = int(cs["position"][j]) - int(cs["position"][i])
+                    d13 = int(cs["position"][k]) - int(cs["position"][i])
+                    key = (int(cs["fil"][i]), int(cs["fil"][j]), int(cs["fil"][k]), d12, d13, d13 + h)
+                    H.setdefault(key, []).append((ind, int(cs["position"][i]), False))
+    return H

@@ -53,3 +53,54 @@ def test_countmats_reverse_complement():
     assert fwd[0].tolist() == [[0, 1, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]]
     rc = po.countmats(np.array([1]), np.array([1]), np.array([2]), True, codes, lens, 1, 3)     # revcomp(CGT) = ACG
     assert rc[0].tolist() == [[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0]]
+
+
+# ---- src/inference/_2_enumerate.jl -----------------------------------------------------------------------------
+def _recs(rows):
+    from motifs_jl_amd._lib import CODE_DTYPE  # registered by conftest's pkg loader
+
+    out = np.zeros(len(rows), dtype=CODE_DTYPE)
+    for i, (p, f, s, m) in enumerate(rows):
+        out[i] = (p, f, s, np.float16(m))
+    return out
+
+
+def test_julia_quantile_known_answers(pkg):
+    v = np.array([1.0, 2.0, 3.0, 4.0, 5.0], dtype=np.float16)
+    # aleph = (n-1)p + 1: p=0.5 -> 3.0 exactly; p=0.35 -> j=2, gamma=0.4 -> 2 + 0.4*1
+    assert po.julia_quantile_f16(v, 0.5) == 3.0
+    assert abs(po.julia_quantile_f16(v, 0.35) - 2.4) < 1e-12
+    assert po.julia_quantile_f16(v[:1], 0.3) == 1.0
+    # same as numpy's default (type-7) quantile when b - a is exact in Float16
+    rng = np.random.default_rng(3)
+    w = (rng.integers(1, 2000, size=501) / 8.0).astype(np.float16)
+    for p in (0.01, 0.05, 0.25, 0.5, 0.75):
+        assert abs(po.julia_quantile_f16(w, p) - np.quantile(w.astype(np.float64), p)) < 1e-9
+
+
+def test_scanning_ranges_quirks_and_vectorised_form(pkg):
+    post = pkg.post
+    # seq 1,1,2,3,3: pushes (1,2) at i=3, (3,3) at i=4; the last range (4,5) is never pushed
+    r = _recs([(5, 1, 1, 1), (9, 2, 1, 1), (3, 1, 2, 1), (4, 1, 3, 1), (8, 2, 3, 1)])
+    assert po.scanning_ranges(r) == [(1, 2), (3, 3)]
+    # a gap (sequence 2 has no component): the counter lags and single-element ranges follow until it catches up
+    g = _recs([(1, 1, 1, 1), (2, 1, 3, 1), (3, 1, 3, 1), (4, 1, 3, 1), (5, 1, 4, 1), (6, 1, 5, 1)])
+    assert po.scanning_ranges(g) == [(1, 1), (2, 2), (3, 4), (5, 5)]
+    rng = np.random.default_rng(11)
+    for trial in range(30):
+        n = int(rng.integers(1, 80))
+        seq = np.sort(rng.integers(1, 25, size=n)).astype(np.uint32)
+        rr = _recs([(1, 1, int(s), 1) for s in seq])
+        want = po.scanning_ranges(rr)
+        st, ln = post.scanning_ranges(seq)
+        assert [(int(a) + 1, int(a) + int(b)) for a, b in zip(st, ln)] == want
+
+
+def test_enumerate_triplets_by_hand(pkg):
+    # one range of four components; stable sort by position puts (3,f2) (5,f1) (5,f3) (9,f1)
+    r = _recs([(5, 1, 1, 2.0), (9, 1, 1, 2.0), (3, 2, 1, 2.0), (5, 3, 1, 2.0), (7, 1, 2, 2.0)])
+    H = po.enumerate_triplets(r, po.scanning_ranges(r), h=12)
+    assert list(H.keys()) == [(2, 1, 3, 2, 2, 14), (2, 1, 1, 2, 6, 18), (2, 3, 1, 2, 6, 18), (1, 3, 1, 0, 4, 16)]
+    assert H[(2, 1, 3, 2, 2, 14)] == [(1, 3, False)] and H[(1, 3, 1, 0, 4, 16)] == [(1, 5, False)]
+    f, thr = po.filter_code_components_using_quantile(_recs([(1, 1, 1, 1.0), (2, 1, 1, 2.0), (3, 1, 1, 3.0)]), 0.5)
+    assert thr == 2.0 and list(f["position"]) == [3]

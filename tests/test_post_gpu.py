@@ -63,3 +63,43 @@ def test_consumers_match_oracle(ctx, pkg, K, lo, hi):
     for k in range(K):
         w = (want[k, : int(lens[k]), :].T + np.float32(0.01)).astype(np.float16)
         assert np.array_equal(mats[k].view(np.uint16), w.view(np.uint16))
+
+
+# ---- consumers of the code records (§8f-4) -----------------------------------------------------------------------
+def _random_code_records(pkg, nseq, seed, gap_every=0):
+    rng = np.random.default_rng(seed)
+    rows = []
+    for s in range(1, nseq + 1):
+        if gap_every and s % gap_every == 0:
+            continue                                          # a sequence without components
+        ncomp = int(rng.integers(1, 14))
+        fils = np.sort(rng.integers(1, 25, size=ncomp))       # retrieval order: syntax filter, then position
+        for f in fils:
+            rows.append((int(rng.integers(1, 179)), int(f), s, float(np.float16(rng.uniform(0.01, 9.0)))))
+    recs = np.zeros(len(rows), dtype=pkg._lib.CODE_DTYPE)
+    for i, (p, f, s, m) in enumerate(rows):
+        recs[i] = (p, f, s, np.float16(m))
+    order = np.lexsort((recs["position"], recs["fil"], recs["seq"]))
+    return recs[order]
+
+
+@pytest.mark.parametrize("nseq,p,gap", [(60, 0.05, 0), (200, 0.35, 7), (40, 0.75, 0)])
+def test_quantile_filter_and_triplets_match_oracle(ctx, pkg, nseq, p, gap):
+    post = pkg.post
+    recs = _random_code_records(pkg, nseq, 100 + nseq, gap)
+    n = len(recs)
+    dev = torch.from_numpy(recs.view(np.uint8).reshape(n, 12)).cuda()
+    want_f, want_thr = po.filter_code_components_using_quantile(recs, p)
+    out, m, thr = post.filter_code_components(ctx, dev, n, p)
+    assert thr == want_thr and m == len(want_f)
+    got_f = out[:m].cpu().numpy().reshape(-1).view(pkg._lib.CODE_DTYPE)
+    assert np.array_equal(got_f, want_f)
+
+    H = po.enumerate_triplets(want_f, po.scanning_ranges(want_f), h=12)
+    got = post.enumerate_triplets(ctx, out, m, 12)
+    assert got["n_triplets"] == sum(len(v) for v in H.values())
+    assert [tuple(int(x) for x in k) for k in got["keys"]] == list(H.keys()), "keys or their insertion order differ"
+    assert list(got["counts"]) == [len(v) for v in H.values()]
+    flat = [(s, pos) for v in H.values() for (s, pos, _) in v]
+    assert list(zip(got["values"]["seq_num"].tolist(), got["values"]["pos"].tolist())) == flat
+    assert not got["values"]["comp"].any()
