@@ -274,3 +274,41 @@ def test_short_buffer_reports_needed_count(torch_cuda, ctx, pkg):
     assert needed == n
     ctx.synchronize()
     assert not hits[cap:].any() and not sc[cap:].any(), "records past cap were written"
+
+
+def test_two_implementations_agree_at_full_size(torch_cuda, ctx, pkg, monkeypatch):
+    """BASELINE configs[1] size, both strands: the default path (matrix-core candidate filter + exact re-scoring
+    of ~1 % of the pairs) against the exhaustive kernel that evaluates every window of every PWM in sequential
+    binary16 (`MOTIFS_SCAN_VALU=1`, read when a context is created).  Records, scores and histograms must be
+    identical: an exhaustive check of the candidate bound eps_k at full size."""
+    torch = torch_cuda
+    sy, lib = pkg.synth, pkg._lib
+    N, L, K = 100_000, 200, 200
+    codes = sy.gen_codes(N, L, sy.SEED_BASE + 2, n_plant=5, k=12)
+    pwms, lens = sy.gen_pwm_bank(K, sy.SEED_BASE + 2, alpha=0.3)
+    bank = sy.pad_bank(pwms, lens)
+    monkeypatch.setenv("MOTIFS_SCAN_VALU", "1")
+    exhaustive = lib.Context(0)
+    monkeypatch.delenv("MOTIFS_SCAN_VALU")
+    try:
+        raw = torch.from_numpy(codes).cuda()
+        dcodes = torch.zeros(lib.Context.codes_bytes(N, L), dtype=torch.uint8, device="cuda")
+        ctx.encode_dev(raw.data_ptr(), lib.DATA_CODES_U8, N, L, dcodes.data_ptr())
+        ctx.synchronize()
+        for rc in (0, 1):
+            out = []
+            for cx in (ctx, exhaustive):
+                n = cx.pwm_scan_hits_dev(bank, lens, dcodes.data_ptr(), N, L, rc, None, None, 0)
+                hits = torch.zeros((n, 3), dtype=torch.int32, device="cuda")
+                sc = torch.zeros(n, dtype=torch.int16, device="cuda")
+                cnt = torch.zeros(K, dtype=torch.int64, device="cuda")
+                assert cx.pwm_scan_hits_dev(bank, lens, dcodes.data_ptr(), N, L, rc, hits.data_ptr(), sc.data_ptr(), n,
+                                            counts_ptr=cnt.data_ptr()) == n
+                cx.synchronize()
+                out.append((n, hits, sc, cnt))
+            (n0, h0, s0, c0), (n1, h1, s1, c1) = out
+            assert n0 == n1 and n0 > 20_000_000
+            assert torch.equal(h0, h1) and torch.equal(s0, s1) and torch.equal(c0, c1)
+            del out, h0, h1, s0, s1
+    finally:
+        exhaustive.close()
