@@ -221,7 +221,9 @@ static __device__ __forceinline__ uint16_t exact_score(const _Float16* row, cons
     for (int ind = 1; ind < LEN; ind++) acc = acc + t[ind];
     return __builtin_bit_cast(uint16_t, acc);
 }
-static __device__ __forceinline__ bool half_pos(uint16_t h) { return (int16_t)h > 0; }   // > 0 (finite inputs: no NaN)
+// binary16 bits > 0, as `pos_scores > 0f0` decides it (_h3_1_alignment.jl:33): +Inf counts, NaN (an Inf - Inf of
+// overflowing partial sums) does not
+static __device__ __forceinline__ bool half_pos(uint16_t h) { return (int16_t)h > 0 && h <= 0x7c00u; }
 
 // the table into LDS when it fits (a straight copy)
 template <bool LDS_TAB, int THREADS>

@@ -312,3 +312,36 @@ def test_two_implementations_agree_at_full_size(torch_cuda, ctx, pkg, monkeypatc
             del out, h0, h1, s0, s1
     finally:
         exhaustive.close()
+
+
+@pytest.mark.parametrize("scale,why", [(256.0, "slack too large for the uniform-slack kernel: per-PWM eps in C"),
+                                       (4096.0, "partial sums overflow binary16: every window stays a candidate"),
+                                       (2.0 ** -16, "subnormal weights: the bank cannot be rescaled exactly")])
+def test_banks_outside_the_uniform_slack_range(torch_cuda, ctx, pkg, scale, why):
+    """Banks whose magnitudes push the candidate kernel off its fast path (pack_mfma, scan_api.hip): the records
+    must still be the reference's, Inf scores and NaN (Inf - Inf) windows included."""
+    sy = pkg.synth
+    N, L, K = 40, 48, 24
+    codes = sy.gen_codes(N, L, 401, n_plant=2, k=8)
+    codes[5, 7] = 4
+    pwms, lens = sy.gen_pwm_bank(K, 402, len_lo=6, len_hi=12, alpha=0.5)
+    pwms = [(np.asarray(p, dtype=np.float32) * scale).astype(np.float16) for p in pwms]
+    assert all(np.isfinite(p).all() for p in pwms)
+    bank = sy.pad_bank(pwms, lens)
+    with np.errstate(over="ignore", invalid="ignore"):
+        for rc in (False, True):
+            h, s, counts = dev_scan_hits(torch_cuda, ctx, pkg, bank, lens, codes, rc, 16, want_counts=True)
+            oh, os_ = oracle_hits(pkg, bank, lens, codes, rc, 16)
+            assert len(oh) > 0
+            assert np.array_equal(h, oh) and np.array_equal(s, os_), why
+            assert np.array_equal(counts, np.bincount(oh[:, 0] - 1, minlength=K))
+    # the dense tensor of the same bank (K % 8 == 0: matrix-core path)
+    torch = torch_cuda
+    want = so.greedy_search(bank, lens, sy.codes_to_onehot(codes).astype(np.float16))
+    raw = torch.from_numpy(codes).cuda()
+    dcodes = torch.zeros(pkg._lib.Context.codes_bytes(N, L), dtype=torch.uint8, device="cuda")
+    out = torch.full((4 * L, N, K), 0x7BFF, dtype=torch.int16, device="cuda")
+    ctx.encode_dev(raw.data_ptr(), pkg._lib.DATA_CODES_U8, N, L, dcodes.data_ptr())
+    ctx.pwm_scan_dense_dev(bank, lens, dcodes.data_ptr(), N, L, out.data_ptr(), 4 * L)
+    ctx.synchronize()
+    assert np.array_equal(out.cpu().numpy().view(np.uint16), want.view(np.uint16))
