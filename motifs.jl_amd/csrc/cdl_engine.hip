@@ -233,6 +233,15 @@ __global__ void k_lin3(const float* x, float a, const float* y, float b, const f
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         out[i] = a * x[i] + b * y[i] + (z ? c * z[i] : 0.0f);
 }
+// VJP of k_lin3: d{x,y,z} (+)= {a,b,c} * go, go read once
+__global__ void k_lin3_bwd(const float* go, size_t n, float a, float* dx, int ax, float b, float* dy, int ay, float c, float* dz, int az) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float g = go[i];
+        if (dx) dx[i] = (ax ? dx[i] : 0.0f) + a * g;
+        if (dy) dy[i] = (ay ? dy[i] : 0.0f) + b * g;
+        if (dz) dz[i] = (az ? dz[i] : 0.0f) + c * g;
+    }
+}
 // The ISTA step of update_ZY (model.jl:240-244) on the compact image, fused:
 //   out = relu(ZY - lst * (g1 + pen * (ZY - FX - ab)) - ls * lst)          (ab optional; pen, lst, ls device scalars)
 __global__ void k_zy_step(const float* ZY, const float* g1, const float* FX, const float* ab, const float* pen, const float* lst,
@@ -311,14 +320,23 @@ Tensor Engine::lin3(Tensor x, float a, Tensor y, float b, Tensor z, float c) {
     if (recording && out->needs_grad)
         tape.push_back([this, out, x, y, z, a, b, c]() {
             if (!out->g) return;
-            Tensor ts[3] = {x, y, z};
-            const float cs[3] = {a, b, c};
-            for (int i = 0; i < 3; i++) {
-                if (!ts[i] || !ts[i]->needs_grad) continue;
-                int acc;
-                float* d = grad_first(ts[i], acc);
-                if (d) EW(k_axpy, out->n, out->g, cs[i], out->n, d, acc);
+            if (x == y || x == z || (z && y == z)) {                  // aliased operands: one contribution at a time
+                Tensor ts[3] = {x, y, z};
+                const float cs[3] = {a, b, c};
+                for (int i = 0; i < 3; i++) {
+                    if (!ts[i] || !ts[i]->needs_grad) continue;
+                    int acc;
+                    float* d = grad_first(ts[i], acc);
+                    if (d) EW(k_axpy, out->n, out->g, cs[i], out->n, d, acc);
+                }
+                return;
             }
+            int ax = 1, ay = 1, az = 1;
+            float* dx = x->needs_grad ? grad_first(x, ax) : nullptr;
+            float* dy = y->needs_grad ? grad_first(y, ay) : nullptr;
+            float* dz = (z && z->needs_grad) ? grad_first(z, az) : nullptr;
+            if (failed) return;
+            EW(k_lin3_bwd, out->n, out->g, out->n, a, dx, ax, b, dy, ay, c, dz, az);
         });
     return out;
 }
@@ -1329,8 +1347,9 @@ __global__ __launch_bounds__(256) void k_build_nz(const float* __restrict__ x, i
 }
 
 // S1: out[s][r][j] (+)= sum_nz v * FAf[g][p - r + h - 1][k][j]      (block = (read, 128 columns), thread = column j)
-__global__ __launch_bounds__(128) void k_sp_syn(NzView nz, const float* __restrict__ FAf, float* __restrict__ out,
-                                                SpDims d, int acc) {
+// any filter height: read-modify-write of the output rows in memory
+__global__ __launch_bounds__(128) void k_sp_syn_any(NzView nz, const float* __restrict__ FAf, float* __restrict__ out,
+                                                    SpDims d, int acc) {
     const int s = blockIdx.y, j = blockIdx.x * 128 + threadIdx.x;
     if (j >= d.W) return;
     const float* Fg = FAf + (size_t)(s / d.B) * d.ldf;
@@ -1348,6 +1367,75 @@ __global__ __launch_bounds__(128) void k_sp_syn(NzView nz, const float* __restri
             os[(size_t)r * d.W + j] += v * Fg[((size_t)ip * d.K + k) * d.W + j];
         }
     }
+}
+
+// The non-zeros come in ascending position p and each touches rows p .. p + h - 1, so the open rows live in a ring
+// of h LDS slots per column; a row is written to HBM once, when the sweep has passed it.
+__global__ __launch_bounds__(128) void k_sp_syn(NzView nz, const float* __restrict__ FAf, float* __restrict__ out,
+                                                SpDims d, int acc) {
+    extern __shared__ float ring[];                      // [h][128]
+    const int s = blockIdx.y, tx = threadIdx.x, j = blockIdx.x * 128 + tx;
+    const bool live = j < d.W;
+    const int jc = live ? j : d.W - 1;
+    const float* Fg = FAf + (size_t)(s / d.B) * d.ldf + jc;
+    float* os = out + (size_t)s * d.c * d.W + jc;
+    for (int ip = 0; ip < d.h; ip++) ring[ip * 128 + tx] = 0.0f;
+    int base = 0, bslot = 0;                             // lowest open row and its ring slot (base % h)
+    auto close_rows = [&](int upto) {                    // rows [base, upto) are final
+        while (base < upto) {
+            const int nb = upto - base < 8 ? upto - base : 8;
+            float old[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++)                  // the old values of an accumulating call, all loads in flight at once
+                old[u] = (acc && live && u < nb) ? os[(size_t)(base + u) * d.W] : 0.0f;
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                if (u < nb) {
+                    const float v = ring[bslot * 128 + tx];
+                    ring[bslot * 128 + tx] = 0.0f;
+                    if (live) os[(size_t)(base + u) * d.W] = old[u] + v;
+                    bslot = bslot + 1 == d.h ? 0 : bslot + 1;
+                }
+            }
+            base += nb;
+        }
+    };
+    const int cnt = nz.cnt[s];
+    const uint2* es = nz.ent + (size_t)s * nz.cap;
+    constexpr int MAXH = 16;                             // the launcher falls back to the dense form above this height
+    // one entry ahead: the filter values of entry z + 1 are in flight while entry z is folded into the ring
+    float fn[MAXH];
+    uint2 en_n = cnt > 0 ? es[0] : make_uint2(0u, 0u);
+    {
+        const int p = (int)(en_n.x / (unsigned)d.K), k = (int)(en_n.x - (unsigned)p * d.K);
+#pragma unroll
+        for (int ip = 0; ip < MAXH; ip++) fn[ip] = (cnt > 0 && ip < d.h) ? Fg[((size_t)ip * d.K + k) * d.W] : 0.0f;
+    }
+    for (int z = 0; z < cnt; z++) {                      // block-uniform control flow
+        const uint2 en = en_n;
+        float fc[MAXH];
+#pragma unroll
+        for (int ip = 0; ip < MAXH; ip++) fc[ip] = fn[ip];
+        if (z + 1 < cnt) {
+            en_n = es[z + 1];
+            const int pn = (int)(en_n.x / (unsigned)d.K), kn = (int)(en_n.x - (unsigned)pn * d.K);
+#pragma unroll
+            for (int ip = 0; ip < MAXH; ip++)
+                if (ip < d.h) fn[ip] = Fg[((size_t)ip * d.K + kn) * d.W];
+        }
+        const int p = (int)(en.x / (unsigned)d.K);
+        const float v = __uint_as_float(en.y);
+        close_rows(p);                                   // now base == p (entries are sorted by p)
+        int slot = bslot == 0 ? d.h - 1 : bslot - 1;     // row p + h - 1 sits one slot before the base slot
+#pragma unroll
+        for (int ip = 0; ip < MAXH; ip++) {              // row r = p + h - 1 - ip
+            if (ip < d.h) {
+                ring[slot * 128 + tx] = fmaf(v, fc[ip], ring[slot * 128 + tx]);
+                slot = slot == 0 ? d.h - 1 : slot - 1;
+            }
+        }
+    }
+    close_rows(d.c);
 }
 
 // S2: dFAf[g][ip][k][j] += sum_{s in g} sum_nz v * dOut[s][p + h - 1 - ip][j]     (block = (128 columns, ip, group))
@@ -1454,7 +1542,8 @@ static void launch_sp_ana_masked(hipStream_t st, const float* img, const float* 
 }
 
 static void launch_sp_syn(hipStream_t st, const NzView& nz, const float* FAf, float* out, const SpDims& d, int acc) {
-    hipLaunchKernelGGL(k_sp_syn, dim3((d.W + 127) / 128, d.S), dim3(128), 0, st, nz, FAf, out, d, acc);
+    if (d.h <= 16) hipLaunchKernelGGL(k_sp_syn, dim3((d.W + 127) / 128, d.S), dim3(128), (size_t)d.h * 128 * 4, st, nz, FAf, out, d, acc);
+    else hipLaunchKernelGGL(k_sp_syn_any, dim3((d.W + 127) / 128, d.S), dim3(128), 0, st, nz, FAf, out, d, acc);
 }
 
 Tensor Engine::sp_syn(Tensor T, Tensor FAf, Tensor Fk, const SpDims& d) {
