@@ -1061,6 +1061,16 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ A, cons
     }
 }
 
+// y[g][j] (+)= sum of the B consecutive slices x[g*B .. g*B + B) (per-sequence partials -> per-group sums)
+__global__ void k_sum_segments(const float* x, size_t per, int B, size_t total, float* y, int acc) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t g = i / per, j = i - g * per;
+        float a = 0.0f;
+        for (int b = 0; b < B; b++) a += x[(g * B + b) * per + j];
+        y[i] = acc ? y[i] + a : a;
+    }
+}
+
 static void launch_wgrad(Engine& e, const float* A, const float* C, float* dB, const ToepGeom& gm, int acc) {
     hipStream_t st = e.st;
     const int G = gm.S / gm.B;
@@ -1080,17 +1090,35 @@ static void launch_wgrad(Engine& e, const float* A, const float* C, float* dB, c
         hipLaunchKernelGGL(k_tall_bt_T, dim3(nblocks(per * G)), dim3(256), 0, st, dBt, G, H, gm.sa, gm.N, dB, acc);
         return;
     }
-    if (gm.N > 8 && gm.N <= 64 && gm.Q >= 256) {
-        hipLaunchKernelGGL(k_wgrad_mfma, dim3((gm.Q + 127) / 128, G, (gm.N + 31) / 32), dim3(256), 0, st, A, C, dB, gm, acc);
+    // Few groups give few blocks (one per (tile, group)), each with a reduction over all B*P rows of its group:
+    // reduce per sequence instead (B times the blocks) and add the B partial banks afterwards.
+    const size_t per = (size_t)gm.Q * gm.N;
+    const bool mfma = gm.N > 8 && gm.N <= 64 && gm.Q >= 256;
+    const int tiles = mfma ? ((gm.Q + 127) / 128) * ((gm.N + 31) / 32) : ((gm.N + 63) / 64) * ((gm.Q + 63) / 64);
+    auto kernels = [&](float* out, const ToepGeom& gg, int groups, int accf) {
+        if (mfma) {
+            hipLaunchKernelGGL(k_wgrad_mfma, dim3((gg.Q + 127) / 128, groups, (gg.N + 31) / 32), dim3(256), 0, st, A, C, out, gg, accf);
+        } else if (gg.N <= 32) {
+            dim3 grid((gg.N + 31) / 32, (gg.Q + 63) / 64, groups);
+            hipLaunchKernelGGL(k_wgrad<32>, grid, dim3(256), 0, st, A, C, out, gg, accf);
+        } else {
+            dim3 grid((gg.N + 63) / 64, (gg.Q + 63) / 64, groups);
+            hipLaunchKernelGGL(k_wgrad<64>, grid, dim3(256), 0, st, A, C, out, gg, accf);
+        }
+    };
+    if (gm.B > 1 && tiles * G < 2048) {
+        float* part = e.arena.alloc(per * gm.S);
+        if (!part) {
+            e.failed = true;
+            return;
+        }
+        ToepGeom g1 = gm;
+        g1.B = 1;
+        kernels(part, g1, gm.S, 0);
+        hipLaunchKernelGGL(k_sum_segments, dim3(nblocks(per * G)), dim3(256), 0, st, part, per, gm.B, per * G, dB, acc);
         return;
     }
-    if (gm.N <= 32) {
-        dim3 grid((gm.N + 31) / 32, (gm.Q + 63) / 64, G);
-        hipLaunchKernelGGL(k_wgrad<32>, grid, dim3(256), 0, st, A, C, dB, gm, acc);
-    } else {
-        dim3 grid((gm.N + 63) / 64, (gm.Q + 63) / 64, G);
-        hipLaunchKernelGGL(k_wgrad<64>, grid, dim3(256), 0, st, A, C, dB, gm, acc);
-    }
+    kernels(dB, gm, G, acc);
 }
 
 // dA[s][e] += sum_{p,q: a0 + p*sa + q = e} sum_n dC[s][p][n] * Bm[g][q][n]
