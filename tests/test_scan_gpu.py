@@ -345,3 +345,41 @@ def test_banks_outside_the_uniform_slack_range(torch_cuda, ctx, pkg, scale, why)
     ctx.pwm_scan_dense_dev(bank, lens, dcodes.data_ptr(), N, L, out.data_ptr(), 4 * L)
     ctx.synchronize()
     assert np.array_equal(out.cpu().numpy().view(np.uint16), want.view(np.uint16))
+
+
+def test_random_shapes_against_oracle(torch_cuda, ctx, pkg):
+    """A seeded sweep over odd shapes (K across tile and chunk boundaries, mixed PWM lengths, L barely above the
+    longest PWM, batches that do not divide N, all-zero columns, both strands): records, scores and histograms
+    against the oracle, and the dense tensor where it is small enough."""
+    sy = pkg.synth
+    rng = np.random.default_rng(20261004)
+    for trial in range(36):
+        K = int(rng.choice([1, 2, 3, 31, 32, 33, 63, 64, 65, 127, 128, 129, 130, 200, 257]))
+        hi = int(rng.choice([4, 8, 9, 12, 13, 16, 20, 21, 24, 29, 32]))
+        lo = int(rng.integers(max(1, hi - 6), hi + 1))
+        L = int(rng.integers(hi, hi + 70))
+        N = int(rng.integers(1, 90))
+        batch = int(rng.choice([1, 3, 7, 16, 50, 5000]))
+        alpha = float(rng.uniform(0.25, 0.9))
+        codes = sy.gen_codes(N, L, 7000 + trial, n_plant=2, k=min(8, L))
+        for _ in range(int(rng.integers(0, 4))):
+            codes[int(rng.integers(0, N)), int(rng.integers(0, L))] = 4
+        pwms, lens = sy.gen_pwm_bank(K, 8000 + trial, len_lo=lo, len_hi=hi, alpha=alpha)
+        bank = sy.pad_bank(pwms, lens)
+        rc = bool(trial & 1)
+        tag = f"trial {trial}: N={N} L={L} K={K} len {lo}..{hi} batch={batch} rc={rc}"
+        h, s, counts = dev_scan_hits(torch_cuda, ctx, pkg, bank, lens, codes, rc, batch, want_counts=True)
+        oh, os_ = oracle_hits(pkg, bank, lens, codes, rc, batch)
+        assert np.array_equal(h, oh), tag
+        assert np.array_equal(s, os_), tag
+        assert np.array_equal(counts, np.bincount(oh[:, 0] - 1, minlength=K) if len(oh) else np.zeros(K, np.int64)), tag
+        if not rc and N * L * K < 400_000:
+            torch = torch_cuda
+            want = so.greedy_search(bank, lens, sy.codes_to_onehot(codes).astype(np.float16))
+            raw = torch.from_numpy(codes).cuda()
+            dcodes = torch.zeros(pkg._lib.Context.codes_bytes(N, L), dtype=torch.uint8, device="cuda")
+            out = torch.full((4 * L, N, K), 0x7BFF, dtype=torch.int16, device="cuda")
+            ctx.encode_dev(raw.data_ptr(), pkg._lib.DATA_CODES_U8, N, L, dcodes.data_ptr())
+            ctx.pwm_scan_dense_dev(bank, lens, dcodes.data_ptr(), N, L, out.data_ptr(), 4 * L)
+            ctx.synchronize()
+            assert np.array_equal(out.cpu().numpy().view(np.uint16), want.view(np.uint16)), tag
