@@ -276,17 +276,8 @@ def test_short_buffer_reports_needed_count(torch_cuda, ctx, pkg):
     assert not hits[cap:].any() and not sc[cap:].any(), "records past cap were written"
 
 
-def test_two_implementations_agree_at_full_size(torch_cuda, ctx, pkg, monkeypatch):
-    """BASELINE configs[1] size, both strands: the default path (matrix-core candidate filter + exact re-scoring
-    of ~1 % of the pairs) against the exhaustive kernel that evaluates every window of every PWM in sequential
-    binary16 (`MOTIFS_SCAN_VALU=1`, read when a context is created).  Records, scores and histograms must be
-    identical: an exhaustive check of the candidate bound eps_k at full size."""
-    torch = torch_cuda
-    sy, lib = pkg.synth, pkg._lib
-    N, L, K = 100_000, 200, 200
-    codes = sy.gen_codes(N, L, sy.SEED_BASE + 2, n_plant=5, k=12)
-    pwms, lens = sy.gen_pwm_bank(K, sy.SEED_BASE + 2, alpha=0.3)
-    bank = sy.pad_bank(pwms, lens)
+def _both_paths(torch, ctx, lib, monkeypatch, bank, lens, codes, K, min_hits):
+    N, L = codes.shape
     monkeypatch.setenv("MOTIFS_SCAN_VALU", "1")
     exhaustive = lib.Context(0)
     monkeypatch.delenv("MOTIFS_SCAN_VALU")
@@ -307,11 +298,35 @@ def test_two_implementations_agree_at_full_size(torch_cuda, ctx, pkg, monkeypatc
                 cx.synchronize()
                 out.append((n, hits, sc, cnt))
             (n0, h0, s0, c0), (n1, h1, s1, c1) = out
-            assert n0 == n1 and n0 > 20_000_000
+            assert n0 == n1 and n0 > min_hits
             assert torch.equal(h0, h1) and torch.equal(s0, s1) and torch.equal(c0, c1)
             del out, h0, h1, s0, s1
     finally:
         exhaustive.close()
+
+
+def test_two_implementations_agree_mixed_lengths(torch_cuda, ctx, pkg, monkeypatch):
+    """Mixed PWM lengths (6..20: the LEN = 20 templates, three chunks of PWMs, per-PWM last valid starts), a
+    length that is not a multiple of 4, a few all-zero columns: default path against the exhaustive kernel."""
+    sy, lib = pkg.synth, pkg._lib
+    N, L, K = 20_000, 303, 300
+    codes = sy.gen_codes(N, L, 9090, n_plant=5, k=12)
+    rng = np.random.default_rng(9)
+    codes[rng.integers(0, N, 50), rng.integers(0, L, 50)] = 4
+    pwms, lens = sy.gen_pwm_bank(K, 9091, len_lo=6, len_hi=20, alpha=0.35)
+    _both_paths(torch_cuda, ctx, lib, monkeypatch, sy.pad_bank(pwms, lens), lens, codes, K, 1_000_000)
+
+
+def test_two_implementations_agree_at_full_size(torch_cuda, ctx, pkg, monkeypatch):
+    """BASELINE configs[1] size, both strands: the default path (matrix-core candidate filter + exact re-scoring
+    of ~1 % of the pairs) against the exhaustive kernel that evaluates every window of every PWM in sequential
+    binary16 (`MOTIFS_SCAN_VALU=1`, read when a context is created).  Records, scores and histograms must be
+    identical: an exhaustive check of the candidate bound eps_k at full size."""
+    sy, lib = pkg.synth, pkg._lib
+    N, L, K = 100_000, 200, 200
+    codes = sy.gen_codes(N, L, sy.SEED_BASE + 2, n_plant=5, k=12)
+    pwms, lens = sy.gen_pwm_bank(K, sy.SEED_BASE + 2, alpha=0.3)
+    _both_paths(torch_cuda, ctx, lib, monkeypatch, sy.pad_bank(pwms, lens), lens, codes, K, 20_000_000)
 
 
 @pytest.mark.parametrize("scale,why", [(256.0, "slack too large for the uniform-slack kernel: per-PWM eps in C"),
