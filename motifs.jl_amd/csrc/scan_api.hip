@@ -339,8 +339,6 @@ static int scan_hits_mfma(motifs_ctx* c, const BankSlot& bank, int K, const uint
     MOTIFS_HIP_CHECK(c->rowx.reserve((size_t)rows_max * 4));
     if (emit) MOTIFS_HIP_CHECK(c->staging.reserve((size_t)nb_max * stage_per_batch));
     MOTIFS_HIP_CHECK(c->small.reserve(64));
-    MOTIFS_HIP_CHECK(c->pwmcnt.reserve((size_t)2 * bank.KP * 8));
-    if (per_pwm_counts_dev) MOTIFS_HIP_CHECK(hipMemsetAsync(c->pwmcnt.p, 0, (size_t)2 * bank.KP * 8, c->stream));
     // small: [0], [1] record totals (ping-pong between super-batches)
     int64_t* totals = (int64_t*)c->small.p;
     MOTIFS_HIP_CHECK(hipMemsetAsync(c->small.p, 0, 64, c->stream));
@@ -363,7 +361,7 @@ static int scan_hits_mfma(motifs_ctx* c, const BankSlot& bank, int K, const uint
         f.cap = cap;
         f.hits = (HitRec*)hits_dev;
         f.hit_scores = hit_scores_dev;
-        f.pwm_counts = per_pwm_counts_dev ? (int64_t*)c->pwmcnt.p : nullptr;
+        f.pwm_counts = per_pwm_counts_dev;   // zeroed by the caller of this function; only bins k < K are ever touched
         f.n0 = n0 + s0;
         f.hist_bins = (per_pwm_counts_dev && 2 * bank.KP <= FILL_HIST_MAX) ? 2 * bank.KP : 0;
         if (ns < nb * batch)   // cells of reads the last batch does not have are never written by the scan
@@ -388,8 +386,6 @@ static int scan_hits_mfma(motifs_ctx* c, const BankSlot& bank, int K, const uint
     const int64_t emitted = *h_total;
     const bool too_small = emitted > cap;
     *n_out = emitted;
-    if (per_pwm_counts_dev)
-        MOTIFS_HIP_CHECK(hipMemcpyAsync(per_pwm_counts_dev, c->pwmcnt.p, (size_t)K * 8, hipMemcpyDeviceToDevice, c->stream));
     if (too_small && !(cap == 0 && hits_dev == nullptr)) {
         set_error("hit buffer too small: need %lld records, cap %lld", (long long)emitted, (long long)cap);
         return MOTIFS_ERR_BUFFER_TOO_SMALL;
