@@ -128,6 +128,24 @@ def test_cfg1_golden(ctx, pkg):
     assert d.max() <= 1
 
 
+def test_cfg2_golden(ctx, pkg):
+    """One mini-batch at BASELINE configs[1] shape (200 bp, 200 filters of length 12) against the float64 oracle
+    (tests/golden/make_model_cfg2_golden.py): the matrix-core, tall and sparse paths at their real sizes."""
+    g = np.load(os.path.join(HERE, "golden", "model_cfg2.npz"))
+    hp = mo.Hyperparam(filter_len=12, M=200)
+    cdl_o = mo.UCDL(hp, np.random.default_rng(0)).to(torch.float64)
+    for n in mo.PARAM_VECS + ["D", "F"]:
+        setattr(cdl_o, n, torch.tensor(g["init_" + n].astype(np.float64)))
+    cdl_o.lambda_sparsity_warmup, cdl_o.lambda_stepsize_warmup, cdl_o.omega_stepsize_warmup = [float(x) for x in g["warm"]]
+    cdl = to_model(pkg, ctx, hp, 200, cdl_o)
+    loss, flat = gpu_loss_grad(pkg, ctx, cdl, g["codes"], 1)
+    got = split_grad(cdl, flat)
+    assert abs(loss[0] - g["loss0"]) <= RTOL * g["loss0"]
+    for n in NAMES:
+        assert rel_inf(got[n], g[f"grad0_{n}"].astype(np.float64)) <= 5 * RTOL, (n, rel_inf(got[n], g[f"grad0_{n}"]))
+    cdl.model.close()
+
+
 def test_train_step_matches_adabelief_oracle(ctx, pkg):
     hp, codes, cdl_o = tiny(5, G=1)
     cdl = to_model(pkg, ctx, hp, codes.shape[1], cdl_o)
