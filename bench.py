@@ -159,6 +159,41 @@ def main():
     assert dense_pos == nrec and dense_sum == rec_sum, f"dense tensor disagrees with the hit records: {dense_pos} vs {nrec}"
     del dense, pos
 
+    # ---- the consumers of the records on the forward-strand records of this shard ----
+    post = pkg.post
+    nrec = ctx.pwm_scan_hits_dev(bank, lens, dcodes.data_ptr(), N, L, 0, hits[0].data_ptr(), hsc[0].data_ptr(), cap, n0=0)
+
+    def _ms(fn, reps=3):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3
+    mn, mx = post.score_range(ctx, hits[0], hsc[0], nrec, K)
+    thr, _ = post.sweep_thresholds(mn, mx)
+    thr_t = torch.from_numpy(np.ascontiguousarray(thr).view(np.int16)).cuda()
+    cnt_t = torch.zeros(thr.shape, dtype=torch.int64, device="cuda")
+    mn_t = torch.empty(K, dtype=torch.int16, device="cuda")
+    mx_t = torch.empty(K, dtype=torch.int16, device="cuda")
+    th_t = torch.from_numpy(np.ascontiguousarray(thr[:, thr.shape[1] // 2]).view(np.int16)).cuda()
+    oh_t, os_t = torch.empty_like(hits[0]), torch.empty_like(hsc[0])
+    cm_t = torch.zeros((K, int(lens.max()), 4), dtype=torch.int32, device="cuda")
+    consumers = {
+        "records": int(nrec),
+        "score_range_ms": _ms(lambda: ctx.hits_minmax_dev(hits[0].data_ptr(), hsc[0].data_ptr(), nrec, K, mn_t.data_ptr(), mx_t.data_ptr())),
+        "threshold_sweep_ms": _ms(lambda: ctx.hits_threshold_counts_dev(hits[0].data_ptr(), hsc[0].data_ptr(), nrec, K, thr_t.data_ptr(),
+                                                                         thr.shape[1], cnt_t.data_ptr())),
+        "threshold_sweep_steps": int(thr.shape[1]),
+        "filter_ms": _ms(lambda: ctx.hits_filter_dev(hits[0].data_ptr(), hsc[0].data_ptr(), nrec, K, th_t.data_ptr(), oh_t.data_ptr(),
+                                                      os_t.data_ptr())),
+        "count_matrices_ms": _ms(lambda: ctx.hits_count_matrices_dev(hits[0].data_ptr(), nrec, dcodes.data_ptr(), L, 0, lens, K,
+                                                                      int(lens.max()), 0, cm_t.data_ptr())),
+        "note": "SURVEY 8f rows 2-3 on the forward-strand records of the shard, wall time per call incl. launch and sync",
+    }
+    del oh_t, os_t
+
     # ---- attainable HBM rates in this run: a device copy and a fill of ~1 GB, torch kernels ----
     def _rate(fn, nbytes, reps=10):
         for _ in range(3):
@@ -296,6 +331,7 @@ def main():
             "avg_launch_ms": dense_ms / dense_n, "seqs_per_launch": nb,
             "bases_per_s_one_strand": nb * L / (dense_ms / dense_n * 1e-3),
         },
+        "record_consumers": consumers,
         "hbm_measured": {"fill_gbs": hbm_fill_gbs, "copy_gbs_read_plus_write": hbm_copy_gbs,
                          "note": "torch zero_() / copy_() of 1 GiB in this run; nominal peak 8000 GB/s"},
         "kernel_ms_per_step": {"scan_cand": kms["count"][0] / args.steps, "stage_hits_row_scan": kms["offsets"][0] / args.steps,
