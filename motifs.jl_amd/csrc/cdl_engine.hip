@@ -1086,7 +1086,20 @@ static void launch_wgrad(Engine& e, const float* A, const float* C, float* dB, c
         hipLaunchKernelGGL(k_tall_scatter, dim3(nblocks((size_t)gm.S * R * H * gm.N)), dim3(256), 0, st, C, dW, gm.S, gm.P, H, gm.N, R,
                            gm.a0 / gm.sa, gm.ldc);
         const ToepGeom rg = tall_row_geom(gm);
-        hipLaunchKernelGGL(k_wgrad_mfma, dim3((rg.Q + 127) / 128, G, (rg.N + 31) / 32), dim3(256), 0, st, A, dW, dBt, rg, 0);
+        const int rtiles = ((rg.Q + 127) / 128) * ((rg.N + 31) / 32);
+        if (rg.B > 1 && rtiles * G < 2048) {      // per-sequence partial banks, then their sums (see below)
+            float* part = e.arena.alloc(per * gm.S);
+            if (!part) {
+                e.failed = true;
+                return;
+            }
+            ToepGeom r1 = rg;
+            r1.B = 1;
+            hipLaunchKernelGGL(k_wgrad_mfma, dim3((rg.Q + 127) / 128, gm.S, (rg.N + 31) / 32), dim3(256), 0, st, A, dW, part, r1, 0);
+            hipLaunchKernelGGL(k_sum_segments, dim3(nblocks(per * G)), dim3(256), 0, st, part, per, rg.B, per * G, dBt, 0);
+        } else {
+            hipLaunchKernelGGL(k_wgrad_mfma, dim3((rg.Q + 127) / 128, G, (rg.N + 31) / 32), dim3(256), 0, st, A, dW, dBt, rg, 0);
+        }
         hipLaunchKernelGGL(k_tall_bt_T, dim3(nblocks(per * G)), dim3(256), 0, st, dBt, G, H, gm.sa, gm.N, dB, acc);
         return;
     }
