@@ -680,14 +680,32 @@ __global__ __launch_bounds__(512) void k_toep_mfma(const float* __restrict__ A, 
     rows.init(A, gm, g, loc0, lane);
     float4 va[4];
     float bt[16];
+    // B tile [32 k][32 n]: four float4 per lane when the rows allow it (N % 4 == 0, 16-byte aligned bank), else scalars
+    const bool bvec = (gm.N & 3) == 0 && (((uintptr_t)Bg) & 15) == 0;
+    const int bk = lane >> 3, bn = (lane & 7) * 4;            // this lane's (k, n) corner in the vector form
+    const bool bn_ok = n0 + bn + 3 < gm.N;
+    const float* bptr = Bg + (size_t)bk * gm.N + n0 + (bn_ok ? bn : 0);
     auto load_b = [&](int q0) {
+        if (bvec) {
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
-            const int f = lane + j * 64, kk = f >> 5, n = f & 31;
-            const int q = q0 + kk;
-            const bool ok = q < gm.Q && n0 + n < gm.N;
-            const float x = Bg[ok ? (size_t)q * gm.N + n0 + n : 0];
-            bt[j] = ok ? x : 0.0f;
+            for (int j = 0; j < 4; j++) {
+                const int q = q0 + bk + 8 * j;
+                const bool ok = bn_ok && q < gm.Q;
+                const float4 x = *(const float4*)(ok ? bptr + (size_t)(q0 + 8 * j) * gm.N : Bg);
+                bt[4 * j + 0] = ok ? x.x : 0.0f;
+                bt[4 * j + 1] = ok ? x.y : 0.0f;
+                bt[4 * j + 2] = ok ? x.z : 0.0f;
+                bt[4 * j + 3] = ok ? x.w : 0.0f;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const int f = lane + j * 64, kk = f >> 5, n = f & 31;
+                const int q = q0 + kk;
+                const bool ok = q < gm.Q && n0 + n < gm.N;
+                const float x = Bg[ok ? (size_t)q * gm.N + n0 + n : 0];
+                bt[j] = ok ? x : 0.0f;
+            }
         }
     };
     if (ks * BK < gm.Q) {
@@ -696,10 +714,17 @@ __global__ __launch_bounds__(512) void k_toep_mfma(const float* __restrict__ A, 
     }
     for (int q0 = ks * BK; q0 < gm.Q; q0 += KS * BK) {
         rows.store(va, As[wave], lane);
+        if (bvec) {
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
-            const int f = lane + j * 64;
-            Bs[wave][f >> 5][f & 31] = bt[j];
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int u = 0; u < 4; u++) Bs[wave][bk + 8 * j][bn + u] = bt[4 * j + u];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const int f = lane + j * 64;
+                Bs[wave][f >> 5][f & 31] = bt[j];
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
