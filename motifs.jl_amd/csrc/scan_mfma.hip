@@ -93,7 +93,7 @@ static __device__ __forceinline__ void cand_read(const f16x8 (&A)[PG][T], const 
 
 // UEPS: the bank was scaled by a power of two on the host so that one slack, the inline constant 4.0, serves
 // every PWM (C is then not a register operand and the wave needs 64 VGPRs fewer); otherwise C = eps_k from cinit.
-template <int T, int PG, bool UEPS, int RPB>
+template <int T, int PG, bool UEPS, int RPB, int TGB>
 static __device__ __forceinline__ void scan_cand_body(const uint4* __restrict__ afrag, const float* __restrict__ cinit,
                                                       const uint8_t* __restrict__ codes, uint32_t* __restrict__ cells,
                                                       const CandDims& d) {
@@ -101,10 +101,11 @@ static __device__ __forceinline__ void scan_cand_body(const uint4* __restrict__ 
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int w = lane & 31, h = lane >> 5;
     uint2* oh = oh_all + (size_t)wave * ((d.ohlen + 3) & ~3);
-    // a block = RPB reads x 2 tile groups: the two halves of a 128-byte line of cells (4 reads x 2 chunks) are
-    // written by the same block at about the same time
+    // a block = RPB reads x TGB tile groups: with TGB = 2 the block writes both chunks of its reads (half lines of
+    // cells; 4 reads x 1 group was measured 1.7x slower on a two-group bank: the halves of a line then come from
+    // different blocks at different times); TGB = 1 serves banks with a single tile group.
     const int slot = wave % RPB;
-    const int tg = blockIdx.y * 2 + wave / RPB;      // tile group: PWM tiles [tg*PG, tg*PG + PG)
+    const int tg = blockIdx.y * TGB + wave / RPB;    // tile group: PWM tiles [tg*PG, tg*PG + PG)
     if (tg * PG >= d.used_tiles) return;
     const int tile0 = tg * PG;
     const int chunk = tile0 >> 2, word0 = tile0 & 3;
@@ -179,13 +180,13 @@ template <int T, int PG>
 __global__ __launch_bounds__(512) void scan_cand_kernel(const uint4* __restrict__ afrag, const float* __restrict__ cinit,
                                                         const uint8_t* __restrict__ codes, uint32_t* __restrict__ cells,
                                                         const CandDims d) {
-    scan_cand_body<T, PG, false, 4>(afrag, cinit, codes, cells, d);
+    scan_cand_body<T, PG, false, 4, 2>(afrag, cinit, codes, cells, d);
 }
-// uniform slack: the wave fits 168 VGPRs, so three 4-wave blocks (2 reads x 2 tile groups) share a CU
-template <int T, int PG>
+// uniform slack: the wave fits 168 VGPRs, so three 4-wave blocks (2 reads x 2 tile groups, or 4 reads x 1) share a CU
+template <int T, int PG, int TGB>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(T * PG <= 16 ? 3 : 2, 4))) void scan_cand_kernel_u(
     const uint4* __restrict__ afrag, const uint8_t* __restrict__ codes, uint32_t* __restrict__ cells, const CandDims d) {
-    scan_cand_body<T, PG, true, 2>(afrag, nullptr, codes, cells, d);
+    scan_cand_body<T, PG, true, 4 / TGB, TGB>(afrag, nullptr, codes, cells, d);
 }
 
 // ---- candidates -> records ---------------------------------------------------------------------------------
@@ -543,12 +544,14 @@ __global__ __launch_bounds__(VF_THREADS) void emit_records(FillArgs a) {
 
 template <int T, int PG>
 static hipError_t launch_cand_tp(const CandArgs& a, hipStream_t st) {
-    const int rpb = a.uniform_eps ? 2 : 4;
+    const int ntg = (a.d.used_tiles + PG - 1) / PG;           // tile groups that hold PWMs
+    const int tgb = (a.uniform_eps && ntg == 1) ? 1 : 2;
+    const int rpb = a.uniform_eps ? 4 / tgb : 4;
     const int64_t per_block = (int64_t)rpb * a.d.spw;
-    const int ntg = a.ntiles / PG;
-    dim3 grid((unsigned)((a.d.N + per_block - 1) / per_block), (unsigned)((ntg + 1) / 2), 1);
-    const size_t lds = (size_t)2 * rpb * ((a.d.ohlen + 3) & ~3) * 8;
-    if (a.uniform_eps) hipLaunchKernelGGL((scan_cand_kernel_u<T, PG>), grid, dim3(256), lds, st, a.afrag, a.codes, a.cells, a.d);
+    dim3 grid((unsigned)((a.d.N + per_block - 1) / per_block), (unsigned)((ntg + tgb - 1) / tgb), 1);
+    const size_t lds = (size_t)tgb * rpb * ((a.d.ohlen + 3) & ~3) * 8;
+    if (a.uniform_eps && tgb == 1) hipLaunchKernelGGL((scan_cand_kernel_u<T, PG, 1>), grid, dim3(256), lds, st, a.afrag, a.codes, a.cells, a.d);
+    else if (a.uniform_eps) hipLaunchKernelGGL((scan_cand_kernel_u<T, PG, 2>), grid, dim3(256), lds, st, a.afrag, a.codes, a.cells, a.d);
     else hipLaunchKernelGGL((scan_cand_kernel<T, PG>), grid, dim3(512), lds, st, a.afrag, a.cinit, a.codes, a.cells, a.d);
     return hipGetLastError();
 }
