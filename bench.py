@@ -91,7 +91,10 @@ def main():
     raw = torch.from_numpy(codes).cuda()
     dcodes = torch.zeros(lib.Context.codes_bytes(N, L), dtype=torch.uint8, device="cuda")
     ctx.encode_dev(raw.data_ptr(), lib.DATA_CODES_U8, N, L, dcodes.data_ptr())
-    counts = torch.zeros((2, K), dtype=torch.int64, device="cuda")      # per-strand hit histograms
+    # per-strand hit histograms, two sets: the all-reduce of step i runs beside the scan of step i + 1
+    counts_ring = [torch.zeros((2, K), dtype=torch.int64, device="cuda") for _ in range(2)]
+    pending = [None, None]
+    step_no = [0]
     # size the record buffers once (count-only pass), with head-room
     need = [ctx.pwm_scan_hits_dev(bank, lens, dcodes.data_ptr(), N, L, rc, None, None, 0, n0=rank * N) for rc in (0, 1)]
     cap = int(max(need) * 1.05) + 1024
@@ -101,15 +104,28 @@ def main():
 
     def step():
         tot = 0
+        i = step_no[0] & 1
+        step_no[0] += 1
+        if pending[i] is not None:          # the all-reduce that last used this set of counters
+            pending[i].wait()
+            pending[i] = None
+        counts = counts_ring[i]
         for rc in (0, 1):
             tot += ctx.pwm_scan_hits_dev(bank, lens, dcodes.data_ptr(), N, L, rc, hits[rc].data_ptr(), hsc[rc].data_ptr(),
                                          cap, n0=rank * N, counts_ptr=counts[rc].data_ptr())
         if world > 1:  # the one real exchange of the scan: the K int64 hit counts of both strands
-            dist.all_reduce(counts)
+            pending[i] = dist.all_reduce(counts, async_op=True)
         return tot
+
+    def drain():
+        for i in (0, 1):
+            if pending[i] is not None:
+                pending[i].wait()
+                pending[i] = None
 
     for _ in range(args.warmup):
         step()
+    drain()
     torch.cuda.synchronize()
     ctx.enable_timing(True)
     ctx.reset_timing()
@@ -120,6 +136,7 @@ def main():
     nhits = 0
     for _ in range(args.steps):
         nhits = step()
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
