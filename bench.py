@@ -242,7 +242,7 @@ def main():
         ctx.encode_dev(traw.data_ptr(), lib.DATA_CODES_U8, St, L, tdev.data_ptr())
         tloss = torch.zeros(Gt, dtype=torch.float32, device="cuda")
         tgrad = torch.zeros(cdl.model.nP, dtype=torch.float32, device="cuda")
-        par.dp_train_step(cdl.model, tdev.data_ptr(), Gt, tloss, tgrad)        # warm-up
+        par.dp_train_step(cdl.model, tdev.data_ptr(), Gt, tloss, tgrad, Gt * world)        # warm-up
         torch.cuda.synchronize()
         ctx.enable_timing(True)
         ctx.reset_timing()
@@ -251,7 +251,7 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.train_steps):
-            par.dp_train_step(cdl.model, tdev.data_ptr(), Gt, tloss, tgrad)
+            par.dp_train_step(cdl.model, tdev.data_ptr(), Gt, tloss, tgrad, Gt * world)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()

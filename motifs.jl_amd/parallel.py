@@ -31,15 +31,18 @@ def allreduce_sum_(t):
     return t
 
 
-def dp_train_step(model, codes_ptr, n_groups_local, loss_t, grad_t):
+def dp_train_step(model, codes_ptr, n_groups_local, loss_t, grad_t, n_groups_total=None):
     """One data-parallel optimiser step: local summed gradient -> all-reduce -> mean -> AdaBelief
-    (identical on every rank, so the replicas stay bit-identical)."""
+    (identical on every rank, so the replicas stay bit-identical).  n_groups_total: the number of mini-batches
+    over all ranks when the caller knows it (equal shards); otherwise it is all-reduced too."""
     _, ws = world()
     model.loss_grad_dev(codes_ptr, n_groups_local, loss_t.data_ptr(), grad_t.data_ptr())
     allreduce_sum_(grad_t)
-    n_total = torch.tensor([n_groups_local], dtype=torch.int64, device=grad_t.device)
-    allreduce_sum_(n_total)
-    model.adabelief_dev(grad_t.data_ptr(), 1.0 / float(n_total.item()))
+    if n_groups_total is None:
+        n_total = torch.tensor([n_groups_local], dtype=torch.int64, device=grad_t.device)
+        allreduce_sum_(n_total)
+        n_groups_total = int(n_total.item())
+    model.adabelief_dev(grad_t.data_ptr(), 1.0 / float(n_groups_total))
     return loss_t
 
 
