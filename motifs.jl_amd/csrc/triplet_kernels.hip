@@ -306,17 +306,18 @@ int motifs_triplets_group_dev(motifs_ctx* c, const uint64_t* keys_dev, int64_t n
     typedef unsigned long long u64;
     // workspace: sorted keys, two index arrays, unique keys / counts / offsets / firsts / order (each at most n entries)
     const size_t nn = (size_t)n;
-    MOTIFS_HIP_CHECK(c->staging.reserve(nn * 8 + nn * 4 * 2 + nn * 8 + nn * 4 + nn * 8 + nn * 4 * 3 + 256));
+    const size_t seg = ((nn + 3) & ~(size_t)3);               // entries per array, rounded so that every array starts 16-byte aligned
+    MOTIFS_HIP_CHECK(c->staging.reserve(seg * (8 + 4 + 4 + 8 + 4 + 8 + 4 + 4 + 4) + 256));
     char* w = (char*)c->staging.p;
-    u64* ks = (u64*)w;                 w += nn * 8;
-    uint32_t* idx = (uint32_t*)w;      w += nn * 4;
-    uint32_t* idxs = (uint32_t*)w;     w += nn * 4;
-    u64* uks = (u64*)w;                w += nn * 8;
-    uint32_t* cnts = (uint32_t*)w;     w += nn * 4;
-    int64_t* offs = (int64_t*)w;       w += nn * 8;
-    uint32_t* firsts = (uint32_t*)w;   w += nn * 4;
-    uint32_t* firsts2 = (uint32_t*)w;  w += nn * 4;
-    uint32_t* order = (uint32_t*)w;    w += nn * 4;
+    u64* ks = (u64*)w;                 w += seg * 8;
+    uint32_t* idx = (uint32_t*)w;      w += seg * 4;
+    uint32_t* idxs = (uint32_t*)w;     w += seg * 4;
+    u64* uks = (u64*)w;                w += seg * 8;
+    uint32_t* cnts = (uint32_t*)w;     w += seg * 4;
+    int64_t* offs = (int64_t*)w;       w += seg * 8;
+    uint32_t* firsts = (uint32_t*)w;   w += seg * 4;
+    uint32_t* firsts2 = (uint32_t*)w;  w += seg * 4;
+    uint32_t* order = (uint32_t*)w;    w += seg * 4;
     uint32_t* runs = (uint32_t*)w;
     hipLaunchKernelGGL(k_iota, dim3(grid_for(n)), dim3(256), 0, st, idx, n);
     size_t tb = 0, tb2 = 0;
