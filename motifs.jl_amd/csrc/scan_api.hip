@@ -365,7 +365,7 @@ static int scan_hits_mfma(motifs_ctx* c, const BankSlot& bank, int K, const uint
         f.n0 = n0 + s0;
         f.hist_bins = (per_pwm_counts_dev && 2 * bank.KP <= FILL_HIST_MAX) ? 2 * bank.KP : 0;
         if (ns < nb * batch)   // cells of reads the last batch does not have are never written by the scan
-            MOTIFS_HIP_CHECK(hipMemsetAsync(c->cnt.p, 0, (size_t)nb * per_batch, c->stream));
+            MOTIFS_HIP_CHECK(hipMemsetAsync((char*)c->cnt.p + (size_t)(nb - 1) * per_batch, 0, per_batch, c->stream));
         {
             KernelTimer t(c, KS_SCAN_COUNT);
             MOTIFS_HIP_CHECK(launch_cand(a, c->stream));
