@@ -1436,72 +1436,56 @@ __global__ __launch_bounds__(128) void k_sp_syn_any(NzView nz, const float* __re
 }
 
 // The non-zeros come in ascending position p and each touches rows p .. p + h - 1, so the open rows live in a ring
-// of h LDS slots per column; a row is written to HBM once, when the sweep has passed it.
+// of 16 LDS slots per column (slot = row & 15, h <= 16); a row is written to HBM once, when the sweep has passed it.
+// HT = the filter height when it is the usual 12 (loops unroll without scalar bookkeeping), 0 = read it from d.
+template <int HT>
 __global__ __launch_bounds__(128) void k_sp_syn(NzView nz, const float* __restrict__ FAf, float* __restrict__ out,
                                                 SpDims d, int acc) {
-    extern __shared__ float ring[];                      // [h][128]
+    __shared__ float ring[16][128];
     const int s = blockIdx.y, tx = threadIdx.x, j = blockIdx.x * 128 + tx;
+    const int h = HT ? HT : d.h;
     const bool live = j < d.W;
     const int jc = live ? j : d.W - 1;
     const float* Fg = FAf + (size_t)(s / d.B) * d.ldf + jc;
     float* os = out + (size_t)s * d.c * d.W + jc;
-    for (int ip = 0; ip < d.h; ip++) ring[ip * 128 + tx] = 0.0f;
-    int base = 0, bslot = 0;                             // lowest open row and its ring slot (base % h)
-    auto close_rows = [&](int upto) {                    // rows [base, upto) are final
-        while (base < upto) {
-            const int nb = upto - base < 8 ? upto - base : 8;
-            float old[8];
 #pragma unroll
-            for (int u = 0; u < 8; u++)                  // the old values of an accumulating call, all loads in flight at once
-                old[u] = (acc && live && u < nb) ? os[(size_t)(base + u) * d.W] : 0.0f;
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                if (u < nb) {
-                    const float v = ring[bslot * 128 + tx];
-                    ring[bslot * 128 + tx] = 0.0f;
-                    if (live) os[(size_t)(base + u) * d.W] = old[u] + v;
-                    bslot = bslot + 1 == d.h ? 0 : bslot + 1;
-                }
-            }
-            base += nb;
-        }
-    };
+    for (int i = 0; i < 16; i++) ring[i][tx] = 0.0f;
+    int base = 0;                                        // lowest open row
     const int cnt = nz.cnt[s];
     const uint2* es = nz.ent + (size_t)s * nz.cap;
-    constexpr int MAXH = 16;                             // the launcher falls back to the dense form above this height
-    // one entry ahead: the filter values of entry z + 1 are in flight while entry z is folded into the ring
-    float fn[MAXH];
-    uint2 en_n = cnt > 0 ? es[0] : make_uint2(0u, 0u);
-    {
-        const int p = (int)(en_n.x / (unsigned)d.K), k = (int)(en_n.x - (unsigned)p * d.K);
-#pragma unroll
-        for (int ip = 0; ip < MAXH; ip++) fn[ip] = (cnt > 0 && ip < d.h) ? Fg[((size_t)ip * d.K + k) * d.W] : 0.0f;
-    }
-    for (int z = 0; z < cnt; z++) {                      // block-uniform control flow
-        const uint2 en = en_n;
-        float fc[MAXH];
-#pragma unroll
-        for (int ip = 0; ip < MAXH; ip++) fc[ip] = fn[ip];
-        if (z + 1 < cnt) {
-            en_n = es[z + 1];
-            const int pn = (int)(en_n.x / (unsigned)d.K), kn = (int)(en_n.x - (unsigned)pn * d.K);
-#pragma unroll
-            for (int ip = 0; ip < MAXH; ip++)
-                if (ip < d.h) fn[ip] = Fg[((size_t)ip * d.K + kn) * d.W];
+    const size_t kw = (size_t)d.K * d.W;
+    for (int z = 0; z <= cnt; z++) {                     // block-uniform control flow; the last trip closes the tail
+        int p = d.c, k = 0;
+        float v = 0.0f;
+        if (z < cnt) {
+            const uint2 en = es[z];
+            p = (int)(en.x / (unsigned)d.K);
+            k = (int)(en.x - (unsigned)p * d.K);
+            v = __uint_as_float(en.y);
         }
-        const int p = (int)(en.x / (unsigned)d.K);
-        const float v = __uint_as_float(en.y);
-        close_rows(p);                                   // now base == p (entries are sorted by p)
-        int slot = bslot == 0 ? d.h - 1 : bslot - 1;     // row p + h - 1 sits one slot before the base slot
+        float f[16];                                     // the entry's filter column, in flight while rows close
+        if (z < cnt) {
 #pragma unroll
-        for (int ip = 0; ip < MAXH; ip++) {              // row r = p + h - 1 - ip
-            if (ip < d.h) {
-                ring[slot * 128 + tx] = fmaf(v, fc[ip], ring[slot * 128 + tx]);
-                slot = slot == 0 ? d.h - 1 : slot - 1;
+            for (int ip = 0; ip < 16; ip++)
+                if (ip < h) f[ip] = Fg[(size_t)ip * kw + (size_t)k * d.W];
+        }
+        for (; base < p; base++) {                       // rows below p are final
+            const float r = ring[base & 15][tx];
+            ring[base & 15][tx] = 0.0f;
+            if (live) {
+                float* o = os + (size_t)base * d.W;
+                *o = acc ? *o + r : r;
             }
         }
+        if (z < cnt) {
+#pragma unroll
+            for (int ip = 0; ip < 16; ip++)
+                if (ip < h) {                            // row p + h - 1 - ip
+                    float* slot = &ring[(p + h - 1 - ip) & 15][tx];
+                    *slot = fmaf(v, f[ip], *slot);
+                }
+        }
     }
-    close_rows(d.c);
 }
 
 // S2: dFAf[g][ip][k][j] += sum_{s in g} sum_nz v * dOut[s][p + h - 1 - ip][j]     (block = (128 columns, ip, group))
@@ -1608,7 +1592,8 @@ static void launch_sp_ana_masked(hipStream_t st, const float* img, const float* 
 }
 
 static void launch_sp_syn(hipStream_t st, const NzView& nz, const float* FAf, float* out, const SpDims& d, int acc) {
-    if (d.h <= 16) hipLaunchKernelGGL(k_sp_syn, dim3((d.W + 127) / 128, d.S), dim3(128), (size_t)d.h * 128 * 4, st, nz, FAf, out, d, acc);
+    if (d.h == 12) hipLaunchKernelGGL(k_sp_syn<12>, dim3((d.W + 127) / 128, d.S), dim3(128), 0, st, nz, FAf, out, d, acc);
+    else if (d.h <= 16) hipLaunchKernelGGL(k_sp_syn<0>, dim3((d.W + 127) / 128, d.S), dim3(128), 0, st, nz, FAf, out, d, acc);
     else hipLaunchKernelGGL(k_sp_syn_any, dim3((d.W + 127) / 128, d.S), dim3(128), 0, st, nz, FAf, out, d, acc);
 }
 
