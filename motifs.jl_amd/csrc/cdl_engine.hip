@@ -1546,8 +1546,22 @@ __global__ __launch_bounds__(256) void k_sp_ana_masked(const float* __restrict__
         const int p = (int)(en.x / (unsigned)d.K), k = (int)(en.x - (unsigned)p * d.K);
         const float* fk = Fk + (size_t)(s / d.B) * d.ldf + (size_t)k * d.W * d.h;
         float a = 0.0f;
-        for (int j = lane; j < d.W; j += 64)
-            for (int i = 0; i < d.h; i++) a = fmaf(is[(size_t)(p + i) * d.W + j], fk[(size_t)j * d.h + i], a);
+        if (d.h == 12 && (((uintptr_t)fk) & 15) == 0) {      // the lane's 12 filter taps as three 16-byte loads
+            for (int j = lane; j < d.W; j += 64) {
+                const float4* f4 = (const float4*)(fk + (size_t)j * 12);
+                const float4 f0 = f4[0], f1 = f4[1], f2 = f4[2];
+                const float* ip = is + (size_t)p * d.W + j;
+                float x[12];
+#pragma unroll
+                for (int i = 0; i < 12; i++) x[i] = ip[(size_t)i * d.W];
+                a = fmaf(x[0], f0.x, a), a = fmaf(x[1], f0.y, a), a = fmaf(x[2], f0.z, a), a = fmaf(x[3], f0.w, a);
+                a = fmaf(x[4], f1.x, a), a = fmaf(x[5], f1.y, a), a = fmaf(x[6], f1.z, a), a = fmaf(x[7], f1.w, a);
+                a = fmaf(x[8], f2.x, a), a = fmaf(x[9], f2.y, a), a = fmaf(x[10], f2.z, a), a = fmaf(x[11], f2.w, a);
+            }
+        } else {
+            for (int j = lane; j < d.W; j += 64)
+                for (int i = 0; i < d.h; i++) a = fmaf(is[(size_t)(p + i) * d.W + j], fk[(size_t)j * d.h + i], a);
+        }
         for (int dd = 32; dd >= 1; dd >>= 1) a += __shfl_xor(a, dd);
         if (lane == 0) out[(size_t)s * d.l * d.K + en.x] += a;
     }
