@@ -1489,21 +1489,28 @@ __global__ __launch_bounds__(128) void k_sp_syn(NzView nz, const float* __restri
 }
 
 // S2: dFAf[g][ip][k][j] += sum_{s in g} sum_nz v * dOut[s][p + h - 1 - ip][j]     (block = (128 columns, ip, group))
+// Each thread owns the K outputs of its (ip, j): they are accumulated in a private LDS column (k is data-dependent)
+// and added to dF once, instead of a read-modify-write of global memory per non-zero.
 __global__ __launch_bounds__(128) void k_sp_wgrad_syn(NzView nz, const float* __restrict__ dOut, float* __restrict__ dF,
                                                       SpDims d) {
-    const int g = blockIdx.z, ip = blockIdx.y, j = blockIdx.x * 128 + threadIdx.x;
-    if (j >= d.W) return;
-    float* dFg = dF + (size_t)g * d.h * d.K * d.W + (size_t)ip * d.K * d.W;
+    extern __shared__ float accs[];                      // [K][128]
+    const int g = blockIdx.z, ip = blockIdx.y, tx = threadIdx.x, j = blockIdx.x * 128 + tx;
+    const int jc = j < d.W ? j : d.W - 1;                // clamp: out-of-range threads compute, do not store
+    for (int k = 0; k < d.K; k++) accs[k * 128 + tx] = 0.0f;
     for (int b = 0; b < d.B; b++) {
         const int s = g * d.B + b;
-        const float* ds = dOut + (size_t)s * d.c * d.W;
+        const float* ds = dOut + (size_t)s * d.c * d.W + (size_t)(d.h - 1 - ip) * d.W + jc;
         const int cnt = nz.cnt[s];
         const uint2* es = nz.ent + (size_t)s * nz.cap;
-        for (int z = 0; z < cnt; z++) {
+        for (int z = 0; z < cnt; z++) {                  // block-uniform
             const uint2 en = es[z];
             const int p = (int)(en.x / (unsigned)d.K), k = (int)(en.x - (unsigned)p * d.K);
-            dFg[(size_t)k * d.W + j] += __uint_as_float(en.y) * ds[(size_t)(p + d.h - 1 - ip) * d.W + j];
+            accs[k * 128 + tx] = fmaf(__uint_as_float(en.y), ds[(size_t)p * d.W], accs[k * 128 + tx]);
         }
+    }
+    if (j < d.W) {
+        float* dFg = dF + (size_t)g * d.h * d.K * d.W + (size_t)ip * d.K * d.W + j;
+        for (int k = 0; k < d.K; k++) dFg[(size_t)k * d.W] += accs[k * 128 + tx];
     }
 }
 
@@ -1636,7 +1643,7 @@ Tensor Engine::sp_syn(Tensor T, Tensor FAf, Tensor Fk, const SpDims& d) {
                 const int G = d.S / d.B;
                 if (!dF) return;
                 if (d.ldf != 0) {
-                    hipLaunchKernelGGL(k_sp_wgrad_syn, dim3((d.W + 127) / 128, d.h, G), dim3(128), 0, st, nz, out->g, dF, d);
+                    hipLaunchKernelGGL(k_sp_wgrad_syn, dim3((d.W + 127) / 128, d.h, G), dim3(128), (size_t)d.K * 128 * 4, st, nz, out->g, dF, d);
                 } else {
                     const size_t per = (size_t)d.h * d.K * d.W;
                     float* tmp = arena.alloc(per * G);
@@ -1645,7 +1652,7 @@ Tensor Engine::sp_syn(Tensor T, Tensor FAf, Tensor Fk, const SpDims& d) {
                         return;
                     }
                     (void)hipMemsetAsync(tmp, 0, per * G * 4, st);
-                    hipLaunchKernelGGL(k_sp_wgrad_syn, dim3((d.W + 127) / 128, d.h, G), dim3(128), 0, st, nz, out->g, tmp, d);
+                    hipLaunchKernelGGL(k_sp_wgrad_syn, dim3((d.W + 127) / 128, d.h, G), dim3(128), (size_t)d.K * 128 * 4, st, nz, out->g, tmp, d);
                     hipLaunchKernelGGL(k_sum_groups, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, st, tmp, per, G, dF);
                 }
             }
