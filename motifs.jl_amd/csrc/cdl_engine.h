@@ -101,7 +101,8 @@ struct Engine {
 
     // ---- primitives (each records its VJP) ----
     Tensor lin(Tensor x, float a, Tensor y, float b, float cst);          // a*x + b*y(bcast modulo y.n) + cst
-    Tensor lin3(Tensor x, float a, Tensor y, float b, Tensor z, float c);  // a*x + b*y + c*z (z optional), one pass
+    // a*x + b*(ymask .* y) + c*z in one pass (z, ymask optional; ymask is a constant 0/1 mask)
+    Tensor lin3(Tensor x, float a, Tensor y, float b, Tensor z, float c, const float* ymask = nullptr);
     // relu(ZY - lst*(g1 + pen*(ZY - FX - ab)) - ls*lst): the ISTA step of update_ZY fused (ab optional; scalars are 1-element tensors)
     Tensor zy_step(Tensor ZY, Tensor g1, Tensor FX, Tensor ab, Tensor pen, Tensor lst, Tensor ls);
     Tensor mul(Tensor x, Tensor y);                                       // x .* y (y broadcast modulo y.n)

@@ -229,16 +229,19 @@ __global__ void k_sumsq_groups_bwd(const float* gout, const float* x, size_t per
 }
 
 // a*x + b*y + c*z in one pass (z optional)
-__global__ void k_lin3(const float* x, float a, const float* y, float b, const float* z, float c, size_t n, float* out) {
+// ymask (optional): a constant 0/1 mask on y (cat_ZY's median mask), folded in instead of a separate masked copy of y
+__global__ void k_lin3(const float* x, float a, const float* y, const float* ymask, float b, const float* z, float c, size_t n,
+                       float* out) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        out[i] = a * x[i] + b * y[i] + (z ? c * z[i] : 0.0f);
+        out[i] = a * x[i] + b * (ymask ? ymask[i] * y[i] : y[i]) + (z ? c * z[i] : 0.0f);
 }
-// VJP of k_lin3: d{x,y,z} (+)= {a,b,c} * go, go read once
-__global__ void k_lin3_bwd(const float* go, size_t n, float a, float* dx, int ax, float b, float* dy, int ay, float c, float* dz, int az) {
+// VJP of k_lin3: d{x,y,z} (+)= {a,b*ymask,c} * go, go read once
+__global__ void k_lin3_bwd(const float* go, size_t n, float a, float* dx, int ax, float b, const float* ymask, float* dy, int ay, float c,
+                           float* dz, int az) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const float g = go[i];
         if (dx) dx[i] = (ax ? dx[i] : 0.0f) + a * g;
-        if (dy) dy[i] = (ay ? dy[i] : 0.0f) + b * g;
+        if (dy) dy[i] = (ay ? dy[i] : 0.0f) + b * (ymask ? ymask[i] * g : g);
         if (dz) dz[i] = (az ? dz[i] : 0.0f) + c * g;
     }
 }
@@ -313,22 +316,23 @@ Tensor Engine::lin(Tensor x, float a, Tensor y, float b, float cst) {
     return out;
 }
 
-Tensor Engine::lin3(Tensor x, float a, Tensor y, float b, Tensor z, float c) {
+Tensor Engine::lin3(Tensor x, float a, Tensor y, float b, Tensor z, float c, const float* ymask) {
     Tensor out = make(x->n, x->needs_grad || y->needs_grad || (z && z->needs_grad));
     if (failed) return out;
-    EW(k_lin3, x->n, x->v, a, y->v, b, z ? z->v : nullptr, c, x->n, out->v);
+    EW(k_lin3, x->n, x->v, a, y->v, ymask, b, z ? z->v : nullptr, c, x->n, out->v);
     if (recording && out->needs_grad)
-        tape.push_back([this, out, x, y, z, a, b, c]() {
+        tape.push_back([this, out, x, y, z, a, b, c, ymask]() {
             if (!out->g) return;
             if (x == y || x == z || (z && y == z)) {                  // aliased operands: one contribution at a time
-                Tensor ts[3] = {x, y, z};
-                const float cs[3] = {a, b, c};
-                for (int i = 0; i < 3; i++) {
-                    if (!ts[i] || !ts[i]->needs_grad) continue;
-                    int acc;
-                    float* d = grad_first(ts[i], acc);
-                    if (d) EW(k_axpy, out->n, out->g, cs[i], out->n, d, acc);
-                }
+                int ax;
+                float* dx = x->needs_grad ? grad_first(x, ax) : nullptr;
+                if (dx) EW(k_lin3_bwd, out->n, out->g, out->n, a, dx, ax, 0.0f, nullptr, nullptr, 1, 0.0f, nullptr, 1);
+                int ay;
+                float* dy = y->needs_grad ? grad_first(y, ay) : nullptr;
+                if (dy) EW(k_lin3_bwd, out->n, out->g, out->n, 0.0f, nullptr, 1, b, ymask, dy, ay, 0.0f, nullptr, 1);
+                int az;
+                float* dz = (z && z->needs_grad) ? grad_first(z, az) : nullptr;
+                if (dz) EW(k_lin3_bwd, out->n, out->g, out->n, 0.0f, nullptr, 1, 0.0f, nullptr, nullptr, 1, c, dz, az);
                 return;
             }
             int ax = 1, ay = 1, az = 1;
@@ -336,7 +340,7 @@ Tensor Engine::lin3(Tensor x, float a, Tensor y, float b, Tensor z, float c) {
             float* dy = y->needs_grad ? grad_first(y, ay) : nullptr;
             float* dz = (z && z->needs_grad) ? grad_first(z, az) : nullptr;
             if (failed) return;
-            EW(k_lin3_bwd, out->n, out->g, out->n, a, dx, ax, b, dy, ay, c, dz, az);
+            EW(k_lin3_bwd, out->n, out->g, out->n, a, dx, ax, b, ymask, dy, ay, c, dz, az);
         });
     return out;
 }

@@ -70,6 +70,14 @@ struct Graph {
         median_mask(e.st, ZY->v, mask->v, G, (int)(ZY->n / G), ws->v);
         return e.maskmul(ZY, mask->v, m->hp.magnifying_factor);
     }
+    // the mask of cat_ZY alone (constant in the backward, @ignore :208), for callers that fold it into their own pass
+    const float* zy_mask(Tensor ZY) {
+        Tensor mask = e.make(ZY->n, false);
+        Tensor ws = e.make(median_workspace_bytes(G) / 4 + 64, false);
+        if (e.failed) return nullptr;
+        median_mask(e.st, ZY->v, mask->v, G, (int)(ZY->n / G), ws->v);
+        return mask->v;
+    }
     // project_X (model.jl:181-192): keep the entries >= the q-th largest of each sequence
     Tensor project_X(Tensor Xu) {
         Tensor bit = e.make(Xu->n, false);
@@ -151,8 +159,9 @@ static void admm_xyz(motifs_model* m, Graph& gr, const Scalars& sc, const Graph:
         Tensor g1 = gr.anaD(diff, bD);
         ZY = e.zy_step(ZY, g1, FX, ab, sc.pen[t], sc.lst[t], sc.ls[t]);   // z_grad/y_grad + the shrinkage (:240-244)
         // update_X (:247-254); `sum(FX, dims=3)` is a no-op on the already summed FX
-        Tensor ZYm = gr.cat_ZY(ZY);
-        Tensor xg = gr.anaF(e.lin3(FX, 1.0f, ZYm, -1.0f, ab, 1.0f), bF);   // FX - (ZY - [alpha beta])
+        // FX - (cat_ZY(ZY) - [alpha beta]); the magnified, median-masked image is formed inside the same pass
+        const float* zm = gr.zy_mask(ZY);
+        Tensor xg = gr.anaF(e.lin3(FX, 1.0f, ZY, -m->hp.magnifying_factor, ab, 1.0f, zm), bF);
         X = gr.project_X(e.lin(X, 1.0f, e.mul(xg, sc.ost[t]), -1.0f, 0.0f));
         // (:263-266)
         FX = gr.synF(X, bF);
