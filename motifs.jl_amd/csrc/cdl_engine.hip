@@ -523,13 +523,27 @@ __global__ __launch_bounds__(256) void k_toep(const float* __restrict__ A, const
         __syncthreads();
     }
     float* Cs = C + (size_t)s * gm.ldc;
+    const bool vec = TN == 4 && (gm.N & 3) == 0 && (gm.ldc & 3) == 0 && (((uintptr_t)C) & 15) == 0;   // whole float4 per row
 #pragma unroll
     for (int i = 0; i < TM; i++) {
         const int p = p0 + ty * TM + i;
         if (p >= gm.P) continue;
+        const int nb = n0 + tx * TN;
+        if (vec) {
+            if (nb < gm.N) {
+                float4* o = (float4*)&Cs[(size_t)p * gm.N + nb];
+                float4 v = make_float4(accv[i][0], accv[i][1 % TN], accv[i][2 % TN], accv[i][3 % TN]);
+                if (acc) {
+                    const float4 t = *o;
+                    v.x += t.x, v.y += t.y, v.z += t.z, v.w += t.w;
+                }
+                *o = v;
+            }
+            continue;
+        }
 #pragma unroll
         for (int j = 0; j < TN; j++) {
-            const int n = n0 + tx * TN + j;
+            const int n = nb + j;
             if (n < gm.N) {
                 float* o = &Cs[(size_t)p * gm.N + n];
                 *o = acc ? *o + accv[i][j] : accv[i][j];
