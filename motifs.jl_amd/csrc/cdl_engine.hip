@@ -1369,15 +1369,47 @@ __global__ void k_swap02(const float* x, int g, int d0, int d1, int d2, float* o
         out[i] = acc ? out[i] + v : v;
     }
 }
+// the same through an LDS tile of 16 middle indices: both the reads ([d0][16][d2]: runs of 16*d2 floats) and the writes
+// ([d2][16][d0]: runs of 16*d0 floats) are then contiguous instead of 4-byte accesses d1*d2 floats apart
+constexpr int SWAP_T1 = 16;
+__global__ __launch_bounds__(256) void k_swap02_tiled(const float* __restrict__ x, int d0, int d1, int d2, float* __restrict__ out, int acc) {
+    extern __shared__ float tile[];                      // [d0][T1][d2 + 1]
+    const int gg = blockIdx.y, j0 = blockIdx.x * SWAP_T1;
+    const int nj = d1 - j0 < SWAP_T1 ? d1 - j0 : SWAP_T1;
+    const size_t per = (size_t)d0 * d1 * d2;
+    const float* xs = x + (size_t)gg * per;
+    float* os = out + (size_t)gg * per;
+    const int run_in = nj * d2, p2 = d2 + 1;
+    for (int i = threadIdx.x; i < d0 * run_in; i += 256) {       // x[i0][j0 + jj][i2], contiguous in (jj, i2)
+        const int i0 = i / run_in, r = i - i0 * run_in, jj = r / d2, i2 = r - jj * d2;
+        tile[(i0 * SWAP_T1 + jj) * p2 + i2] = xs[((size_t)i0 * d1 + j0) * d2 + r];
+    }
+    __syncthreads();
+    const int run_out = nj * d0;
+    for (int i = threadIdx.x; i < d2 * run_out; i += 256) {      // out[i2][j0 + jj][i0], contiguous in (jj, i0)
+        const int i2 = i / run_out, r = i - i2 * run_out, jj = r / d0, i0 = r - jj * d0;
+        float* o = &os[((size_t)i2 * d1 + j0) * d0 + r];
+        const float v = tile[(i0 * SWAP_T1 + jj) * p2 + i2];
+        *o = acc ? *o + v : v;
+    }
+}
+static void launch_swap02(hipStream_t st, const float* x, int g, int d0, int d1, int d2, float* out, int acc) {
+    const size_t lds = (size_t)d0 * SWAP_T1 * (d2 + 1) * 4;
+    if (lds <= 48 * 1024)
+        hipLaunchKernelGGL(k_swap02_tiled, dim3((d1 + SWAP_T1 - 1) / SWAP_T1, g), dim3(256), lds, st, x, d0, d1, d2, out, acc);
+    else
+        hipLaunchKernelGGL(k_swap02, dim3(nblocks((size_t)g * d0 * d1 * d2)), dim3(256), 0, st, x, g, d0, d1, d2, out, acc);
+}
+
 Tensor Engine::swap02(Tensor x, int g, int d0, int d1, int d2) {
     Tensor out = make(x->n, x->needs_grad);
     if (failed) return out;
-    EW(k_swap02, x->n, x->v, g, d0, d1, d2, out->v, 0);
+    launch_swap02(st, x->v, g, d0, d1, d2, out->v, 0);
     if (recording && out->needs_grad)
         tape.push_back([this, out, x, g, d0, d1, d2]() {
             int acc;
             float* dx = out->g ? grad_first(x, acc) : nullptr;
-            if (dx) EW(k_swap02, x->n, out->g, g, d2, d1, d0, dx, acc);
+            if (dx) launch_swap02(st, out->g, g, d2, d1, d0, dx, acc);
         });
     return out;
 }
@@ -1745,7 +1777,7 @@ Tensor Engine::wgrad_sp(Tensor img, Tensor T, const SpDims& d) {
                         failed = true;
                         return;
                     }
-                    hipLaunchKernelGGL(k_swap02, dim3(nblocks(per * G)), dim3(256), 0, st, out->g, G, d.h, d.W, d.K, tk, 0);
+                    launch_swap02(st, out->g, G, d.h, d.W, d.K, tk, 0);
                     NzView mz = nz_of_mask(T, d.S);
                     if (!failed) launch_sp_ana_masked(st, img->v, tk, mz, dT, dg, d.l * d.K);
                 } else {
