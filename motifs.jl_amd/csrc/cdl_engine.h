@@ -21,6 +21,7 @@
 #include <functional>
 #include <map>
 #include <string>
+#include <utility>
 #include <vector>
 
 namespace motifs {
@@ -105,6 +106,8 @@ struct Engine {
     Tensor lin3(Tensor x, float a, Tensor y, float b, Tensor z, float c, const float* ymask = nullptr);
     // relu(ZY - lst*(g1 + pen*(ZY - FX - ab)) - ls*lst): the ISTA step of update_ZY fused (ab optional; scalars are 1-element tensors)
     Tensor zy_step(Tensor ZY, Tensor g1, Tensor FX, Tensor ab, Tensor pen, Tensor lst, Tensor ls);
+    // the same with the dual update folded in: abn = FX - ZY + abp (abp optional), then the step with abn; returns {out, abn}
+    std::pair<Tensor, Tensor> zy_step2(Tensor ZY, Tensor g1, Tensor FX, Tensor abp, Tensor pen, Tensor lst, Tensor ls);
     Tensor mul(Tensor x, Tensor y);                                       // x .* y (y broadcast modulo y.n)
     Tensor relu(Tensor x);
     Tensor maskmul(Tensor x, const float* mask, float c);                 // c * mask .* x, mask constant

@@ -297,6 +297,66 @@ __global__ void k_zy_step_bwd(const float* go, const float* out, const float* ZY
     }
 }
 
+// The same step with the dual update of the previous pass folded in (model.jl:263-266 then :240-244): the scaled
+// duals [alpha beta] advance by FX - ZY on entry,
+//   abn = FX - ZY + abp                         (abp optional: zero duals, :338)
+//   out = relu(ZY - lst * (g1 + pen * (ZY - FX - abn)) - ls * lst)
+// which saves the separate three-term pass (and its VJP) per ADMM pass.
+__global__ void k_zy_step2(const float* ZY, const float* g1, const float* FX, const float* abp, const float* pen, const float* lst,
+                           const float* ls, size_t n, float* out, float* abn) {
+    const float p = *pen, s = *lst, l = *ls;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float zy = ZY[i], fx = FX[i];
+        const float dual = (fx - zy) + (abp ? abp[i] : 0.0f);
+        const float inner = zy - (fx + dual);
+        const float grad = g1[i] + inner * p;
+        const float u = (zy - grad * s) - l * s;
+        abn[i] = dual;
+        out[i] = u > 0.0f ? u : 0.0f;
+    }
+}
+// VJP: go = d out (may be null), gab = d abn (may be null).  inner = 2 ZY - 2 FX - abp.
+__global__ void k_zy_step2_bwd(const float* go, const float* gab, const float* out, const float* ZY, const float* g1, const float* FX,
+                               const float* abp, const float* pen, const float* lst, const float* ls, size_t n, float* dZY, int aZY,
+                               float* dg1, int ag1, float* dFX, int aFX, float* dabp, int aabp, float* dpen, float* dlst, float* dls) {
+    const float p = *pen, s = *lst, l = *ls;
+    double sp = 0, ss = 0, sl = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float du = (go && out[i] > 0.0f) ? go[i] : 0.0f;
+        const float gb = gab ? gab[i] : 0.0f;
+        const float zy = ZY[i], fx = FX[i];
+        const float dual = (fx - zy) + (abp ? abp[i] : 0.0f);
+        const float inner = zy - (fx + dual);
+        const float grad = g1[i] + inner * p;
+        const float t = s * p * du;
+        if (dZY) dZY[i] = (aZY ? dZY[i] : 0.0f) + (du - 2.0f * t) - gb;
+        if (dg1) dg1[i] = (ag1 ? dg1[i] : 0.0f) - s * du;
+        if (dFX) dFX[i] = (aFX ? dFX[i] : 0.0f) + 2.0f * t + gb;
+        if (dabp) dabp[i] = (aabp ? dabp[i] : 0.0f) + t + gb;
+        sp -= (double)du * (double)(s * inner);
+        ss -= (double)du * (double)(grad + l);
+        sl -= (double)du * (double)s;
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+        sp += __shfl_xor(sp, d);
+        ss += __shfl_xor(ss, d);
+        sl += __shfl_xor(sl, d);
+    }
+    __shared__ double red[3][4];
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        red[0][wv] = sp;
+        red[1][wv] = ss;
+        red[2][wv] = sl;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (dpen) atomicAdd(dpen, (float)(red[0][0] + red[0][1] + red[0][2] + red[0][3]));
+        if (dlst) atomicAdd(dlst, (float)(red[1][0] + red[1][1] + red[1][2] + red[1][3]));
+        if (dls) atomicAdd(dls, (float)(red[2][0] + red[2][1] + red[2][2] + red[2][3]));
+    }
+}
+
 #define EW(kern, n, ...) hipLaunchKernelGGL(kern, dim3(nblocks(n)), dim3(256), 0, st, __VA_ARGS__)
 
 Tensor Engine::lin(Tensor x, float a, Tensor y, float b, float cst) {
@@ -367,6 +427,31 @@ Tensor Engine::zy_step(Tensor ZY, Tensor g1, Tensor FX, Tensor ab, Tensor pen, T
                                ab ? ab->v : nullptr, pen->v, lst->v, ls->v, out->n, d0, a0, d1, a1, d2, a2, d3, a3, dp, ds, dl);
         });
     return out;
+}
+
+std::pair<Tensor, Tensor> Engine::zy_step2(Tensor ZY, Tensor g1, Tensor FX, Tensor abp, Tensor pen, Tensor lst, Tensor ls) {
+    const bool ng = ZY->needs_grad || g1->needs_grad || FX->needs_grad || (abp && abp->needs_grad) || pen->needs_grad ||
+                    lst->needs_grad || ls->needs_grad;
+    Tensor out = make(ZY->n, ng);
+    Tensor abn = make(ZY->n, ng);
+    if (failed) return {out, abn};
+    EW(k_zy_step2, ZY->n, ZY->v, g1->v, FX->v, abp ? abp->v : nullptr, pen->v, lst->v, ls->v, ZY->n, out->v, abn->v);
+    if (recording && ng)
+        tape.push_back([this, out, abn, ZY, g1, FX, abp, pen, lst, ls]() {
+            if (!out->g && !abn->g) return;
+            int a0 = 1, a1 = 1, a2 = 1, a3 = 1;
+            float* d0 = ZY->needs_grad ? grad_first(ZY, a0) : nullptr;
+            float* d1 = g1->needs_grad ? grad_first(g1, a1) : nullptr;
+            float* d2 = FX->needs_grad ? grad_first(FX, a2) : nullptr;
+            float* d3 = (abp && abp->needs_grad) ? grad_first(abp, a3) : nullptr;
+            float* dp = pen->needs_grad ? grad(pen) : nullptr;
+            float* ds = lst->needs_grad ? grad(lst) : nullptr;
+            float* dl = ls->needs_grad ? grad(ls) : nullptr;
+            if (failed) return;
+            hipLaunchKernelGGL(k_zy_step2_bwd, dim3(nblocks(out->n, 256, 2048)), dim3(256), 0, st, out->g, abn->g, out->v, ZY->v, g1->v,
+                               FX->v, abp ? abp->v : nullptr, pen->v, lst->v, ls->v, out->n, d0, a0, d1, a1, d2, a2, d3, a3, dp, ds, dl);
+        });
+    return {out, abn};
 }
 
 Tensor Engine::mul(Tensor x, Tensor y) {

@@ -157,15 +157,20 @@ static void admm_xyz(motifs_model* m, Graph& gr, const Scalars& sc, const Graph:
         // update_ZY (:237-245)
         Tensor diff = e.lin(gr.synD(ZY, bD), 1.0f, gr.Sone, -1.0f, 0.0f);
         Tensor g1 = gr.anaD(diff, bD);
-        ZY = e.zy_step(ZY, g1, FX, ab, sc.pen[t], sc.lst[t], sc.ls[t]);   // z_grad/y_grad + the shrinkage (:240-244)
+        if (t == 0) {
+            ZY = e.zy_step(ZY, g1, FX, nullptr, sc.pen[t], sc.lst[t], sc.ls[t]);   // z_grad/y_grad + the shrinkage (:240-244)
+        } else {
+            // the dual update that closes the previous pass (:263-266: ab += FX - ZY) rides in the same kernel
+            auto r = e.zy_step2(ZY, g1, FX, ab, sc.pen[t], sc.lst[t], sc.ls[t]);
+            ZY = r.first;
+            ab = r.second;
+        }
         // update_X (:247-254); `sum(FX, dims=3)` is a no-op on the already summed FX
         // FX - (cat_ZY(ZY) - [alpha beta]); the magnified, median-masked image is formed inside the same pass
         const float* zm = gr.zy_mask(ZY);
         Tensor xg = gr.anaF(e.lin3(FX, 1.0f, ZY, -m->hp.magnifying_factor, ab, 1.0f, zm), bF);
         X = gr.project_X(e.lin(X, 1.0f, e.mul(xg, sc.ost[t]), -1.0f, 0.0f));
-        // (:263-266)
-        FX = gr.synF(X, bF);
-        ab = e.lin3(FX, 1.0f, ZY, -1.0f, ab, 1.0f);
+        FX = gr.synF(X, bF);                                              // the duals advance at the top of the next pass
     }
     e.note("ZY", ZY);
     e.note("X", X);
