@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 
 namespace motifs {
 
@@ -873,6 +874,169 @@ __global__ __launch_bounds__(512) void k_toep_mfma(const float* __restrict__ A, 
     }
 }
 
+// The syntax-layer analysis (model.jl:251, conv(img, F, flipped)) with the image resident in LDS.  The Toeplitz
+// rows of one sequence overlap by (H-1)/H, so a block keeps the 32 + H - 1 image rows of its 32 output rows in
+// LDS (CC channels at a time, double buffered) and feeds the matrix cores from there: one ds_read per MFMA for
+// the image operand.  The filter operand comes from a copy of the bank in fragment order (k_frag_b): the 64
+// lane values of four consecutive MFMA steps lie together, so one 16-byte load per lane (1 KB per wave,
+// contiguous) feeds four MFMAs; the bank stays in L2.  4 waves split the reduction (window rows j), partial
+// tiles meet in LDS and leave as one contiguous [32][N] span.
+//   Bf[g][t][lane][u] = B[g][8t + 2u + (lane >> 5)][min(lane & 31, N-1)]     (columns >= N are never stored)
+__global__ void k_frag_b(const float* __restrict__ Bm, int G, int Q, int N, float* __restrict__ out) {
+    const size_t per = (size_t)(Q / 8) * 256, total = per * G;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t g = i / per, r = i - g * per;
+        const int u = (int)(r & 3), lane = (int)((r >> 2) & 63);
+        const size_t t = r >> 8;
+        const size_t q = 8 * t + 2 * u + (lane >> 5);
+        out[i] = Bm[g * (size_t)Q * N + q * N + min(lane & 31, N - 1)];
+    }
+}
+template <int H, int CC>
+__global__ __launch_bounds__(256) void k_ana_lds(const float* __restrict__ A, const float* __restrict__ Bf, float* __restrict__ C,
+                                                 ToepGeom gm, int acc, int tps, int64_t ldbf) {
+    constexpr int ST = CC + 1, ROWS = 32 + H, JW = H / 4, C4 = CC / 4, NV = (ROWS * C4 + 255) / 256;   // one spare row
+    extern __shared__ float lds[];                 // 2 x [ROWS][ST]; at the end 4 x [32][32]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int s = blockIdx.x / tps, p0 = (blockIdx.x - s * tps) * 32;
+    const int W = gm.sa, NCH = W / CC, N = gm.N;
+    const float* img = A + (size_t)s * gm.lda + gm.a0 + (size_t)p0 * W;
+    const int lim = gm.amax - gm.a0 - p0 * W;      // valid flat range seen from img
+    const float4* Bg = (const float4*)(Bf + (size_t)(s / gm.B) * ldbf) + lane;
+    float4 v[NV];
+    auto gload = [&](int c0) {
+#pragma unroll
+        for (int i = 0; i < NV; i++) {
+            const int idx = tid + i * 256, row = idx / C4, c4 = idx - row * C4;
+            const int flat = row * W + c0 + c4 * 4;
+            const bool ok = idx < ROWS * C4 && flat + 3 < lim;
+            const float4 x = *(const float4*)(img + (ok ? flat : 0));
+            v[i] = ok ? x : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto lstore = [&](float* buf) {
+#pragma unroll
+        for (int i = 0; i < NV; i++) {
+            const int idx = tid + i * 256, row = idx / C4, c4 = idx - row * C4;
+            if (idx < ROWS * C4) {
+                float* d = buf + row * ST + c4 * 4;
+                d[0] = v[i].x, d[1] = v[i].y, d[2] = v[i].z, d[3] = v[i].w;
+            }
+        }
+    };
+    f32x16 accv;
+#pragma unroll
+    for (int i = 0; i < 16; i++) accv[i] = 0.0f;
+    const int aoff = ((lane & 31) + wave * JW) * ST + (lane >> 5);
+    constexpr int NI = CC / 2, FJ = CC / 8;         // MFMAs and filter fragments (4 MFMAs each) per window row and chunk
+    constexpr int PF = FJ % 5 == 0 ? 5 : 4;         // fragments in flight
+    static_assert(CC % 8 == 0 && FJ % PF == 0, "the fragment ring carries over from window row to window row");
+    // fragments of window row j, chunk ch: channels ch*CC + 8 * f .., f < FJ
+    auto bbase = [&](int ch, int j) -> const float4* { return Bg + ((((size_t)j * W + (size_t)ch * CC) >> 3) << 6); };
+    float4 br[PF];
+    gload(0);
+    {
+        const float4* b0 = bbase(0, wave * JW);
+#pragma unroll
+        for (int i = 0; i < PF; i++) br[i] = b0[i * 64];
+    }
+    lstore(lds);
+    __syncthreads();
+    for (int ch = 0; ch < NCH; ch++) {
+        float* buf = lds + (ch & 1) * (ROWS * ST);
+        const bool more = ch + 1 < NCH;
+        if (more) gload((ch + 1) * CC);            // in flight under the MFMAs below
+        const float* a = buf + aoff;
+        float ar[4];
+        ar[0] = a[0], ar[1] = a[2], ar[2] = a[4], ar[3] = a[6];
+#pragma unroll 1
+        for (int jj = 0; jj < JW; jj++) {
+            const float4* cur = bbase(ch, wave * JW + jj);
+            const float4* nxt = jj + 1 < JW ? bbase(ch, wave * JW + jj + 1) : more ? bbase(ch + 1, wave * JW) : cur;
+#pragma unroll
+            for (int i = 0; i < NI; i++) {
+                const float4 bq = br[(i / 4) % PF];
+                const float av = ar[i & 3], bv = (i & 3) == 0 ? bq.x : (i & 3) == 1 ? bq.y : (i & 3) == 2 ? bq.z : bq.w;
+                // four steps ahead; past the end of the row that is the start of the next one (the spare LDS row after the last)
+                ar[i & 3] = i + 4 < NI ? a[2 * (i + 4)] : a[ST + 2 * (i + 4 - NI)];
+                accv = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, accv, 0, 0, 0);
+                if ((i & 3) == 3) {                // the fragment is used up: refill its slot
+                    const int f = i / 4 + PF;
+                    br[(i / 4) % PF] = f < FJ ? cur[f * 64] : nxt[(f - FJ) * 64];
+                }
+                __builtin_amdgcn_sched_barrier(0); // keep the prefetch distances as written
+            }
+            a += ST;
+        }
+        if (more) lstore(lds + ((ch + 1) & 1) * (ROWS * ST));
+        __syncthreads();
+    }
+    // partial tiles -> LDS [wave][row][32]; register r of lane l is (row (r&3) + 8*(r>>2) + 4*(l>>5), column l&31)
+    float* red = lds + wave * 1024;
+#pragma unroll
+    for (int r = 0; r < 16; r++) red[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = accv[r];
+    __syncthreads();
+    const int nrow = min(32, gm.P - p0);
+    float* Cs = C + (size_t)s * gm.ldc + (size_t)p0 * N;
+    const int total = nrow * N;                    // one contiguous span of the output
+    const bool vec = (N & 3) == 0 && (((uintptr_t)Cs) & 15) == 0;
+    if (vec) {
+        for (int e4 = tid; e4 * 4 < total; e4 += 256) {
+            const int e = e4 * 4, row = e / N, col = e - row * N;
+            const float* q = lds + row * 32 + col;
+            float4 o;
+            o.x = (q[0] + q[1024]) + (q[2048] + q[3072]);
+            o.y = (q[1] + q[1025]) + (q[2049] + q[3073]);
+            o.z = (q[2] + q[1026]) + (q[2050] + q[3074]);
+            o.w = (q[3] + q[1027]) + (q[2051] + q[3075]);
+            float4* dst = (float4*)(Cs + e);
+            if (acc) {
+                const float4 t = *dst;
+                o.x += t.x, o.y += t.y, o.z += t.z, o.w += t.w;
+            }
+            *dst = o;
+        }
+    } else {
+        for (int e = tid; e < total; e += 256) {
+            const int row = e / N, col = e - row * N;
+            const float* q = lds + row * 32 + col;
+            const float o = (q[0] + q[1024]) + (q[2048] + q[3072]);
+            Cs[e] = acc ? Cs[e] + o : o;
+        }
+    }
+}
+// the shapes k_ana_lds takes: whole in-bounds windows of H = 4k image rows, up to 32 output channels
+template <int H, int CC>
+static bool launch_ana_lds(Engine& e, const float* A, const float* Bm, float* C, const ToepGeom& gm, int acc) {
+    if (gm.sa <= 0 || gm.Q != H * gm.sa || gm.sa % CC != 0 || gm.N < 9 || gm.N > 32) return false;
+    if (gm.a0 < 0 || (int64_t)gm.a0 + (int64_t)(gm.P - 1) * gm.sa + gm.Q > gm.amax) return false;
+    if ((gm.sa & 7) || (gm.a0 & 3) || (gm.lda & 3) || (((uintptr_t)A) & 15)) return false;
+    constexpr int need = 2 * (32 + H) * (CC + 1) * 4 > 16384 ? 2 * (32 + H) * (CC + 1) * 4 : 16384;
+    const int tps = (gm.P + 31) / 32;
+    const long jobs = (long)gm.S * tps;
+    const int gB = gm.ldb == 0 ? 1 : gm.S / gm.B;
+    const size_t perf = (size_t)(gm.Q / 8) * 256;
+    float* Bf = e.arena.alloc(perf * gB);
+    if (!Bf) {
+        e.failed = true;
+        return true;
+    }
+    hipLaunchKernelGGL(k_frag_b, dim3(nblocks(perf * gB)), dim3(256), 0, e.st, Bm, gB, gm.Q, gm.N, Bf);
+    // blocks per CU: the count whose rounds x resident waves is smallest (all blocks take the same time)
+    int best = 1;
+    long cost = -1;
+    for (int k = 1; k <= 4 && k * need <= 160 * 1024; k++) {
+        const long c = ((jobs + 256L * k - 1) / (256L * k)) * k;
+        if (cost < 0 || c <= cost) cost = c, best = k;
+    }
+    int lds = (160 * 1024 / best) & ~1023;
+    if (lds > 64 * 1024) lds = 64 * 1024;
+    if (lds < need) lds = need;
+    hipLaunchKernelGGL((k_ana_lds<H, CC>), dim3((unsigned)jobs), dim3(256), (size_t)lds, e.st, A, Bf, C, gm, acc, tps,
+                       (int64_t)(gm.ldb == 0 ? 0 : perf));
+    return true;
+}
+
 // N <= 4 outputs (D-layer synthesis and its relatives: an image 4 bases wide): one row per lane, 4
 // accumulators, 8 waves = 2 row tiles of 64 x 4 slices of the reduction, wave-private LDS as above.
 __global__ __launch_bounds__(512) void k_toep_n4(const float* __restrict__ A, const float* __restrict__ Bm,
@@ -1093,6 +1257,13 @@ static void launch_toep(Engine& e, const float* A, const float* Bm, float* C, co
                            dim3(512), 0, st, A, Bt, Wt, rg, 0);
         hipLaunchKernelGGL(k_tall_gather, dim3(nblocks((size_t)gm.S * gm.P * gm.N)), dim3(256), 0, st, Wt, C, gm.S, gm.P, H, gm.N, R,
                            gm.a0 / gm.sa, gm.ldc, acc);
+        return;
+    }
+    static const bool legacy = getenv("MOTIFS_TOEP_LEGACY") != nullptr;   // debugging aid: the pre-LDS kernels
+    if (legacy) {
+    } else if (launch_ana_lds<12, 80>(e, A, Bm, C, gm, acc) || launch_ana_lds<12, 64>(e, A, Bm, C, gm, acc) ||
+               launch_ana_lds<12, 32>(e, A, Bm, C, gm, acc) || launch_ana_lds<8, 64>(e, A, Bm, C, gm, acc) ||
+               launch_ana_lds<8, 32>(e, A, Bm, C, gm, acc)) {
         return;
     }
     // MFMA form: narrow output, long reduction (tiles never straddle two filter groups)
