@@ -1215,6 +1215,149 @@ __global__ void k_tall_scatter(const float* __restrict__ dC, float* __restrict__
     }
 }
 
+// The row GEMM of the tall forms on the matrix cores: C[r][n] = sum_q A[r][q] B[q][n] over contiguous rows of Q
+// floats, N <= 64 outputs (the D-layer synthesis: 400 channels -> 12 lags x 4 bases).  HBM-bound (the rows are read
+// once), so a block takes 32 rows whole into LDS with 16-byte loads, its 4 waves split the reduction, and
+// v_mfma_f32_16x16x4_f32 tiles cover N in 16-column blocks (48 = 3 blocks, nothing padded).  The filter comes in
+// fragment order, one 16-byte load per lane and reduction step for all column blocks:
+//   Bf[g][ks][lane][cb] = B[g][4 ks + (lane >> 4)][min(16 cb + (lane & 15), N-1)]
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__global__ void k_frag_b16(const float* __restrict__ Bm, int G, int Q, int N, float* __restrict__ out) {
+    const size_t per = (size_t)(Q / 4) * 256, total = per * G;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t g = i / per, r = i - g * per;
+        const int cb = (int)(r & 3), lane = (int)((r >> 2) & 63);
+        const size_t q = 4 * (r >> 8) + (lane >> 4);
+        out[i] = 16 * cb < N ? Bm[g * (size_t)Q * N + q * N + min(16 * cb + (lane & 15), N - 1)] : 0.0f;
+    }
+}
+template <int NT>
+__global__ __launch_bounds__(256) void k_rowgemm_lds(const float* __restrict__ A, const float* __restrict__ Bf, float* __restrict__ C,
+                                                     int rpg, int tpg, int Q, int N, int64_t ldbf, int acc) {
+    constexpr int NV = 15, U = 4;                  // 16-byte loads per thread (Q <= 480); reduction steps per prefetch unit
+    extern __shared__ float lds[];                 // [32][Q + 1]; at the end 4 x [32][16 NT]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = blockIdx.x / tpg, r0 = (blockIdx.x - g * tpg) * 32;
+    const int nrow = min(32, rpg - r0), ST = Q + 1, Q4 = Q >> 2;
+    const size_t row0 = (size_t)g * rpg + r0;
+    const float4* At = (const float4*)(A + row0 * Q);
+    const int nf4 = nrow * Q4, tf4 = 32 * Q4;
+    float4 v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+        const int idx = tid + i * 256;
+        const float4 x = At[idx < nf4 ? idx : 0];
+        v[i] = idx < nf4 ? x : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    {
+        int row = tid / Q4, c4 = tid - row * Q4;
+        const int drow = 256 / Q4, dc = 256 - drow * Q4;
+#pragma unroll
+        for (int i = 0; i < NV; i++) {
+            if (tid + i * 256 < tf4) {
+                float* d = lds + row * ST + c4 * 4;
+                d[0] = v[i].x, d[1] = v[i].y, d[2] = v[i].z, d[3] = v[i].w;
+            }
+            row += drow, c4 += dc;
+            if (c4 >= Q4) c4 -= Q4, row++;
+        }
+    }
+    __syncthreads();
+    f32x4 accv[2][NT];
+#pragma unroll
+    for (int rb = 0; rb < 2; rb++)
+#pragma unroll
+        for (int cb = 0; cb < NT; cb++) accv[rb][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nks = Q >> 4;                        // reduction steps (4 channels each) of this wave
+    const float* a0p = lds + (lane & 15) * ST + wave * (Q >> 2) + (lane >> 4);
+    const float* a1p = a0p + 16 * ST;
+    const float4* bp = (const float4*)(Bf + (size_t)g * ldbf) + (size_t)(wave * nks) * 64 + lane;
+    float4 cur[U], nxt[U];
+#pragma unroll
+    for (int i = 0; i < U; i++) cur[i] = bp[(size_t)min(i, nks - 1) * 64];
+    for (int u0 = 0; u0 < nks; u0 += U) {
+#pragma unroll
+        for (int i = 0; i < U; i++) nxt[i] = bp[(size_t)min(u0 + U + i, nks - 1) * 64];
+#pragma unroll
+        for (int i = 0; i < U; i++) {
+            if (u0 + i < nks) {
+                const float a0 = a0p[4 * (u0 + i)], a1 = a1p[4 * (u0 + i)];
+                const float bv[4] = {cur[i].x, cur[i].y, cur[i].z, cur[i].w};
+#pragma unroll
+                for (int cb = 0; cb < NT; cb++) {
+                    accv[0][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bv[cb], accv[0][cb], 0, 0, 0);
+                    accv[1][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bv[cb], accv[1][cb], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < U; i++) cur[i] = nxt[i];
+    }
+    __syncthreads();                               // the image rows are done with: partial tiles take their place
+    constexpr int RW = 16 * NT;
+    float* red = lds + wave * (32 * RW);
+#pragma unroll
+    for (int rb = 0; rb < 2; rb++)
+#pragma unroll
+        for (int cb = 0; cb < NT; cb++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) red[(rb * 16 + 4 * (lane >> 4) + r) * RW + cb * 16 + (lane & 15)] = accv[rb][cb][r];
+    __syncthreads();
+    float* Cs = C + row0 * N;
+    const int total = nrow * N;                    // one contiguous span of the output
+    const bool vec = (N & 3) == 0 && (((uintptr_t)Cs) & 15) == 0;
+    if (vec) {
+        for (int e4 = tid; e4 * 4 < total; e4 += 256) {
+            const int e = e4 * 4, row = e / N, col = e - row * N;
+            const float* q = lds + row * RW + col;
+            float4 o;
+            o.x = (q[0] + q[32 * RW]) + (q[64 * RW] + q[96 * RW]);
+            o.y = (q[1] + q[32 * RW + 1]) + (q[64 * RW + 1] + q[96 * RW + 1]);
+            o.z = (q[2] + q[32 * RW + 2]) + (q[64 * RW + 2] + q[96 * RW + 2]);
+            o.w = (q[3] + q[32 * RW + 3]) + (q[64 * RW + 3] + q[96 * RW + 3]);
+            float4* dst = (float4*)(Cs + e);
+            if (acc) {
+                const float4 t = *dst;
+                o.x += t.x, o.y += t.y, o.z += t.z, o.w += t.w;
+            }
+            *dst = o;
+        }
+    } else {
+        for (int e = tid; e < total; e += 256) {
+            const int row = e / N, col = e - row * N;
+            const float* q = lds + row * RW + col;
+            const float o = (q[0] + q[32 * RW]) + (q[64 * RW] + q[96 * RW]);
+            Cs[e] = acc ? Cs[e] + o : o;
+        }
+    }
+}
+// rows must be contiguous ([S][P][Q] with nothing between sequences), Q a multiple of 16 up to 480, N <= 64
+static bool launch_rowgemm_lds(Engine& e, const float* A, const float* Bm, float* C, const ToepGeom& rg, int acc) {
+    if (rg.a0 != 0 || rg.sa != rg.Q || rg.lda != (int64_t)rg.P * rg.Q || rg.ldc != (int64_t)rg.P * rg.N) return false;
+    if ((rg.Q & 15) || rg.Q > 480 || rg.Q < 64 || rg.N < 9 || rg.N > 64 || (((uintptr_t)A) & 15)) return false;
+    const int groups = rg.ldb == 0 ? 1 : rg.S / rg.B;
+    const long rpg = (long)(rg.S / groups) * rg.P;
+    const int tpg = (int)((rpg + 31) / 32);
+    const size_t perf = (size_t)(rg.Q / 4) * 256;
+    float* Bf = e.arena.alloc(perf * groups);
+    if (!Bf) {
+        e.failed = true;
+        return true;
+    }
+    hipLaunchKernelGGL(k_frag_b16, dim3(nblocks(perf * groups)), dim3(256), 0, e.st, Bm, groups, rg.Q, rg.N, Bf);
+    const int NT = (rg.N + 15) / 16;
+    const size_t lds = std::max((size_t)32 * (rg.Q + 1) * 4, (size_t)4 * 32 * 16 * NT * 4);
+    const dim3 grid((unsigned)(groups * tpg));
+    const int64_t ldbf = rg.ldb == 0 ? 0 : (int64_t)perf;
+#define ROWGEMM(NTV) hipLaunchKernelGGL((k_rowgemm_lds<NTV>), grid, dim3(256), lds, e.st, A, Bf, C, (int)rpg, tpg, rg.Q, rg.N, ldbf, acc)
+    if (NT == 1) ROWGEMM(1);
+    else if (NT == 2) ROWGEMM(2);
+    else if (NT == 3) ROWGEMM(3);
+    else ROWGEMM(4);
+#undef ROWGEMM
+    return true;
+}
+
 static bool is_tall(const ToepGeom& gm) {
     if (gm.N > 8 || gm.sa < 64 || gm.Q % gm.sa != 0 || gm.amax % gm.sa != 0 || gm.a0 % gm.sa != 0) return false;
     const int H = gm.Q / gm.sa;
@@ -1252,9 +1395,12 @@ static void launch_toep(Engine& e, const float* A, const float* Bm, float* C, co
         }
         hipLaunchKernelGGL(k_tall_bt, dim3(nblocks(per * gB)), dim3(256), 0, st, Bm, gB, H, gm.sa, gm.N, Bt);
         const ToepGeom rg = tall_row_geom(gm);
-        const int grp_rows = rg.B * rg.P;
-        hipLaunchKernelGGL(k_toep_mfma, dim3((unsigned)((grp_rows + 63) / 64), (unsigned)(rg.S / rg.B), (unsigned)((rg.N + 31) / 32)),
-                           dim3(512), 0, st, A, Bt, Wt, rg, 0);
+        static const bool legacy_rows = getenv("MOTIFS_TOEP_LEGACY") != nullptr;
+        if (legacy_rows || !launch_rowgemm_lds(e, A, Bt, Wt, rg, 0)) {
+            const int grp_rows = rg.B * rg.P;
+            hipLaunchKernelGGL(k_toep_mfma, dim3((unsigned)((grp_rows + 63) / 64), (unsigned)(rg.S / rg.B), (unsigned)((rg.N + 31) / 32)),
+                               dim3(512), 0, st, A, Bt, Wt, rg, 0);
+        }
         hipLaunchKernelGGL(k_tall_gather, dim3(nblocks((size_t)gm.S * gm.P * gm.N)), dim3(256), 0, st, Wt, C, gm.S, gm.P, H, gm.N, R,
                            gm.a0 / gm.sa, gm.ldc, acc);
         return;

@@ -146,6 +146,29 @@ def test_cfg2_golden(ctx, pkg):
     cdl.model.close()
 
 
+def test_cfg2_groups_are_independent(ctx, pkg):
+    """Two mini-batches at configs[1] shape in one launch == one at a time: the per-group filter banks of the ADMM_DF
+    passes and the group indexing of the LDS-resident GEMM kernels at their real sizes."""
+    g = np.load(os.path.join(HERE, "golden", "model_cfg2.npz"))
+    hp = mo.Hyperparam(filter_len=12, M=200)
+    cdl_o = mo.UCDL(hp, np.random.default_rng(0)).to(torch.float64)
+    for n in mo.PARAM_VECS + ["D", "F"]:
+        setattr(cdl_o, n, torch.tensor(g["init_" + n].astype(np.float64)))
+    cdl_o.lambda_sparsity_warmup, cdl_o.lambda_stepsize_warmup, cdl_o.omega_stepsize_warmup = [float(x) for x in g["warm"]]
+    cdl = to_model(pkg, ctx, hp, 200, cdl_o)
+    B = hp.batch_size
+    codes = np.concatenate([g["codes"], np.random.default_rng(7).integers(0, 4, size=g["codes"].shape).astype(np.uint8)])
+    loss, flat = gpu_loss_grad(pkg, ctx, cdl, codes, 2)
+    acc = np.zeros_like(flat, dtype=np.float64)
+    for k in range(2):
+        l1, f1 = gpu_loss_grad(pkg, ctx, cdl, codes[k * B:(k + 1) * B], 1)
+        assert abs(l1[0] - loss[k]) <= 1e-6 * abs(loss[k])
+        acc += f1
+    assert abs(loss[0] - g["loss0"]) <= RTOL * g["loss0"]
+    assert rel_inf(flat, acc) <= 1e-5
+    cdl.model.close()
+
+
 def test_train_step_matches_adabelief_oracle(ctx, pkg):
     hp, codes, cdl_o = tiny(5, G=1)
     cdl = to_model(pkg, ctx, hp, codes.shape[1], cdl_o)
