@@ -1507,6 +1507,119 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ A, cons
 }
 
 // y[g][j] (+)= sum of the B consecutive slices x[g*B .. g*B + B) (per-sequence partials -> per-group sums)
+// The filter gradient of the row GEMM: part[s][q][n] = sum_r A[s][r][q] * C[s][r][n] over the R contiguous rows of
+// sequence s (Q floats of A, N <= 48 of C per row).  HBM-bound: A is read once.  A block walks its sequence 32
+// rows at a time (rows to LDS with 16-byte accesses, the next 32 already in flight in registers); wave w owns the
+// 16-row blocks w, w+4, .. of q for all column blocks (v_mfma_f32_16x16x4_f32, the accumulators stay in registers
+// for the whole sequence).  Row strides of both LDS tiles are 16 mod 32 floats: conflict-free operand reads.
+template <int QW>
+__global__ __launch_bounds__(256) void k_rowwgrad_lds(const float* __restrict__ A, const float* __restrict__ C, float* __restrict__ part,
+                                                      int R, int Q, int N, int ST, int SN) {
+    constexpr int NT = 3, NVA = 15, NVC = 2;       // 16-byte loads per thread: 32 x Q (Q <= 480) of A, 32 x N (N <= 64) of C
+    extern __shared__ float lds[];                 // A tile [32][ST], C tile [32][SN]
+    float* Cs = lds + 32 * ST;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int s = blockIdx.x, Q4 = Q >> 2, N4 = N >> 2, QB = Q >> 4;
+    const float4* Ag = (const float4*)(A + (size_t)s * R * Q);
+    const float4* Cg = (const float4*)(C + (size_t)s * R * N);
+    float4 va[NVA], vc[NVC];
+    auto gload = [&](int r0) {
+        const int na = min(32, R - r0) * Q4, nc = min(32, R - r0) * N4;
+#pragma unroll
+        for (int i = 0; i < NVA; i++) {
+            const int idx = tid + i * 256;
+            const float4 x = Ag[(size_t)r0 * Q4 + (idx < na ? idx : 0)];
+            va[i] = idx < na ? x : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < NVC; i++) {
+            const int idx = tid + i * 256;
+            const float4 x = Cg[(size_t)r0 * N4 + (idx < nc ? idx : 0)];
+            vc[i] = idx < nc ? x : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto lstore = [&]() {
+        int row = tid / Q4, c4 = tid - row * Q4;
+        const int drow = 256 / Q4, dc = 256 - drow * Q4;
+#pragma unroll
+        for (int i = 0; i < NVA; i++) {
+            if (tid + i * 256 < 32 * Q4) *(float4*)(lds + row * ST + c4 * 4) = va[i];
+            row += drow, c4 += dc;
+            if (c4 >= Q4) c4 -= Q4, row++;
+        }
+#pragma unroll
+        for (int i = 0; i < NVC; i++) {
+            const int idx = tid + i * 256;
+            if (idx < 32 * N4) {
+                const int r = idx / N4, c = idx - r * N4;
+                *(float4*)(Cs + r * SN + c * 4) = vc[i];
+            }
+        }
+    };
+    f32x4 accv[QW][NT];
+#pragma unroll
+    for (int i = 0; i < QW; i++)
+#pragma unroll
+        for (int cb = 0; cb < NT; cb++) accv[i][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // columns N .. 16 NT - 1 of the C tile stay zero
+    for (int i = tid; i < 32 * SN; i += 256) Cs[i] = 0.0f;
+    const float* ap = lds + (lane >> 4) * ST + (lane & 15) + wave * 16;     // A'[q][r] = tile[r][q]
+    const float* cp = Cs + (lane >> 4) * SN + (lane & 15);
+    gload(0);
+    for (int r0 = 0; r0 < R; r0 += 32) {
+        __syncthreads();                           // the previous tile has been read
+        lstore();
+        __syncthreads();
+        if (r0 + 32 < R) gload(r0 + 32);
+#pragma unroll
+        for (int ks = 0; ks < 8; ks++) {
+            float bv[NT];
+#pragma unroll
+            for (int cb = 0; cb < NT; cb++) bv[cb] = cp[ks * 4 * SN + cb * 16];
+#pragma unroll
+            for (int i = 0; i < QW; i++) {
+                if (wave + 4 * i < QB) {
+                    const float av = ap[ks * 4 * ST + i * 64];
+#pragma unroll
+                    for (int cb = 0; cb < NT; cb++) accv[i][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[cb], accv[i][cb], 0, 0, 0);
+                }
+            }
+        }
+    }
+    float* out = part + (size_t)s * Q * N;
+#pragma unroll
+    for (int i = 0; i < QW; i++) {
+        if (wave + 4 * i < QB) {
+#pragma unroll
+            for (int cb = 0; cb < NT; cb++) {
+                const int n = cb * 16 + (lane & 15);
+                if (n < N) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) out[(size_t)((wave + 4 * i) * 16 + 4 * (lane >> 4) + r) * N + n] = accv[i][cb][r];
+                }
+            }
+        }
+    }
+}
+// per-sequence partial banks part[S][Q][N] of the row GEMM's filter gradient; false when the shape is not covered
+static bool launch_rowwgrad_lds(Engine& e, const float* A, const float* C, float* part, const ToepGeom& rg) {
+    if (rg.a0 != 0 || rg.sa != rg.Q || rg.lda != (int64_t)rg.P * rg.Q || rg.ldc != (int64_t)rg.P * rg.N) return false;
+    if ((rg.Q & 15) || rg.Q > 480 || rg.Q < 64 || rg.N < 33 || rg.N > 48 || (rg.N & 3)) return false;
+    if ((((uintptr_t)A) & 15) || (((uintptr_t)C) & 15)) return false;
+    auto pad16 = [](int x) { return x + ((16 - x % 32) + 32) % 32; };     // smallest stride >= x that is 16 mod 32
+    const int ST = pad16(rg.Q), SN = pad16(48);
+    const size_t lds = (size_t)32 * (ST + SN) * 4;
+    const int QB = rg.Q / 16, QW = (QB + 3) / 4;
+    if (lds > 64 * 1024) return false;
+#define ROWWGRAD(QWV) hipLaunchKernelGGL((k_rowwgrad_lds<QWV>), dim3(rg.S), dim3(256), lds, e.st, A, C, part, rg.P, rg.Q, rg.N, ST, SN)
+    if (QW <= 4) ROWWGRAD(4);
+    else if (QW <= 6) ROWWGRAD(6);
+    else if (QW == 7) ROWWGRAD(7);
+    else ROWWGRAD(8);
+#undef ROWWGRAD
+    return true;
+}
+
 __global__ void k_sum_segments(const float* x, size_t per, int B, size_t total, float* y, int acc) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const size_t g = i / per, j = i - g * per;
@@ -1540,7 +1653,9 @@ static void launch_wgrad(Engine& e, const float* A, const float* C, float* dB, c
             }
             ToepGeom r1 = rg;
             r1.B = 1;
-            hipLaunchKernelGGL(k_wgrad_mfma, dim3((rg.Q + 127) / 128, gm.S, (rg.N + 31) / 32), dim3(256), 0, st, A, dW, part, r1, 0);
+            static const bool legacy_rows = getenv("MOTIFS_TOEP_LEGACY") != nullptr;
+            if (legacy_rows || !launch_rowwgrad_lds(e, A, dW, part, rg))
+                hipLaunchKernelGGL(k_wgrad_mfma, dim3((rg.Q + 127) / 128, gm.S, (rg.N + 31) / 32), dim3(256), 0, st, A, dW, part, r1, 0);
             hipLaunchKernelGGL(k_sum_segments, dim3(nblocks(per * G)), dim3(256), 0, st, part, per, rg.B, per * G, dBt, 0);
         } else {
             hipLaunchKernelGGL(k_wgrad_mfma, dim3((rg.Q + 127) / 128, G, (rg.N + 31) / 32), dim3(256), 0, st, A, dW, dBt, rg, 0);
