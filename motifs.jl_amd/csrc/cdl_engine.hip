@@ -1358,6 +1358,122 @@ static bool launch_rowgemm_lds(Engine& e, const float* A, const float* Bm, float
     return true;
 }
 
+// Short windows, wide outputs (the D-layer analysis, model.jl:238, and the adjoint of its synthesis: Q = 4 fl <= 64
+// terms of the signal, N = 2M = 400 outputs): out[s][p][n] (+)= sum_q sig[s][a0 + p sa + q] B[q][n].  The output
+// stream bounds it (116 MB at cfg-2).  Every wave works alone: its 32 rows of windows live in registers as MFMA
+// operands for the whole job (Q/2 values per lane), the bank comes from L2 in fragment order, one column tile of
+// 32 at a time, the next tile's fragments in flight:
+//   Bf[g][ct][kg][lane][u] = B[g][8 kg + 2 u + (lane >> 5)][min(32 ct + (lane & 31), N-1)]
+__global__ void k_frag_bw(const float* __restrict__ Bm, int G, int Q, int N, float* __restrict__ out) {
+    const int KG = Q / 8, NCT = (N + 31) / 32;
+    const size_t per = (size_t)NCT * KG * 256, total = per * G;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t g = i / per, r = i - g * per;
+        const int u = (int)(r & 3), lane = (int)((r >> 2) & 63);
+        const int kg = (int)((r >> 8) % KG), ct = (int)((r >> 8) / KG);
+        const int q = 8 * kg + 2 * u + (lane >> 5);
+        out[i] = Bm[g * (size_t)Q * N + (size_t)q * N + min(32 * ct + (lane & 31), N - 1)];
+    }
+}
+template <int KG>
+__global__ __launch_bounds__(256) void k_toep_wide(const float* __restrict__ A, const float* __restrict__ Bf, float* __restrict__ C,
+                                                   ToepGeom gm, int acc, int tps, int64_t ldbf, int SO) {
+    extern __shared__ float lds[];                 // the block's 32 output rows, [32][SO]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int s = blockIdx.x / tps, p0 = (blockIdx.x - s * tps) * 32;
+    const float* sig = A + (size_t)s * gm.lda;
+    float a[4 * KG];
+    {
+        const int base = gm.a0 + (p0 + (lane & 31)) * gm.sa + (lane >> 5);
+#pragma unroll
+        for (int ks = 0; ks < 4 * KG; ks++) {
+            const int e = base + 2 * ks;
+            const bool ok = e >= 0 && e < gm.amax;
+            const float x = sig[ok ? e : 0];
+            a[ks] = ok ? x : 0.0f;
+        }
+    }
+    const float4* bp = (const float4*)(Bf + (size_t)(s / gm.B) * ldbf) + lane;
+    const int nct = (gm.N + 31) >> 5;
+    float4 cur[KG], nxt[KG];
+    if (wave < nct) {
+#pragma unroll
+        for (int kg = 0; kg < KG; kg++) cur[kg] = bp[(size_t)(wave * KG + kg) * 64];
+    }
+    for (int ct = wave; ct < nct; ct += 4) {       // wave w: column tiles w, w+4, ..
+        const int cn = min(ct + 4, nct - 1);
+#pragma unroll
+        for (int kg = 0; kg < KG; kg++) nxt[kg] = bp[(size_t)(cn * KG + kg) * 64];
+        f32x16 accv;
+#pragma unroll
+        for (int i = 0; i < 16; i++) accv[i] = 0.0f;
+#pragma unroll
+        for (int kg = 0; kg < KG; kg++) {
+            accv = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * kg + 0], cur[kg].x, accv, 0, 0, 0);
+            accv = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * kg + 1], cur[kg].y, accv, 0, 0, 0);
+            accv = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * kg + 2], cur[kg].z, accv, 0, 0, 0);
+            accv = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * kg + 3], cur[kg].w, accv, 0, 0, 0);
+        }
+        const int col = ct * 32 + (lane & 31);
+        if (col < gm.N) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) lds[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * SO + col] = accv[r];
+        }
+#pragma unroll
+        for (int kg = 0; kg < KG; kg++) cur[kg] = nxt[kg];
+    }
+    __syncthreads();
+    // the rows leave whole: [nrow][N] is one contiguous span of the output
+    const int nrow = min(32, gm.P - p0), N4 = gm.N >> 2;
+    float* Cs = C + (size_t)s * gm.ldc + (size_t)p0 * gm.N;
+    if ((gm.N & 3) == 0 && (((uintptr_t)Cs) & 15) == 0) {
+        int row = tid / N4, c4 = tid - row * N4;
+        const int drow = 256 / N4, dc = 256 - drow * N4;
+        for (int idx = tid; idx < nrow * N4; idx += 256) {
+            float4 o = *(const float4*)(lds + row * SO + c4 * 4);
+            float4* dst = (float4*)Cs + idx;
+            if (acc) {
+                const float4 t = *dst;
+                o.x += t.x, o.y += t.y, o.z += t.z, o.w += t.w;
+            }
+            *dst = o;
+            row += drow, c4 += dc;
+            if (c4 >= N4) c4 -= N4, row++;
+        }
+    } else {
+        for (int idx = tid; idx < nrow * gm.N; idx += 256) {
+            const int row = idx / gm.N, col = idx - row * gm.N;
+            const float o = lds[row * SO + col];
+            Cs[idx] = acc ? Cs[idx] + o : o;
+        }
+    }
+}
+static bool launch_toep_wide(Engine& e, const float* A, const float* Bm, float* C, const ToepGeom& gm, int acc) {
+    if (gm.N < 64 || gm.N > 480 || gm.Q > 64 || (gm.Q & 7) || gm.Q < 32) return false;
+    const int KG = gm.Q / 8, NCT = (gm.N + 31) / 32;
+    const int gB = gm.ldb == 0 ? 1 : gm.S / gm.B;
+    const size_t perf = (size_t)NCT * KG * 256;
+    float* Bf = e.arena.alloc(perf * gB);
+    if (!Bf) {
+        e.failed = true;
+        return true;
+    }
+    hipLaunchKernelGGL(k_frag_bw, dim3(nblocks(perf * gB)), dim3(256), 0, e.st, Bm, gB, gm.Q, gm.N, Bf);
+    const int tps = (gm.P + 31) / 32;
+    const dim3 grid((unsigned)((long)gm.S * tps));
+    const int SO = ((gm.N + 3) & ~3) + 4;          // 4 rows apart = 16 banks apart
+    const size_t lds = (size_t)32 * SO * 4;
+    const int64_t ldbf = gm.ldb == 0 ? 0 : (int64_t)perf;
+#define TOEPWIDE(K) hipLaunchKernelGGL((k_toep_wide<K>), grid, dim3(256), lds, e.st, A, Bf, C, gm, acc, tps, ldbf, SO)
+    if (KG == 4) TOEPWIDE(4);
+    else if (KG == 5) TOEPWIDE(5);
+    else if (KG == 6) TOEPWIDE(6);
+    else if (KG == 7) TOEPWIDE(7);
+    else TOEPWIDE(8);
+#undef TOEPWIDE
+    return true;
+}
+
 static bool is_tall(const ToepGeom& gm) {
     if (gm.N > 8 || gm.sa < 64 || gm.Q % gm.sa != 0 || gm.amax % gm.sa != 0 || gm.a0 % gm.sa != 0) return false;
     const int H = gm.Q / gm.sa;
@@ -1425,6 +1541,7 @@ static void launch_toep(Engine& e, const float* A, const float* Bm, float* C, co
                            gm, acc);
         return;
     }
+    if (!legacy && launch_toep_wide(e, A, Bm, C, gm, acc)) return;
     if (gm.N <= 32) {
         dim3 grid((gm.N + 31) / 32, (gm.P + 63) / 64, gm.S);
         hipLaunchKernelGGL(k_toep<32>, grid, dim3(256), 0, st, A, Bm, C, gm, acc);
@@ -1742,7 +1859,7 @@ __global__ void k_flipT(const float* x, int g, int H, int W, int N, float* out, 
 // dA[s][e] += sum_{p,q: a0 + p*sa + q = e} sum_n dC[s][p][n] * Bm[g][q][n]  (adjoint of the Toeplitz
 // gather).  With A viewed as rows of W = sa columns and the window as H = Q/W rows, this is again a
 // Toeplitz GEMM: over dC (rows of N columns) with the filter flipT(Bm) = [H][N][W], rows reversed.
-static bool toep_adjoint_a(Engine& e, const float* dC, const float* Bm, float* dA, const ToepGeom& gm) {
+static bool toep_adjoint_a(Engine& e, const float* dC, const float* Bm, float* dA, const ToepGeom& gm, int acc = 1) {
     const int W = gm.sa, H = gm.Q / gm.sa;
     const int gB = gm.ldb == 0 ? 1 : gm.S / gm.B;
     const size_t per = (size_t)gm.Q * gm.N;
@@ -1764,7 +1881,7 @@ static bool toep_adjoint_a(Engine& e, const float* dC, const float* Bm, float* d
     g2.ldc = gm.lda;
     g2.B = gm.B;
     g2.ldb = gm.ldb == 0 ? 0 : (int64_t)per;
-    launch_toep(e, dC, tmp, dA, g2, 1);
+    launch_toep(e, dC, tmp, dA, g2, acc);
     return true;
 }
 
@@ -1776,8 +1893,11 @@ Tensor Engine::toep(Tensor A, Tensor Bm, const ToepGeom& gm) {
         tape.push_back([this, out, A, Bm, gm]() {
             if (!out->g) return;
             if (A->needs_grad) {
-                float* dA = grad(A);
-                if (dA) toep_adjoint_a(*this, out->g, Bm->v, dA, gm);
+                // the adjoint writes every element of dA when the windows tile whole rows: no zero fill on first use
+                int a = 1;
+                const bool whole = gm.amax == gm.lda && gm.amax % gm.sa == 0;
+                float* dA = whole ? grad_first(A, a) : grad(A);
+                if (dA) toep_adjoint_a(*this, out->g, Bm->v, dA, gm, a);
             }
             if (Bm->needs_grad) {
                 float* dB = grad(Bm);
@@ -1811,12 +1931,15 @@ Tensor Engine::wgrad(Tensor A, Tensor C, const ToepGeom& gm) {
             ToepGeom g2 = gm;
             g2.ldb = (int64_t)gm.Q * gm.N;   // the "filter" of the adjoints is dOut, one slice per group
             if (A->needs_grad) {
-                float* dA = grad(A);
-                if (dA) toep_adjoint_a(*this, C->v, out->g, dA, g2);
+                int a = 1;
+                const bool whole = gm.amax == gm.lda && gm.amax % gm.sa == 0;
+                float* dA = whole ? grad_first(A, a) : grad(A);
+                if (dA) toep_adjoint_a(*this, C->v, out->g, dA, g2, a);
             }
             if (C->needs_grad) {
-                float* dCc = grad(C);
-                if (dCc) launch_toep(*this, A->v, out->g, dCc, g2, 1);
+                int a = 1;
+                float* dCc = gm.ldc == (int64_t)gm.P * gm.N ? grad_first(C, a) : grad(C);
+                if (dCc) launch_toep(*this, A->v, out->g, dCc, g2, a);
             }
         });
     return out;
