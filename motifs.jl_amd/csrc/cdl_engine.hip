@@ -1746,6 +1746,39 @@ __global__ void k_sum_segments(const float* x, size_t per, int B, size_t total, 
     }
 }
 
+// The window matrix of a Toeplitz operand, Wn[s][p][q] = A[s][a0 + p sa + q] (zero outside the valid range): with it
+// the filter gradient of a short-window, wide-output form is the row GEMM's, transposed.
+__global__ void k_windows(const float* __restrict__ A, ToepGeom gm, float* __restrict__ Wn) {
+    const size_t total = (size_t)gm.S * gm.P * gm.Q;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int q = (int)(i % gm.Q), p = (int)((i / gm.Q) % gm.P);
+        const size_t s = i / ((size_t)gm.Q * gm.P);
+        const int e = gm.a0 + p * gm.sa + q;
+        Wn[i] = (e >= 0 && e < gm.amax) ? A[s * gm.lda + e] : 0.0f;
+    }
+}
+// dB[g][q][n] (+)= sum_{b < B} part[g B + b][n][q], Q <= 48.  One block per (32 columns n, group): the partial banks
+// are read as contiguous [32][Q] spans, the sums turn in LDS and leave as 128-byte row pieces.
+__global__ __launch_bounds__(256) void k_sum_segments_T(const float* __restrict__ part, int Q, int N, int B, float* __restrict__ dB, int acc) {
+    __shared__ float t[48][33];
+    const int n0 = blockIdx.x * 32, g = blockIdx.y, tid = threadIdx.x;
+    const int nn_max = min(32, N - n0), cnt = nn_max * Q;
+    const size_t per = (size_t)Q * N;
+    for (int idx = tid; idx < cnt; idx += 256) {
+        float a = 0.0f;
+        for (int b = 0; b < B; b++) a += part[((size_t)g * B + b) * per + (size_t)n0 * Q + idx];
+        t[idx % Q][idx / Q] = a;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < Q * 32; idx += 256) {
+        const int q = idx >> 5, nn = idx & 31;
+        if (nn < nn_max) {
+            float* o = dB + (size_t)g * per + (size_t)q * N + n0 + nn;
+            *o = acc ? *o + t[q][nn] : t[q][nn];
+        }
+    }
+}
+
 static void launch_wgrad(Engine& e, const float* A, const float* C, float* dB, const ToepGeom& gm, int acc) {
     hipStream_t st = e.st;
     const int G = gm.S / gm.B;
@@ -1780,9 +1813,27 @@ static void launch_wgrad(Engine& e, const float* A, const float* C, float* dB, c
         hipLaunchKernelGGL(k_tall_bt_T, dim3(nblocks(per * G)), dim3(256), 0, st, dBt, G, H, gm.sa, gm.N, dB, acc);
         return;
     }
+    const size_t per = (size_t)gm.Q * gm.N;
+    static const bool legacy = getenv("MOTIFS_TOEP_LEGACY") != nullptr;
+    // short windows, wide outputs (the D-layer analysis): the transposed row-GEMM gradient over the window matrix
+    if (!legacy && gm.Q <= 48 && gm.Q > 32 && gm.N >= 64 && gm.ldc == (int64_t)gm.P * gm.N) {
+        ToepGeom rg;
+        rg.S = gm.S, rg.P = gm.P, rg.Q = gm.N, rg.N = gm.Q, rg.sa = gm.N, rg.a0 = 0, rg.amax = gm.P * gm.N;
+        rg.lda = (int64_t)gm.P * gm.N, rg.ldc = (int64_t)gm.P * gm.Q, rg.B = gm.B, rg.ldb = 0;
+        float* Wn = e.arena.alloc((size_t)gm.S * gm.P * gm.Q);
+        float* part = e.arena.alloc(per * gm.S);
+        if (!Wn || !part) {
+            e.failed = true;
+            return;
+        }
+        hipLaunchKernelGGL(k_windows, dim3(nblocks((size_t)gm.S * gm.P * gm.Q)), dim3(256), 0, st, A, gm, Wn);
+        if (launch_rowwgrad_lds(e, C, Wn, part, rg)) {
+            hipLaunchKernelGGL(k_sum_segments_T, dim3((gm.N + 31) / 32, G), dim3(256), 0, st, part, gm.Q, gm.N, gm.B, dB, acc);
+            return;
+        }
+    }
     // Few groups give few blocks (one per (tile, group)), each with a reduction over all B*P rows of its group:
     // reduce per sequence instead (B times the blocks) and add the B partial banks afterwards.
-    const size_t per = (size_t)gm.Q * gm.N;
     const bool mfma = gm.N > 8 && gm.N <= 64 && gm.Q >= 256;
     const int tiles = mfma ? ((gm.Q + 127) / 128) * ((gm.N + 31) / 32) : ((gm.N + 63) / 64) * ((gm.Q + 63) / 64);
     auto kernels = [&](float* out, const ToepGeom& gg, int groups, int accf) {
