@@ -2543,66 +2543,108 @@ void topq_mask(hipStream_t st, const float* X, float* bitmat, int S, int n_per_s
 // create_ZY_mask (model.jl:194-204): median of the strictly positive entries of the whole mini-batch
 // (mean of the two middle values for an even count: Statistics.middle(a, b) = a/2 + b/2); mask = ZY >= median.
 // No positive entry -> the reference skips the mask (:209); that is mask == 1 here.
-// Multi-block radix select: 4 passes of (histogram over all blocks, digit choice per group); the lower
-// and the upper middle element are tracked side by side.
+// Multi-block radix select: 3 passes of (histogram over all blocks, digit choice per group) over digits of
+// 11, 11 and 10 bits (positive floats order like their bit patterns); the lower and the upper middle element are
+// tracked side by side.
 struct MedState {
     uint32_t cnt, pref[2], k[2];
 };
+constexpr int MED_BINS = 2048;
+static __host__ __device__ __forceinline__ int med_shift(int pass) { return pass == 0 ? 21 : pass == 1 ? 10 : 0; }
+static __host__ __device__ __forceinline__ int med_bits(int pass) { return pass == 2 ? 10 : 11; }
 
 __global__ __launch_bounds__(256) void k_med_hist(const float* __restrict__ x, int n, const MedState* __restrict__ state,
-                                                  uint32_t* __restrict__ hist, int shift) {
-    __shared__ uint32_t h[2][256];
+                                                  uint32_t* __restrict__ hist, int pass) {
+    __shared__ uint32_t h[2][MED_BINS];
     const int g = blockIdx.y;
-    for (int i = threadIdx.x; i < 512; i += 256) (&h[0][0])[i] = 0;
+    for (int i = threadIdx.x; i < 2 * MED_BINS; i += 256) (&h[0][0])[i] = 0;
     __syncthreads();
-    const uint32_t mask = shift == 24 ? 0u : (0xffffffffu << (shift + 8));
-    const uint32_t p0 = shift == 24 ? 0u : state[g].pref[0], p1 = shift == 24 ? 0u : state[g].pref[1];
+    const int shift = med_shift(pass);
+    const uint32_t dmask = (1u << med_bits(pass)) - 1u;
+    const uint32_t mask = pass == 0 ? 0u : (0xffffffffu << (shift + med_bits(pass)));
+    const uint32_t p0 = pass == 0 ? 0u : state[g].pref[0], p1 = pass == 0 ? 0u : state[g].pref[1];
     const float* xs = x + (size_t)g * n;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        const float v = xs[i];
-        if (!(v > 0.0f)) continue;
-        const uint32_t key = __float_as_uint(v);       // positive floats order like their bit patterns
-        const uint32_t d = (key >> shift) & 0xffu;
-        if ((key & mask) == p0) atomicAdd(&h[0][d], 1u);
-        if (shift != 24 && (key & mask) == p1) atomicAdd(&h[1][d], 1u);
+    // consecutive entries of a lane often share the leading digit: runs are counted in registers, one atomic per run
+    uint32_t run_d = 0xffffffffu, run_c = 0;
+    auto take = [&](float v) {
+        if (!(v > 0.0f)) return;
+        const uint32_t key = __float_as_uint(v);
+        const uint32_t d = (key >> shift) & dmask;
+        if ((key & mask) == p0) {
+            if (d == run_d) {
+                run_c++;
+            } else {
+                if (run_c) atomicAdd(&h[0][run_d], run_c);
+                run_d = d, run_c = 1;
+            }
+        }
+        if (pass != 0 && (key & mask) == p1) atomicAdd(&h[1][d], 1u);
+    };
+    if ((n & 3) == 0 && (((uintptr_t)xs) & 15) == 0) {
+        const float4* x4 = (const float4*)xs;
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < (n >> 2); i += gridDim.x * 256) {
+            const float4 v = x4[i];
+            take(v.x), take(v.y), take(v.z), take(v.w);
+        }
+    } else {
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) take(xs[i]);
     }
+    if (run_c) atomicAdd(&h[0][run_d], run_c);
     __syncthreads();
-    for (int i = threadIdx.x; i < 512; i += 256) {
+    for (int i = threadIdx.x; i < 2 * MED_BINS; i += 256) {
         const uint32_t c = (&h[0][0])[i];
-        if (c) atomicAdd(&hist[(size_t)g * 512 + i], c);
+        if (c) atomicAdd(&hist[(size_t)g * 2 * MED_BINS + i], c);
     }
 }
 
-__global__ void k_med_select(MedState* state, uint32_t* hist, int shift) {
-    const int g = blockIdx.x;
-    uint32_t* h = hist + (size_t)g * 512;
-    if (threadIdx.x == 0) {
-        MedState st = state[g];
-        if (shift == 24) {
-            uint32_t c = 0;
-            for (int b = 0; b < 256; b++) c += h[b];
-            st.cnt = c;
-            st.pref[0] = st.pref[1] = 0;
-            st.k[0] = c ? (c - 1) / 2 : 0;
-            st.k[1] = c / 2;
-        }
-        if (st.cnt) {
-            for (int sel = 0; sel < 2; sel++) {
-                const uint32_t* hh = h + (shift == 24 ? 0 : sel * 256);
-                uint32_t run = 0;
-                int b = 0;
-                for (; b < 255; b++) {
-                    if (run + hh[b] > st.k[sel]) break;
-                    run += hh[b];
-                }
-                st.pref[sel] |= (uint32_t)b << shift;
-                st.k[sel] -= run;
-            }
-        }
-        state[g] = st;
-    }
+// digit choice: the first bin whose running count exceeds k (the last bin if none does); 256 threads x 8 bins
+__global__ __launch_bounds__(256) void k_med_select(MedState* state, uint32_t* hist, int pass) {
+    __shared__ uint32_t part[256];
+    __shared__ MedState sst;
+    const int g = blockIdx.x, tid = threadIdx.x, shift = med_shift(pass);
+    uint32_t* h = hist + (size_t)g * 2 * MED_BINS;
+    if (tid == 0) sst = state[g];
     __syncthreads();
-    for (int i = threadIdx.x; i < 512; i += blockDim.x) h[i] = 0;   // ready for the next pass
+    for (int sel = 0; sel < 2; sel++) {
+        const uint32_t* hh = h + (pass == 0 ? 0 : sel * MED_BINS);
+        uint32_t loc[8], sum = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) loc[j] = hh[tid * 8 + j], sum += loc[j];
+        part[tid] = sum;
+        __syncthreads();
+        for (int d = 1; d < 256; d <<= 1) {        // inclusive scan
+            const uint32_t v = tid >= d ? part[tid - d] : 0;
+            __syncthreads();
+            part[tid] += v;
+            __syncthreads();
+        }
+        const uint32_t total = part[255], before = part[tid] - sum;
+        if (pass == 0 && sel == 0 && tid == 0) {
+            sst.cnt = total;
+            sst.pref[0] = sst.pref[1] = 0;
+            sst.k[0] = total ? (total - 1) / 2 : 0;
+            sst.k[1] = total / 2;
+        }
+        __syncthreads();
+        const uint32_t k = sst.k[sel];
+        const bool any = sst.cnt != 0;
+        // owner: the thread whose bins hold the k-th element; thread 255 also takes "none exceeds"
+        const bool owner = any && ((before <= k && k < before + sum) || (tid == 255 && k >= total));
+        __syncthreads();
+        if (owner) {
+            uint32_t run = before;
+            int b = tid * 8;
+            for (int j = 0; j < 8; j++, b++) {
+                if (b == MED_BINS - 1 || run + loc[j] > k) break;
+                run += loc[j];
+            }
+            sst.pref[sel] |= (uint32_t)b << shift;
+            sst.k[sel] = k - run;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) state[g] = sst;
+    for (int i = tid; i < 2 * MED_BINS; i += 256) h[i] = 0;   // ready for the next pass
 }
 
 __global__ void k_med_apply(const float* __restrict__ x, int n, const MedState* __restrict__ state, float* __restrict__ mask) {
@@ -2622,13 +2664,13 @@ void median_mask(hipStream_t st, const float* ZY, float* mask, int G, int n_per_
     uint32_t* hist = (uint32_t*)((char*)workspace + (((size_t)G * sizeof(MedState) + 255) & ~(size_t)255));
     (void)hipMemsetAsync(workspace, 0, median_workspace_bytes(G), st);
     const unsigned nb = (unsigned)std::min<size_t>((n_per_group + 256 * 16 - 1) / (256 * 16), 64);
-    for (int shift = 24; shift >= 0; shift -= 8) {
-        hipLaunchKernelGGL(k_med_hist, dim3(nb, G), dim3(256), 0, st, ZY, n_per_group, state, hist, shift);
-        hipLaunchKernelGGL(k_med_select, dim3(G), dim3(64), 0, st, state, hist, shift);
+    for (int pass = 0; pass < 3; pass++) {
+        hipLaunchKernelGGL(k_med_hist, dim3(nb, G), dim3(256), 0, st, ZY, n_per_group, state, hist, pass);
+        hipLaunchKernelGGL(k_med_select, dim3(G), dim3(256), 0, st, state, hist, pass);
     }
     hipLaunchKernelGGL(k_med_apply, dim3(nb, G), dim3(256), 0, st, ZY, n_per_group, state, mask);
 }
-size_t median_workspace_bytes(int G) { return (((size_t)G * sizeof(MedState) + 255) & ~(size_t)255) + (size_t)G * 512 * 4; }
+size_t median_workspace_bytes(int G) { return (((size_t)G * sizeof(MedState) + 255) & ~(size_t)255) + (size_t)G * 2 * MED_BINS * 4; }
 
 __global__ void k_onehot(const uint8_t* codes, int pitch, float* S, int nseq, int L) {
     const size_t total = (size_t)nseq * L;
