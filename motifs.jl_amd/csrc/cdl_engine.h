@@ -103,7 +103,7 @@ struct Engine {
     // ---- primitives (each records its VJP) ----
     Tensor lin(Tensor x, float a, Tensor y, float b, float cst);          // a*x + b*y(bcast modulo y.n) + cst
     // a*x + b*(ymask .* y) + c*z in one pass (z, ymask optional; ymask is a constant 0/1 mask)
-    Tensor lin3(Tensor x, float a, Tensor y, float b, Tensor z, float c, const float* ymask = nullptr);
+    Tensor lin3(Tensor x, float a, Tensor y, float b, Tensor z, float c, const float* ythr = nullptr, int groups = 1);   // ythr: y counts where y >= ythr[group]
     // relu(ZY - lst*(g1 + pen*(ZY - FX - ab)) - ls*lst): the ISTA step of update_ZY fused (ab optional; scalars are 1-element tensors)
     Tensor zy_step(Tensor ZY, Tensor g1, Tensor FX, Tensor ab, Tensor pen, Tensor lst, Tensor ls);
     // the same with the dual update folded in: abn = FX - ZY + abp (abp optional), then the step with abn; returns {out, abn}
@@ -111,6 +111,7 @@ struct Engine {
     Tensor mul(Tensor x, Tensor y);                                       // x .* y (y broadcast modulo y.n)
     Tensor relu(Tensor x);
     Tensor maskmul(Tensor x, const float* mask, float c);                 // c * mask .* x, mask constant
+    Tensor thrmul(Tensor x, const float* thr, int groups, float c);       // c * [x >= thr[group]] .* x, the selection constant
     Tensor expo(Tensor x);
     Tensor norm4(Tensor x);                                               // x / sum over each 4 consecutive
     Tensor norml2(Tensor x, int seg);                                     // x / ||x|| per segment
@@ -130,7 +131,7 @@ struct Engine {
 // selections (constants in the backward: @ignore, model.jl:190, :208)
 void topq_mask(hipStream_t st, const float* X, float* bitmat, int S, int n_per_seq, int q);
 size_t median_workspace_bytes(int G);
-void median_mask(hipStream_t st, const float* ZY, float* mask, int G, int n_per_group, void* workspace);
+void median_threshold(hipStream_t st, const float* ZY, float* thr, int G, int n_per_group, void* workspace);
 void onehot_from_codes(hipStream_t st, const uint8_t* codes, int pitch, float* S, int nseq, int L);
 void adabelief_step(hipStream_t st, float* x, float* m, float* s, const float* grad, size_t n, float gscale, float eta,
                     float b1, float b2, float eps, float b1p, float b2p);

@@ -229,21 +229,40 @@ __global__ void k_sumsq_groups_bwd(const float* gout, const float* x, size_t per
         dx[i] = (acc ? dx[i] : 0.0f) + coef2 * x[i] * gout[i / per_group];
 }
 
-// a*x + b*y + c*z in one pass (z optional)
-// ymask (optional): a constant 0/1 mask on y (cat_ZY's median mask), folded in instead of a separate masked copy of y
-__global__ void k_lin3(const float* x, float a, const float* y, const float* ymask, float b, const float* z, float c, size_t n,
+// a*x + b*y + c*z in one pass (z optional), one grid row per group of `per` elements.
+// ythr (optional): cat_ZY's median mask folded in as a threshold per group, y counts where y >= ythr[group]
+// (a constant in the backward, @ignore model.jl:208) - no 0/1 mask is ever written or read.
+__global__ void k_lin3(const float* x, float a, const float* y, const float* ythr, float b, const float* z, float c, size_t per,
                        float* out) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        out[i] = a * x[i] + b * (ymask ? ymask[i] * y[i] : y[i]) + (z ? c * z[i] : 0.0f);
+    const size_t base = (size_t)blockIdx.y * per;
+    const float t = ythr ? ythr[blockIdx.y] : 0.0f;
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < per; j += (size_t)gridDim.x * blockDim.x) {
+        const size_t i = base + j;
+        const float yv = y[i];
+        out[i] = a * x[i] + b * ((ythr && !(yv >= t)) ? 0.0f : yv) + (z ? c * z[i] : 0.0f);
+    }
 }
-// VJP of k_lin3: d{x,y,z} (+)= {a,b*ymask,c} * go, go read once
-__global__ void k_lin3_bwd(const float* go, size_t n, float a, float* dx, int ax, float b, const float* ymask, float* dy, int ay, float c,
-                           float* dz, int az) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+// VJP of k_lin3: d{x,y,z} (+)= {a, b*[y >= thr], c} * go, go read once
+__global__ void k_lin3_bwd(const float* go, size_t per, float a, float* dx, int ax, float b, const float* y, const float* ythr, float* dy,
+                           int ay, float c, float* dz, int az) {
+    const size_t base = (size_t)blockIdx.y * per;
+    const float t = ythr ? ythr[blockIdx.y] : 0.0f;
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < per; j += (size_t)gridDim.x * blockDim.x) {
+        const size_t i = base + j;
         const float g = go[i];
         if (dx) dx[i] = (ax ? dx[i] : 0.0f) + a * g;
-        if (dy) dy[i] = (ay ? dy[i] : 0.0f) + b * (ymask ? ymask[i] * g : g);
+        if (dy) dy[i] = (ay ? dy[i] : 0.0f) + b * ((ythr && !(y[i] >= t)) ? 0.0f : g);
         if (dz) dz[i] = (az ? dz[i] : 0.0f) + c * g;
+    }
+}
+// c * [x >= thr[group]] .* x and its VJP (src = x forward, src = d out backward; sel = x both times)
+__global__ void k_thrmul(const float* src, const float* sel, const float* thr, float c, size_t per, float* out, int acc) {
+    const size_t base = (size_t)blockIdx.y * per;
+    const float t = thr[blockIdx.y];
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < per; j += (size_t)gridDim.x * blockDim.x) {
+        const size_t i = base + j;
+        const float v = sel[i] >= t ? c * src[i] : 0.0f;
+        out[i] = acc ? out[i] + v : v;
     }
 }
 // The ISTA step of update_ZY (model.jl:240-244) on the compact image, fused:
@@ -377,23 +396,26 @@ Tensor Engine::lin(Tensor x, float a, Tensor y, float b, float cst) {
     return out;
 }
 
-Tensor Engine::lin3(Tensor x, float a, Tensor y, float b, Tensor z, float c, const float* ymask) {
+Tensor Engine::lin3(Tensor x, float a, Tensor y, float b, Tensor z, float c, const float* ythr, int groups) {
     Tensor out = make(x->n, x->needs_grad || y->needs_grad || (z && z->needs_grad));
     if (failed) return out;
-    EW(k_lin3, x->n, x->v, a, y->v, ymask, b, z ? z->v : nullptr, c, x->n, out->v);
+    const int G = ythr ? groups : 1;
+    const size_t per = x->n / G;
+    const dim3 grid(nblocks(per, 256, std::max<size_t>(256 * 32 / G, 1)), G);
+    hipLaunchKernelGGL(k_lin3, grid, dim3(256), 0, st, x->v, a, y->v, ythr, b, z ? z->v : nullptr, c, per, out->v);
     if (recording && out->needs_grad)
-        tape.push_back([this, out, x, y, z, a, b, c, ymask]() {
+        tape.push_back([this, out, x, y, z, a, b, c, ythr, per, grid]() {
             if (!out->g) return;
             if (x == y || x == z || (z && y == z)) {                  // aliased operands: one contribution at a time
                 int ax;
                 float* dx = x->needs_grad ? grad_first(x, ax) : nullptr;
-                if (dx) EW(k_lin3_bwd, out->n, out->g, out->n, a, dx, ax, 0.0f, nullptr, nullptr, 1, 0.0f, nullptr, 1);
+                if (dx) hipLaunchKernelGGL(k_lin3_bwd, grid, dim3(256), 0, st, out->g, per, a, dx, ax, 0.0f, nullptr, nullptr, nullptr, 1, 0.0f, nullptr, 1);
                 int ay;
                 float* dy = y->needs_grad ? grad_first(y, ay) : nullptr;
-                if (dy) EW(k_lin3_bwd, out->n, out->g, out->n, 0.0f, nullptr, 1, b, ymask, dy, ay, 0.0f, nullptr, 1);
+                if (dy) hipLaunchKernelGGL(k_lin3_bwd, grid, dim3(256), 0, st, out->g, per, 0.0f, nullptr, 1, b, y->v, ythr, dy, ay, 0.0f, nullptr, 1);
                 int az;
                 float* dz = (z && z->needs_grad) ? grad_first(z, az) : nullptr;
-                if (dz) EW(k_lin3_bwd, out->n, out->g, out->n, 0.0f, nullptr, 1, 0.0f, nullptr, nullptr, 1, c, dz, az);
+                if (dz) hipLaunchKernelGGL(k_lin3_bwd, grid, dim3(256), 0, st, out->g, per, 0.0f, nullptr, 1, 0.0f, nullptr, nullptr, nullptr, 1, c, dz, az);
                 return;
             }
             int ax = 1, ay = 1, az = 1;
@@ -401,7 +423,22 @@ Tensor Engine::lin3(Tensor x, float a, Tensor y, float b, Tensor z, float c, con
             float* dy = y->needs_grad ? grad_first(y, ay) : nullptr;
             float* dz = (z && z->needs_grad) ? grad_first(z, az) : nullptr;
             if (failed) return;
-            EW(k_lin3_bwd, out->n, out->g, out->n, a, dx, ax, b, ymask, dy, ay, c, dz, az);
+            hipLaunchKernelGGL(k_lin3_bwd, grid, dim3(256), 0, st, out->g, per, a, dx, ax, b, y->v, ythr, dy, ay, c, dz, az);
+        });
+    return out;
+}
+
+Tensor Engine::thrmul(Tensor x, const float* thr, int groups, float c) {
+    Tensor out = make(x->n, x->needs_grad);
+    if (failed) return out;
+    const size_t per = x->n / groups;
+    const dim3 grid(nblocks(per, 256, std::max<size_t>(256 * 32 / groups, 1)), groups);
+    hipLaunchKernelGGL(k_thrmul, grid, dim3(256), 0, st, x->v, x->v, thr, c, per, out->v, 0);
+    if (recording && out->needs_grad)
+        tape.push_back([this, out, x, thr, c, per, grid]() {
+            int acc;
+            float* dx = out->g ? grad_first(x, acc) : nullptr;
+            if (dx) hipLaunchKernelGGL(k_thrmul, grid, dim3(256), 0, st, out->g, x->v, thr, c, per, dx, acc);
         });
     return out;
 }
@@ -2647,19 +2684,19 @@ __global__ __launch_bounds__(256) void k_med_select(MedState* state, uint32_t* h
     for (int i = tid; i < 2 * MED_BINS; i += 256) h[i] = 0;   // ready for the next pass
 }
 
-__global__ void k_med_apply(const float* __restrict__ x, int n, const MedState* __restrict__ state, float* __restrict__ mask) {
-    const int g = blockIdx.y;
+__global__ void k_med_thr(const MedState* __restrict__ state, int G, float* __restrict__ thr) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= G) return;
     const MedState st = state[g];
-    float med = -INFINITY;
+    float med = -INFINITY;                         // no positive entry: everything passes
     if (st.cnt) {
         const float lo = __uint_as_float(st.pref[0]), hi = __uint_as_float(st.pref[1]);
         med = (st.cnt & 1u) ? lo : lo / 2 + hi / 2;
     }
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
-        mask[(size_t)g * n + i] = x[(size_t)g * n + i] >= med ? 1.0f : 0.0f;
+    thr[g] = med;
 }
 
-void median_mask(hipStream_t st, const float* ZY, float* mask, int G, int n_per_group, void* workspace) {
+void median_threshold(hipStream_t st, const float* ZY, float* thr, int G, int n_per_group, void* workspace) {
     MedState* state = (MedState*)workspace;
     uint32_t* hist = (uint32_t*)((char*)workspace + (((size_t)G * sizeof(MedState) + 255) & ~(size_t)255));
     (void)hipMemsetAsync(workspace, 0, median_workspace_bytes(G), st);
@@ -2668,7 +2705,7 @@ void median_mask(hipStream_t st, const float* ZY, float* mask, int G, int n_per_
         hipLaunchKernelGGL(k_med_hist, dim3(nb, G), dim3(256), 0, st, ZY, n_per_group, state, hist, pass);
         hipLaunchKernelGGL(k_med_select, dim3(G), dim3(256), 0, st, state, hist, pass);
     }
-    hipLaunchKernelGGL(k_med_apply, dim3(nb, G), dim3(256), 0, st, ZY, n_per_group, state, mask);
+    hipLaunchKernelGGL(k_med_thr, dim3((G + 63) / 64), dim3(64), 0, st, state, G, thr);
 }
 size_t median_workspace_bytes(int G) { return (((size_t)G * sizeof(MedState) + 255) & ~(size_t)255) + (size_t)G * 2 * MED_BINS * 4; }
 

@@ -64,19 +64,18 @@ struct Graph {
 
     // cat_ZY (model.jl:206-210): magnifying_factor * (ZY >= median of the positive entries of the mini-batch) .* ZY
     Tensor cat_ZY(Tensor ZY) {
-        Tensor mask = e.make(ZY->n, false);
-        Tensor ws = e.make(median_workspace_bytes(G) / 4 + 64, false);
+        const float* thr = zy_thr(ZY);
         if (e.failed) return ZY;
-        median_mask(e.st, ZY->v, mask->v, G, (int)(ZY->n / G), ws->v);
-        return e.maskmul(ZY, mask->v, m->hp.magnifying_factor);
+        return e.thrmul(ZY, thr, G, m->hp.magnifying_factor);
     }
-    // the mask of cat_ZY alone (constant in the backward, @ignore :208), for callers that fold it into their own pass
-    const float* zy_mask(Tensor ZY) {
-        Tensor mask = e.make(ZY->n, false);
+    // the medians behind cat_ZY's mask, one per mini-batch (constants in the backward, @ignore :208): consumers compare
+    // against them in their own pass instead of reading a 0/1 mask
+    const float* zy_thr(Tensor ZY) {
+        Tensor thr = e.make((size_t)G + 64, false);
         Tensor ws = e.make(median_workspace_bytes(G) / 4 + 64, false);
         if (e.failed) return nullptr;
-        median_mask(e.st, ZY->v, mask->v, G, (int)(ZY->n / G), ws->v);
-        return mask->v;
+        median_threshold(e.st, ZY->v, thr->v, G, (int)(ZY->n / G), ws->v);
+        return thr->v;
     }
     // project_X (model.jl:181-192): keep the entries >= the q-th largest of each sequence
     Tensor project_X(Tensor Xu) {
@@ -167,8 +166,8 @@ static void admm_xyz(motifs_model* m, Graph& gr, const Scalars& sc, const Graph:
         }
         // update_X (:247-254); `sum(FX, dims=3)` is a no-op on the already summed FX
         // FX - (cat_ZY(ZY) - [alpha beta]); the magnified, median-masked image is formed inside the same pass
-        const float* zm = gr.zy_mask(ZY);
-        Tensor xg = gr.anaF(e.lin3(FX, 1.0f, ZY, -m->hp.magnifying_factor, ab, 1.0f, zm), bF);
+        const float* zt = gr.zy_thr(ZY);
+        Tensor xg = gr.anaF(e.lin3(FX, 1.0f, ZY, -m->hp.magnifying_factor, ab, 1.0f, zt, gr.G), bF);
         X = gr.project_X(e.lin(X, 1.0f, e.mul(xg, sc.ost[t]), -1.0f, 0.0f));
         FX = gr.synF(X, bF);                                              // the duals advance at the top of the next pass
     }
