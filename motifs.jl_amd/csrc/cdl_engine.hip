@@ -2390,7 +2390,77 @@ static void launch_sp_ana_masked(hipStream_t st, const float* img, const float* 
     hipLaunchKernelGGL(k_sp_ana_masked, dim3(8, d.S), dim3(256), 0, st, img, Fk, nz, out, d);
 }
 
+// S1 by output rows: a block owns 32 rows of one read's image and every thread 4 adjacent columns; the entries that
+// reach row r are the (position-sorted) run with p in (r - h, r], found once per row by bisection.  The image is
+// written (or accumulated) once with 16-byte accesses, the contributions of a row meet in registers in entry order -
+// the same sums as the ring of k_sp_syn, without its serial walk over the entries.
+__global__ __launch_bounds__(256) void k_sp_syn_rows(NzView nz, const float* __restrict__ FAf, float* __restrict__ out, SpDims d, int acc) {
+    constexpr int EC = 256;                        // decoded entries kept in LDS (more: decoded on the fly)
+    __shared__ int lo[32], hi[32];
+    __shared__ int ep[EC], ek[EC];
+    __shared__ float ev[EC];
+    const int s = blockIdx.y, r0 = blockIdx.x * 32, tid = threadIdx.x;
+    const int cnt = nz.cnt[s];
+    const uint2* es = nz.ent + (size_t)s * nz.cap;
+    if (tid < 64) {                                // first entry with p >= r - h + 1 (lo) / p >= r + 1 (hi)
+        const int r = r0 + (tid & 31);
+        const long key = ((long)(tid < 32 ? r - d.h + 1 : r + 1)) * d.K;
+        int a = 0, b = cnt;
+        while (a < b) {
+            const int m = (a + b) >> 1;
+            if ((long)es[m].x < key) a = m + 1;
+            else b = m;
+        }
+        (tid < 32 ? lo : hi)[tid & 31] = a;
+    }
+    __syncthreads();
+    const int nrow = min(32, d.c - r0);
+    const int zb = lo[0], ne = hi[nrow - 1] - zb;
+    const bool cached = ne <= EC;
+    if (cached) {
+        for (int i = tid; i < ne; i += 256) {
+            const uint2 en = es[zb + i];
+            const int p = (int)(en.x / (unsigned)d.K);
+            ep[i] = p, ek[i] = (int)(en.x - (unsigned)p * d.K), ev[i] = __uint_as_float(en.y);
+        }
+    }
+    __syncthreads();
+    const int W4 = d.W >> 2;
+    const float4* F4 = (const float4*)(FAf + (size_t)(s / d.B) * d.ldf);
+    float4* o4 = (float4*)(out + ((size_t)s * d.c + r0) * d.W);
+    int row = tid / W4, c4 = tid - row * W4;
+    const int drow = 256 / W4, dc = 256 - drow * W4;
+    for (int idx = tid; idx < nrow * W4; idx += 256) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int r = r0 + row;
+        for (int z = lo[row]; z < hi[row]; z++) {
+            int p, k;
+            float v;
+            if (cached) {
+                p = ep[z - zb], k = ek[z - zb], v = ev[z - zb];
+            } else {
+                const uint2 en = es[z];
+                p = (int)(en.x / (unsigned)d.K), k = (int)(en.x - (unsigned)p * d.K), v = __uint_as_float(en.y);
+            }
+            const float4 f = F4[((size_t)(d.h - 1 - (r - p)) * d.K + k) * W4 + c4];
+            a.x = fmaf(v, f.x, a.x), a.y = fmaf(v, f.y, a.y), a.z = fmaf(v, f.z, a.z), a.w = fmaf(v, f.w, a.w);
+        }
+        if (acc) {
+            const float4 t = o4[idx];
+            a.x += t.x, a.y += t.y, a.z += t.z, a.w += t.w;
+        }
+        o4[idx] = a;
+        row += drow, c4 += dc;
+        if (c4 >= W4) c4 -= W4, row++;
+    }
+}
+
 static void launch_sp_syn(hipStream_t st, const NzView& nz, const float* FAf, float* out, const SpDims& d, int acc) {
+    static const bool legacy = getenv("MOTIFS_TOEP_LEGACY") != nullptr;
+    if (!legacy && (d.W & 3) == 0 && d.W <= 1024 && (d.ldf & 3) == 0 && ((((uintptr_t)FAf) | ((uintptr_t)out)) & 15) == 0) {
+        hipLaunchKernelGGL(k_sp_syn_rows, dim3((d.c + 31) / 32, d.S), dim3(256), 0, st, nz, FAf, out, d, acc);
+        return;
+    }
     if (d.h == 12) hipLaunchKernelGGL(k_sp_syn<12>, dim3((d.W + 127) / 128, d.S), dim3(128), 0, st, nz, FAf, out, d, acc);
     else if (d.h <= 16) hipLaunchKernelGGL(k_sp_syn<0>, dim3((d.W + 127) / 128, d.S), dim3(128), 0, st, nz, FAf, out, d, acc);
     else hipLaunchKernelGGL(k_sp_syn_any, dim3((d.W + 127) / 128, d.S), dim3(128), 0, st, nz, FAf, out, d, acc);
