@@ -83,6 +83,8 @@ struct Engine {
     std::vector<TNode*> nodes;
     bool recording = true;
     bool failed = false;           // arena exhausted
+    float* zpool = nullptr;        // current pre-zeroed chunk (dies with the arena at reset())
+    size_t zleft = 0;
     std::map<std::string, Tensor> named;
     bool keep_named = false;
 
@@ -91,6 +93,7 @@ struct Engine {
     Tensor make(size_t n, bool needs_grad);
     Tensor wrap(float* v, float* g, size_t n, bool needs_grad);   // external storage (parameters)
     float* grad(Tensor t);         // allocate + zero on first use
+    float* zeros(size_t n);        // n zeroed floats: small requests are carved from chunks zeroed with one fill each
     float* grad_first(Tensor t, int& acc);   // allocate on first use without the zero fill (acc = 0: overwrite)
     NzView nz_build(const float* data, int S, int n_per);   // non-zero list of [S][n_per] values (memory order)
     NzView nz_of(Tensor t, int S);                           // cached list of t's values

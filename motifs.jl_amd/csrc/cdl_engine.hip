@@ -23,6 +23,8 @@ void Engine::reset() {
     tape.clear();
     named.clear();
     arena.reset();
+    zpool = nullptr;
+    zleft = 0;
     failed = false;
 }
 
@@ -46,15 +48,38 @@ Tensor Engine::wrap(float* v, float* g, size_t n, bool needs_grad) {
     return t;
 }
 
-float* Engine::grad(Tensor t) {
-    if (!t->g) {
-        t->g = arena.alloc(t->n);
-        if (!t->g) {
+// Zeroed scratch.  A backward pass asks for a hundred small zeroed buffers (scalar and filter gradients, selection
+// workspaces); each fill is a launch, so they are carved from 64 MB chunks that are zeroed once.
+float* Engine::zeros(size_t n) {
+    constexpr size_t CHUNK = (size_t)16 << 20, SMALL = (size_t)2 << 20;   // floats
+    if (n > SMALL) {
+        float* p = arena.alloc(n);
+        if (!p) {
             failed = true;
             return nullptr;
         }
-        (void)hipMemsetAsync(t->g, 0, t->n * 4, st);
+        (void)hipMemsetAsync(p, 0, n * 4, st);
+        return p;
     }
+    const size_t need = (n + 63) & ~(size_t)63;    // keep 256-byte alignment
+    if (need > zleft) {
+        zpool = arena.alloc(CHUNK);
+        if (!zpool) {
+            failed = true;
+            zleft = 0;
+            return nullptr;
+        }
+        (void)hipMemsetAsync(zpool, 0, CHUNK * 4, st);
+        zleft = CHUNK;
+    }
+    float* p = zpool;
+    zpool += need;
+    zleft -= need;
+    return p;
+}
+
+float* Engine::grad(Tensor t) {
+    if (!t->g) t->g = zeros(t->n);
     return t->g;
 }
 
@@ -2519,8 +2544,9 @@ Tensor Engine::ana_sp(Tensor img, Tensor FA, Tensor FAf, const SpDims& d, const 
             NzView gz = nz_build(out->g, d.S, d.l * d.K);
             if (failed) return;
             if (img->needs_grad) {
-                float* di = grad(img);
-                if (di) launch_sp_syn(st, gz, FAf->v, di, d, 1);
+                int a = 1;
+                float* di = grad_first(img, a);        // the synthesis writes every row: no zero fill on first use
+                if (di) launch_sp_syn(st, gz, FAf->v, di, d, a);
             }
             if (FA->needs_grad) {
                 float* dB = grad(FA);
@@ -2557,14 +2583,15 @@ Tensor Engine::wgrad_sp(Tensor img, Tensor T, const SpDims& d) {
             SpDims dg = d;
             dg.ldf = (int64_t)per;                    // the "filter" of both adjoints is dOut, one slice per group
             if (img->needs_grad) {                    // dimg[r][j] += sum_nz v * dOut[r - p][j][k]  = S1 with flipT(dOut)
-                float* di = grad(img);
+                int a = 1;
+                float* di = grad_first(img, a);
                 float* tmp = arena.alloc(per * G);
                 if (!di || !tmp) {
                     failed = failed || !tmp;
                     return;
                 }
                 hipLaunchKernelGGL(k_flipT, dim3(nblocks(per * G)), dim3(256), 0, st, out->g, G, d.h, d.W, d.K, tmp, 0);
-                launch_sp_syn(st, nz, tmp, di, dg, 1);
+                launch_sp_syn(st, nz, tmp, di, dg, a);
             }
             if (T->needs_grad) {
                 float* dT = grad(T);
@@ -2769,9 +2796,8 @@ __global__ void k_med_thr(const MedState* __restrict__ state, int G, float* __re
 void median_threshold(hipStream_t st, const float* ZY, float* thr, int G, int n_per_group, void* workspace) {
     MedState* state = (MedState*)workspace;
     uint32_t* hist = (uint32_t*)((char*)workspace + (((size_t)G * sizeof(MedState) + 255) & ~(size_t)255));
-    (void)hipMemsetAsync(workspace, 0, median_workspace_bytes(G), st);
     const unsigned nb = (unsigned)std::min<size_t>((n_per_group + 256 * 16 - 1) / (256 * 16), 64);
-    for (int pass = 0; pass < 3; pass++) {
+    for (int pass = 0; pass < 3; pass++) {            // the workspace arrives zeroed (Engine::zeros)
         hipLaunchKernelGGL(k_med_hist, dim3(nb, G), dim3(256), 0, st, ZY, n_per_group, state, hist, pass);
         hipLaunchKernelGGL(k_med_select, dim3(G), dim3(256), 0, st, state, hist, pass);
     }

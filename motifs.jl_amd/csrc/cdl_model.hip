@@ -72,9 +72,9 @@ struct Graph {
     // against them in their own pass instead of reading a 0/1 mask
     const float* zy_thr(Tensor ZY) {
         Tensor thr = e.make((size_t)G + 64, false);
-        Tensor ws = e.make(median_workspace_bytes(G) / 4 + 64, false);
+        float* ws = e.zeros(median_workspace_bytes(G) / 4 + 64);
         if (e.failed) return nullptr;
-        median_threshold(e.st, ZY->v, thr->v, G, (int)(ZY->n / G), ws->v);
+        median_threshold(e.st, ZY->v, thr->v, G, (int)(ZY->n / G), ws);
         return thr->v;
     }
     // project_X (model.jl:181-192): keep the entries >= the q-th largest of each sequence
