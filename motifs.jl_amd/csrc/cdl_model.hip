@@ -119,12 +119,12 @@ static Scalars prep_scalars(motifs_model* m, Graph& gr, bool train) {
     Engine& e = m->eng;
     float* v = m->params + m->nD + m->nF;
     float* g = m->grads + m->nD + m->nF;
+    // all 33 entries are squared in one launch; the scalars are one-element views of the result and of its gradient
+    Tensor sqv = gr.sq(e.wrap(v, g, m->nV, train));
+    float* sg = train ? e.grad(sqv) : nullptr;
     auto block = [&](int off, int n) {
         std::vector<Tensor> out;
-        for (int i = 0; i < n; i++) {
-            Tensor raw = e.wrap(v + off + i, g + off + i, 1, train);
-            out.push_back(gr.sq(raw));
-        }
+        for (int i = 0; i < n; i++) out.push_back(e.wrap(sqv->v + off + i, sg ? sg + off + i : nullptr, 1, train && sg));
         return out;
     };
     Scalars s;
