@@ -2638,15 +2638,33 @@ static __device__ uint32_t block_radix_select(const float* x, int n, uint32_t k,
             if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 0xffu], 1u);
         }
         __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t run = 0;
-            int b = 0;
-            for (; b < 256; b++) {
-                if (run + hist[b] > k) break;
-                run += hist[b];
+        if (threadIdx.x < 64) {                     // first bin whose running count exceeds k: 4 bins per lane, wave scan
+            const int l = threadIdx.x;
+            const uint32_t c0 = hist[4 * l], c1 = hist[4 * l + 1], c2 = hist[4 * l + 2], c3 = hist[4 * l + 3];
+            const uint32_t sum = c0 + c1 + c2 + c3;
+            uint32_t incl = sum;
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t t = __shfl_up(incl, d);
+                if (l >= d) incl += t;
             }
-            sh[0] = (uint32_t)b;
-            sh[1] = run;
+            const uint32_t before = incl - sum;
+            const uint32_t total = __shfl(incl, 63);
+            if ((before <= k && k < incl) || (l == 63 && k >= total)) {
+                uint32_t run = before;
+                int b = 4 * l;
+                if (run + c0 <= k) {
+                    run += c0, b++;
+                    if (run + c1 <= k) {
+                        run += c1, b++;
+                        if (run + c2 <= k) {
+                            run += c2, b++;
+                            if (run + c3 <= k) run += c3, b++;   // only when nothing exceeds k (b = 256, as the serial walk)
+                        }
+                    }
+                }
+                sh[0] = (uint32_t)b;
+                sh[1] = run;
+            }
         }
         __syncthreads();
         prefix |= sh[0] << shift;
