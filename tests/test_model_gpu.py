@@ -105,6 +105,30 @@ def test_tiny_loss_grads_and_intermediates(ctx, pkg, seed):
         assert rel_inf(got[n], want[n]) <= 5 * RTOL, (n, rel_inf(got[n], want[n]))
 
 
+@pytest.mark.parametrize("i", [0, 1, 2])
+def test_mid_shapes_golden(ctx, pkg, i):
+    """Three mid-size shapes against the float64 oracle (tests/golden/make_model_mid_golden.py): other template
+    instances of the LDS-resident matrix-core kernels than configs[0]/[1] take (window heights 8 and 12, channel
+    chunks of 32 / 80, odd K, 40- and 48-wide row GEMMs)."""
+    g = np.load(os.path.join(HERE, "golden", "model_mid.npz"))
+    fl, M, h, K, q, bp = [int(x) for x in g["shapes"][i]]
+    G, B = 2, 3
+    hp = mo.Hyperparam(filter_len=fl, M=M, h=h, K=K, q=q, batch_size=B, num_pass_xyz=2, num_pass_df=2)
+    cdl_o = mo.UCDL(hp, np.random.default_rng(0)).to(torch.float64)
+    for n in mo.PARAM_VECS + ["D", "F"]:
+        setattr(cdl_o, n, torch.tensor(g[f"s{i}_init_{n}"].astype(np.float64)))
+    cdl_o.lambda_sparsity_warmup, cdl_o.lambda_stepsize_warmup, cdl_o.omega_stepsize_warmup = [float(x) for x in g[f"s{i}_warm"]]
+    cdl = to_model(pkg, ctx, hp, bp, cdl_o)
+    loss, flat = gpu_loss_grad(pkg, ctx, cdl, g[f"s{i}_codes"], G)
+    got = split_grad(cdl, flat)
+    for k in range(G):
+        assert abs(loss[k] - g[f"s{i}_loss{k}"]) <= RTOL * g[f"s{i}_loss{k}"]
+    for n in NAMES:
+        want = g[f"s{i}_grad_{n}"].astype(np.float64)
+        assert rel_inf(got[n], want) <= 5 * RTOL, (n, rel_inf(got[n], want))
+    cdl.model.close()
+
+
 def test_cfg1_golden(ctx, pkg):
     g = np.load(os.path.join(HERE, "golden", "model_cfg1.npz"))
     hp = mo.Hyperparam(filter_len=8, M=32)
