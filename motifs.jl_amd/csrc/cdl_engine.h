@@ -83,6 +83,10 @@ struct Engine {
     std::vector<TNode*> nodes;
     bool recording = true;
     bool failed = false;           // arena exhausted
+    // re-laid-out copies of filter banks (fragment order, flipped, transposed), keyed by source and kind: a bank serves
+    // many calls of a pass and its contents are final when the first of them runs
+    std::map<std::pair<const void*, int>, float*> derived;
+    float* relayout(const float* src, int kind, size_t n, bool& fresh);   // fresh: the caller fills it
     float* zpool = nullptr;        // current pre-zeroed chunk (dies with the arena at reset())
     size_t zleft = 0;
     std::map<std::string, Tensor> named;

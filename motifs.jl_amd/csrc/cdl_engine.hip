@@ -23,6 +23,7 @@ void Engine::reset() {
     tape.clear();
     named.clear();
     arena.reset();
+    derived.clear();
     zpool = nullptr;
     zleft = 0;
     failed = false;
@@ -81,6 +82,20 @@ float* Engine::zeros(size_t n) {
 float* Engine::grad(Tensor t) {
     if (!t->g) t->g = zeros(t->n);
     return t->g;
+}
+
+float* Engine::relayout(const float* src, int kind, size_t n, bool& fresh) {
+    auto key = std::make_pair((const void*)src, kind);
+    auto it = derived.find(key);
+    fresh = it == derived.end();
+    if (!fresh) return it->second;
+    float* p = arena.alloc(n);
+    if (!p) {
+        failed = true;
+        return nullptr;
+    }
+    derived[key] = p;
+    return p;
 }
 
 // The gradient buffer of t for a kernel that can either overwrite or accumulate: acc = 0 on first use (no zero fill).
@@ -1078,12 +1093,10 @@ static bool launch_ana_lds(Engine& e, const float* A, const float* Bm, float* C,
     const long jobs = (long)gm.S * tps;
     const int gB = gm.ldb == 0 ? 1 : gm.S / gm.B;
     const size_t perf = (size_t)(gm.Q / 8) * 256;
-    float* Bf = e.arena.alloc(perf * gB);
-    if (!Bf) {
-        e.failed = true;
-        return true;
-    }
-    hipLaunchKernelGGL(k_frag_b, dim3(nblocks(perf * gB)), dim3(256), 0, e.st, Bm, gB, gm.Q, gm.N, Bf);
+    bool fresh;
+    float* Bf = e.relayout(Bm, 1, perf * gB, fresh);
+    if (!Bf) return true;
+    if (fresh) hipLaunchKernelGGL(k_frag_b, dim3(nblocks(perf * gB)), dim3(256), 0, e.st, Bm, gB, gm.Q, gm.N, Bf);
     // blocks per CU: the count whose rounds x resident waves is smallest (all blocks take the same time)
     int best = 1;
     long cost = -1;
@@ -1401,12 +1414,10 @@ static bool launch_rowgemm_lds(Engine& e, const float* A, const float* Bm, float
     const long rpg = (long)(rg.S / groups) * rg.P;
     const int tpg = (int)((rpg + 31) / 32);
     const size_t perf = (size_t)(rg.Q / 4) * 256;
-    float* Bf = e.arena.alloc(perf * groups);
-    if (!Bf) {
-        e.failed = true;
-        return true;
-    }
-    hipLaunchKernelGGL(k_frag_b16, dim3(nblocks(perf * groups)), dim3(256), 0, e.st, Bm, groups, rg.Q, rg.N, Bf);
+    bool fresh;
+    float* Bf = e.relayout(Bm, 2, perf * groups, fresh);
+    if (!Bf) return true;
+    if (fresh) hipLaunchKernelGGL(k_frag_b16, dim3(nblocks(perf * groups)), dim3(256), 0, e.st, Bm, groups, rg.Q, rg.N, Bf);
     const int NT = (rg.N + 15) / 16;
     const size_t lds = std::max((size_t)32 * (rg.Q + 1) * 4, (size_t)4 * 32 * 16 * NT * 4);
     const dim3 grid((unsigned)(groups * tpg));
@@ -1515,12 +1526,10 @@ static bool launch_toep_wide(Engine& e, const float* A, const float* Bm, float* 
     const int KG = gm.Q / 8, NCT = (gm.N + 31) / 32;
     const int gB = gm.ldb == 0 ? 1 : gm.S / gm.B;
     const size_t perf = (size_t)NCT * KG * 256;
-    float* Bf = e.arena.alloc(perf * gB);
-    if (!Bf) {
-        e.failed = true;
-        return true;
-    }
-    hipLaunchKernelGGL(k_frag_bw, dim3(nblocks(perf * gB)), dim3(256), 0, e.st, Bm, gB, gm.Q, gm.N, Bf);
+    bool fresh;
+    float* Bf = e.relayout(Bm, 3, perf * gB, fresh);
+    if (!Bf) return true;
+    if (fresh) hipLaunchKernelGGL(k_frag_bw, dim3(nblocks(perf * gB)), dim3(256), 0, e.st, Bm, gB, gm.Q, gm.N, Bf);
     const int tps = (gm.P + 31) / 32;
     const dim3 grid((unsigned)((long)gm.S * tps));
     const int SO = ((gm.N + 3) & ~3) + 4;          // 4 rows apart = 16 banks apart
@@ -1565,13 +1574,14 @@ static void launch_toep(Engine& e, const float* A, const float* Bm, float* C, co
         const int H = gm.Q / gm.sa, R = gm.amax / gm.sa;
         const int gB = gm.ldb == 0 ? 1 : gm.S / gm.B;
         const size_t per = (size_t)gm.Q * gm.N;
-        float* Bt = e.arena.alloc(per * gB);
+        bool fresh;
+        float* Bt = e.relayout(Bm, 4, per * gB, fresh);
         float* Wt = e.arena.alloc((size_t)gm.S * R * H * gm.N);
         if (!Bt || !Wt) {
             e.failed = true;
             return;
         }
-        hipLaunchKernelGGL(k_tall_bt, dim3(nblocks(per * gB)), dim3(256), 0, st, Bm, gB, H, gm.sa, gm.N, Bt);
+        if (fresh) hipLaunchKernelGGL(k_tall_bt, dim3(nblocks(per * gB)), dim3(256), 0, st, Bm, gB, H, gm.sa, gm.N, Bt);
         const ToepGeom rg = tall_row_geom(gm);
         static const bool legacy_rows = getenv("MOTIFS_TOEP_LEGACY") != nullptr;
         if (legacy_rows || !launch_rowgemm_lds(e, A, Bt, Wt, rg, 0)) {
@@ -1976,12 +1986,10 @@ static bool toep_adjoint_a(Engine& e, const float* dC, const float* Bm, float* d
     const int W = gm.sa, H = gm.Q / gm.sa;
     const int gB = gm.ldb == 0 ? 1 : gm.S / gm.B;
     const size_t per = (size_t)gm.Q * gm.N;
-    float* tmp = e.arena.alloc(per * gB);
-    if (!tmp) {
-        e.failed = true;
-        return false;
-    }
-    hipLaunchKernelGGL(k_flipT, dim3(nblocks(per * gB)), dim3(256), 0, e.st, Bm, gB, H, W, gm.N, tmp, 0);
+    bool fresh;
+    float* tmp = e.relayout(Bm, 5, per * gB, fresh);
+    if (!tmp) return false;
+    if (fresh) hipLaunchKernelGGL(k_flipT, dim3(nblocks(per * gB)), dim3(256), 0, e.st, Bm, gB, H, W, gm.N, tmp, 0);
     ToepGeom g2;
     g2.S = gm.S;
     g2.P = gm.amax / W;
