@@ -1310,10 +1310,10 @@ template <int NT>
 __global__ __launch_bounds__(256) void k_rowgemm_lds(const float* __restrict__ A, const float* __restrict__ Bf, float* __restrict__ C,
                                                      int rpg, int tpg, int Q, int N, int64_t ldbf, int acc) {
     constexpr int NV = 15, U = 4;                  // 16-byte loads per thread (Q <= 480); reduction steps per prefetch unit
-    extern __shared__ float lds[];                 // [32][Q + 1]; at the end 4 x [32][16 NT]
+    extern __shared__ float lds[];                 // [32][Q + 4]; at the end 4 x [32][16 NT]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = blockIdx.x / tpg, r0 = (blockIdx.x - g * tpg) * 32;
-    const int nrow = min(32, rpg - r0), ST = Q + 1, Q4 = Q >> 2;
+    const int nrow = min(32, rpg - r0), ST = Q + 4, Q4 = Q >> 2;   // Q % 16 == 0: rows 4*odd dwords apart, conflict-free operand reads
     const size_t row0 = (size_t)g * rpg + r0;
     const float4* At = (const float4*)(A + row0 * Q);
     const int nf4 = nrow * Q4, tf4 = 32 * Q4;
@@ -1329,10 +1329,7 @@ __global__ __launch_bounds__(256) void k_rowgemm_lds(const float* __restrict__ A
         const int drow = 256 / Q4, dc = 256 - drow * Q4;
 #pragma unroll
         for (int i = 0; i < NV; i++) {
-            if (tid + i * 256 < tf4) {
-                float* d = lds + row * ST + c4 * 4;
-                d[0] = v[i].x, d[1] = v[i].y, d[2] = v[i].z, d[3] = v[i].w;
-            }
+            if (tid + i * 256 < tf4) *(float4*)(lds + row * ST + c4 * 4) = v[i];
             row += drow, c4 += dc;
             if (c4 >= Q4) c4 -= Q4, row++;
         }
@@ -1419,7 +1416,7 @@ static bool launch_rowgemm_lds(Engine& e, const float* A, const float* Bm, float
     if (!Bf) return true;
     if (fresh) hipLaunchKernelGGL(k_frag_b16, dim3(nblocks(perf * groups)), dim3(256), 0, e.st, Bm, groups, rg.Q, rg.N, Bf);
     const int NT = (rg.N + 15) / 16;
-    const size_t lds = std::max((size_t)32 * (rg.Q + 1) * 4, (size_t)4 * 32 * 16 * NT * 4);
+    const size_t lds = std::max((size_t)32 * (rg.Q + 4) * 4, (size_t)4 * 32 * 16 * NT * 4);
     const dim3 grid((unsigned)(groups * tpg));
     const int64_t ldbf = rg.ldb == 0 ? 0 : (int64_t)perf;
 #define ROWGEMM(NTV) hipLaunchKernelGGL((k_rowgemm_lds<NTV>), grid, dim3(256), lds, e.st, A, Bf, C, (int)rpg, tpg, rg.Q, rg.N, ldbf, acc)
@@ -1532,7 +1529,7 @@ static bool launch_toep_wide(Engine& e, const float* A, const float* Bm, float* 
     if (fresh) hipLaunchKernelGGL(k_frag_bw, dim3(nblocks(perf * gB)), dim3(256), 0, e.st, Bm, gB, gm.Q, gm.N, Bf);
     const int tps = (gm.P + 31) / 32;
     const dim3 grid((unsigned)((long)gm.S * tps));
-    const int SO = ((gm.N + 3) & ~3) + 4;          // 4 rows apart = 16 banks apart
+    const int SO = ((gm.N + 15) & ~15) + 8;        // 4 rows apart = 32 banks apart: the two lane halves of a tile store never meet
     const size_t lds = (size_t)32 * SO * 4;
     const int64_t ldbf = gm.ldb == 0 ? 0 : (int64_t)perf;
 #define TOEPWIDE(K) hipLaunchKernelGGL((k_toep_wide<K>), grid, dim3(256), lds, e.st, A, Bf, C, gm, acc, tps, ldbf, SO)
