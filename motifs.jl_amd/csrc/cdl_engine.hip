@@ -357,6 +357,29 @@ __global__ void k_zy_step_bwd(const float* go, const float* out, const float* ZY
     }
 }
 
+// The gradient step of update_X (model.jl:252-253) before the projection: out = X - ost * xg (ost a device scalar),
+// and its VJP in one pass: dX (+)= go, dxg (+)= -ost * go, d ost += -sum(go * xg).
+__global__ void k_x_step(const float* X, const float* xg, const float* ost, size_t n, float* out) {
+    const float o = *ost;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = X[i] - xg[i] * o;
+}
+__global__ void k_x_step_bwd(const float* go, const float* xg, const float* ost, size_t n, float* dX, int aX, float* dxg, int axg,
+                             float* dost) {
+    const float o = *ost;
+    double so = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float g = go[i];
+        if (dX) dX[i] = (aX ? dX[i] : 0.0f) + g;
+        if (dxg) dxg[i] = (axg ? dxg[i] : 0.0f) - o * g;
+        so -= (double)g * (double)xg[i];
+    }
+    for (int d = 32; d >= 1; d >>= 1) so += __shfl_xor(so, d);
+    __shared__ double red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = so;
+    __syncthreads();
+    if (threadIdx.x == 0 && dost) atomicAdd(dost, (float)(red[0] + red[1] + red[2] + red[3]));
+}
+
 // The same step with the dual update of the previous pass folded in (model.jl:263-266 then :240-244): the scaled
 // duals [alpha beta] advance by FX - ZY on entry,
 //   abn = FX - ZY + abp                         (abp optional: zero duals, :338)
@@ -503,6 +526,23 @@ Tensor Engine::zy_step(Tensor ZY, Tensor g1, Tensor FX, Tensor ab, Tensor pen, T
             if (failed) return;
             hipLaunchKernelGGL(k_zy_step_bwd, dim3(nblocks(out->n, 256, 2048)), dim3(256), 0, st, out->g, out->v, ZY->v, g1->v, FX->v,
                                ab ? ab->v : nullptr, pen->v, lst->v, ls->v, out->n, d0, a0, d1, a1, d2, a2, d3, a3, dp, ds, dl);
+        });
+    return out;
+}
+
+Tensor Engine::x_step(Tensor X, Tensor xg, Tensor ost) {
+    Tensor out = make(X->n, X->needs_grad || xg->needs_grad || ost->needs_grad);
+    if (failed) return out;
+    EW(k_x_step, X->n, X->v, xg->v, ost->v, X->n, out->v);
+    if (recording && out->needs_grad)
+        tape.push_back([this, out, X, xg, ost]() {
+            if (!out->g) return;
+            int a0 = 1, a1 = 1;
+            float* d0 = X->needs_grad ? grad_first(X, a0) : nullptr;
+            float* d1 = xg->needs_grad ? grad_first(xg, a1) : nullptr;
+            float* dq = ost->needs_grad ? grad(ost) : nullptr;
+            if (failed) return;
+            hipLaunchKernelGGL(k_x_step_bwd, dim3(nblocks(out->n, 256, 1024)), dim3(256), 0, st, out->g, xg->v, ost->v, out->n, d0, a0, d1, a1, dq);
         });
     return out;
 }

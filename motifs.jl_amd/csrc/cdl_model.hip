@@ -168,7 +168,7 @@ static void admm_xyz(motifs_model* m, Graph& gr, const Scalars& sc, const Graph:
         // FX - (cat_ZY(ZY) - [alpha beta]); the magnified, median-masked image is formed inside the same pass
         const float* zt = gr.zy_thr(ZY);
         Tensor xg = gr.anaF(e.lin3(FX, 1.0f, ZY, -m->hp.magnifying_factor, ab, 1.0f, zt, gr.G), bF);
-        X = gr.project_X(e.lin(X, 1.0f, e.mul(xg, sc.ost[t]), -1.0f, 0.0f));
+        X = gr.project_X(e.x_step(X, xg, sc.ost[t]));
         FX = gr.synF(X, bF);                                              // the duals advance at the top of the next pass
     }
     e.note("ZY", ZY);
