@@ -113,6 +113,7 @@ struct Engine {
     Tensor lin3(Tensor x, float a, Tensor y, float b, Tensor z, float c, const float* ythr = nullptr, int groups = 1);   // ythr: y counts where y >= ythr[group]
     // relu(ZY - lst*(g1 + pen*(ZY - FX - ab)) - ls*lst): the ISTA step of update_ZY fused (ab optional; scalars are 1-element tensors)
     Tensor zy_step(Tensor ZY, Tensor g1, Tensor FX, Tensor ab, Tensor pen, Tensor lst, Tensor ls);
+    Tensor f_step(Tensor Fc, Tensor Fgrad, Tensor kst, Tensor ks);   // relu((Fc - Fgrad*kst) - kst*ks), Fc broadcast over groups if smaller
     Tensor x_step(Tensor X, Tensor xg, Tensor ost);   // X - ost * xg (update_X before the projection), VJP in one pass
     // the same with the dual update folded in: abn = FX - ZY + abp (abp optional), then the step with abn; returns {out, abn}
     std::pair<Tensor, Tensor> zy_step2(Tensor ZY, Tensor g1, Tensor FX, Tensor abp, Tensor pen, Tensor lst, Tensor ls);

@@ -208,9 +208,7 @@ static Tensor forward_loss(motifs_model* m, Graph& gr, bool train) {
         Tensor FXc = gr.synF(X, bFc);
         Tensor R = e.lin3(FXc, 1.0f, ZYm, -1.0f, theta, -1.0f);
         Tensor Fgrad = e.swap02(e.wgrad_sp(R, X, gr.spd(G)), G, m->h, m->twoM, m->K);
-        Tensor t2 = e.lin(e.mul(Fgrad, sc.kst[t]), -1.0f, Fc, 1.0f, 0.0f);
-        Tensor t3 = e.lin(t2, 1.0f, e.mul(sc.kst[t], sc.ks[t]), -1.0f, 0.0f);
-        Fc = e.norml2(e.relu(t3), m->h * m->twoM);
+        Fc = e.norml2(e.f_step(Fc, Fgrad, sc.kst[t], sc.ks[t]), m->h * m->twoM);   // relu(F - kst*Fgrad - kst*ks), normalised
         gF = G;
         bFc = gr.bankF(Fc, gF);
         // theta (:370)
