@@ -37,6 +37,13 @@ struct TNode {
     uint2* nz_ent = nullptr;
     int* gm_cnt = nullptr;
     uint2* gm_ent = nullptr;
+    // set on the first output of zy_step2 by lin3_zy: the combination FX + b*[zy >= thr]*zy + abn formed right after the
+    // step.  Its VJP rides in the step's own backward kernel (the two are neighbours on the tape).
+    TNode* fl_img = nullptr;
+    TNode* fl_x = nullptr;
+    float fl_b = 0.0f;
+    const float* fl_thr = nullptr;
+    int fl_groups = 1;
 };
 
 struct NzView {
@@ -113,6 +120,8 @@ struct Engine {
     Tensor lin3(Tensor x, float a, Tensor y, float b, Tensor z, float c, const float* ythr = nullptr, int groups = 1);   // ythr: y counts where y >= ythr[group]
     // relu(ZY - lst*(g1 + pen*(ZY - FX - ab)) - ls*lst): the ISTA step of update_ZY fused (ab optional; scalars are 1-element tensors)
     Tensor zy_step(Tensor ZY, Tensor g1, Tensor FX, Tensor ab, Tensor pen, Tensor lst, Tensor ls);
+    // FX + b*[zy >= thr[group]]*zy + abn for the outputs (zy, abn) of zy_step2(.., FX, ..): no tape entry of its own
+    Tensor lin3_zy(Tensor FX, Tensor zy, float b, Tensor abn, const float* thr, int groups);
     Tensor f_step(Tensor Fc, Tensor Fgrad, Tensor kst, Tensor ks);   // relu((Fc - Fgrad*kst) - kst*ks), Fc broadcast over groups if smaller
     Tensor x_step(Tensor X, Tensor xg, Tensor ost);   // X - ost * xg (update_X before the projection), VJP in one pass
     // the same with the dual update folded in: abn = FX - ZY + abp (abp optional), then the step with abn; returns {out, abn}

@@ -439,14 +439,24 @@ __global__ void k_zy_step2(const float* ZY, const float* g1, const float* FX, co
     }
 }
 // VJP: go = d out (may be null), gab = d abn (may be null).  inner = 2 ZY - 2 FX - abp.
-__global__ void k_zy_step2_bwd(const float* go, const float* gab, const float* out, const float* ZY, const float* g1, const float* FX,
-                               const float* abp, const float* pen, const float* lst, const float* ls, size_t n, float* dZY, int aZY,
-                               float* dg1, int ag1, float* dFX, int aFX, float* dabp, int aabp, float* dpen, float* dlst, float* dls) {
+// g3 (optional) = d of the combination img = FX + b3*[out >= thr]*out + abn formed after the step (lin3_zy): its
+// three contributions (to d out, d abn and d FX) are folded in here instead of a pass of their own.
+__global__ void k_zy_step2_bwd(const float* go, const float* gab, const float* g3, float b3, const float* thr, const float* out,
+                               const float* ZY, const float* g1, const float* FX, const float* abp, const float* pen, const float* lst,
+                               const float* ls, size_t per, float* dZY, int aZY, float* dg1, int ag1, float* dFX, int aFX, float* dabp,
+                               int aabp, float* dpen, float* dlst, float* dls) {
     const float p = *pen, s = *lst, l = *ls;
+    const size_t base = (size_t)blockIdx.y * per;
+    const float t3 = thr ? thr[blockIdx.y] : 0.0f;
     double sp = 0, ss = 0, sl = 0;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const float du = (go && out[i] > 0.0f) ? go[i] : 0.0f;
-        const float gb = gab ? gab[i] : 0.0f;
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < per; j += (size_t)gridDim.x * blockDim.x) {
+        const size_t i = base + j;
+        const float o = out[i];
+        const float g3v = g3 ? g3[i] : 0.0f;
+        float gz = go ? go[i] : 0.0f;
+        if (g3) gz += b3 * ((thr && !(o >= t3)) ? 0.0f : g3v);
+        const float du = o > 0.0f ? gz : 0.0f;
+        const float gb = (gab ? gab[i] : 0.0f) + g3v;
         const float zy = ZY[i], fx = FX[i];
         const float dual = (fx - zy) + (abp ? abp[i] : 0.0f);
         const float inner = zy - (fx + dual);
@@ -454,7 +464,7 @@ __global__ void k_zy_step2_bwd(const float* go, const float* gab, const float* o
         const float t = s * p * du;
         if (dZY) dZY[i] = (aZY ? dZY[i] : 0.0f) + (du - 2.0f * t) - gb;
         if (dg1) dg1[i] = (ag1 ? dg1[i] : 0.0f) - s * du;
-        if (dFX) dFX[i] = (aFX ? dFX[i] : 0.0f) + 2.0f * t + gb;
+        if (dFX) dFX[i] = (aFX ? dFX[i] : 0.0f) + (2.0f * t + gb) + g3v;
         if (dabp) dabp[i] = (aabp ? dabp[i] : 0.0f) + t + gb;
         sp -= (double)du * (double)(s * inner);
         ss -= (double)du * (double)(grad + l);
@@ -570,6 +580,23 @@ Tensor Engine::zy_step(Tensor ZY, Tensor g1, Tensor FX, Tensor ab, Tensor pen, T
     return out;
 }
 
+Tensor Engine::lin3_zy(Tensor FX, Tensor zy, float b, Tensor abn, const float* thr, int groups) {
+    Tensor out = make(FX->n, FX->needs_grad || zy->needs_grad || abn->needs_grad);
+    if (failed) return out;
+    const int G = thr ? groups : 1;
+    const size_t per = FX->n / G;
+    const dim3 grid(nblocks(per, 256, std::max<size_t>(256 * 32 / G, 1)), G);
+    hipLaunchKernelGGL(k_lin3, grid, dim3(256), 0, st, FX->v, 1.0f, zy->v, thr, b, abn->v, 1.0f, per, out->v);
+    if (recording && out->needs_grad) {            // no tape entry: zy_step2's VJP (the neighbour on the tape) picks this up
+        zy->fl_img = out;
+        zy->fl_x = FX;
+        zy->fl_b = b;
+        zy->fl_thr = thr;
+        zy->fl_groups = G;
+    }
+    return out;
+}
+
 Tensor Engine::f_step(Tensor Fc, Tensor Fgrad, Tensor kst, Tensor ks) {
     Tensor out = make(Fgrad->n, Fc->needs_grad || Fgrad->needs_grad || kst->needs_grad || ks->needs_grad);
     if (failed) return out;
@@ -621,7 +648,10 @@ std::pair<Tensor, Tensor> Engine::zy_step2(Tensor ZY, Tensor g1, Tensor FX, Tens
     EW(k_zy_step2, ZY->n, ZY->v, g1->v, FX->v, abp ? abp->v : nullptr, pen->v, lst->v, ls->v, ZY->n, out->v, abn->v);
     if (recording && ng)
         tape.push_back([this, out, abn, ZY, g1, FX, abp, pen, lst, ls]() {
-            if (!out->g && !abn->g) return;
+            // the combination formed after the step (lin3_zy), if any, and its gradient
+            Tensor img = (out->fl_img && out->fl_x == FX) ? out->fl_img : nullptr;
+            const float* g3 = img ? img->g : nullptr;
+            if (!out->g && !abn->g && !g3) return;
             int a0 = 1, a1 = 1, a2 = 1, a3 = 1;
             float* d0 = ZY->needs_grad ? grad_first(ZY, a0) : nullptr;
             float* d1 = g1->needs_grad ? grad_first(g1, a1) : nullptr;
@@ -631,8 +661,11 @@ std::pair<Tensor, Tensor> Engine::zy_step2(Tensor ZY, Tensor g1, Tensor FX, Tens
             float* ds = lst->needs_grad ? grad(lst) : nullptr;
             float* dl = ls->needs_grad ? grad(ls) : nullptr;
             if (failed) return;
-            hipLaunchKernelGGL(k_zy_step2_bwd, dim3(nblocks(out->n, 256, 2048)), dim3(256), 0, st, out->g, abn->g, out->v, ZY->v, g1->v,
-                               FX->v, abp ? abp->v : nullptr, pen->v, lst->v, ls->v, out->n, d0, a0, d1, a1, d2, a2, d3, a3, dp, ds, dl);
+            const int G = g3 ? out->fl_groups : 1;
+            const size_t per = out->n / G;
+            hipLaunchKernelGGL(k_zy_step2_bwd, dim3(nblocks(per, 256, std::max<size_t>(2048 / G, 1)), G), dim3(256), 0, st, out->g, abn->g, g3,
+                               out->fl_b, g3 ? out->fl_thr : nullptr, out->v, ZY->v, g1->v, FX->v, abp ? abp->v : nullptr, pen->v, lst->v, ls->v,
+                               per, d0, a0, d1, a1, d2, a2, d3, a3, dp, ds, dl);
         });
     return {out, abn};
 }

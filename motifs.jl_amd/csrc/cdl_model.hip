@@ -167,7 +167,10 @@ static void admm_xyz(motifs_model* m, Graph& gr, const Scalars& sc, const Graph:
         // update_X (:247-254); `sum(FX, dims=3)` is a no-op on the already summed FX
         // FX - (cat_ZY(ZY) - [alpha beta]); the magnified, median-masked image is formed inside the same pass
         const float* zt = gr.zy_thr(ZY);
-        Tensor xg = gr.anaF(e.lin3(FX, 1.0f, ZY, -m->hp.magnifying_factor, ab, 1.0f, zt, gr.G), bF);
+        // (for t >= 1 the VJP of this combination is folded into the backward kernel of the step that made ZY and ab)
+        Tensor img = t == 0 ? e.lin3(FX, 1.0f, ZY, -m->hp.magnifying_factor, ab, 1.0f, zt, gr.G)
+                            : e.lin3_zy(FX, ZY, -m->hp.magnifying_factor, ab, zt, gr.G);
+        Tensor xg = gr.anaF(img, bF);
         X = gr.project_X(e.x_step(X, xg, sc.ost[t]));
         FX = gr.synF(X, bF);                                              // the duals advance at the top of the next pass
     }
