@@ -141,7 +141,7 @@ static Scalars prep_scalars(motifs_model* m, Graph& gr, bool train) {
 
 // ADMM_XYZ (model.jl:330-357) on G mini-batches.  Returns ZY (unmagnified codes) and X.
 static void admm_xyz(motifs_model* m, Graph& gr, const Scalars& sc, const Graph::Bank& bD, const Graph::Bank& bF,
-                     Tensor& ZY, Tensor& X) {
+                     Tensor& ZY, Tensor& X, Tensor* FX_out = nullptr) {
     Engine& e = m->eng;
     const float lspw = m->warm[0] * m->warm[0], lsw = m->warm[1] * m->warm[1], osw = m->warm[2] * m->warm[2];
     // warm-up (:224-232, :171-179, :212-216)
@@ -176,6 +176,7 @@ static void admm_xyz(motifs_model* m, Graph& gr, const Scalars& sc, const Graph:
     }
     e.note("ZY", ZY);
     e.note("X", X);
+    if (FX_out) *FX_out = FX;                                             // sum(conv(X, F)) of the final codes
 }
 
 // forward_pass_return_loss (model.jl:375-395) for G mini-batches; per-group losses in `loss` ([G]).
@@ -190,8 +191,8 @@ static Tensor forward_loss(motifs_model* m, Graph& gr, bool train) {
     e.note("Dp", Dp);
     e.note("Fp", Fp);
     Graph::Bank bD = gr.bankD(Dp, 1), bF = gr.bankF(Fp, 1);
-    Tensor ZY, X;
-    admm_xyz(m, gr, sc, bD, bF, ZY, X);
+    Tensor ZY, X, FXfin;
+    admm_xyz(m, gr, sc, bD, bF, ZY, X, &FXfin);
 
     // ADMM_DF (:362-373)
     Tensor ZYm = gr.cat_ZY(ZY);
@@ -199,6 +200,7 @@ static Tensor forward_loss(motifs_model* m, Graph& gr, bool train) {
     int gD = 1, gF = 1;
     Graph::Bank bDc = bD, bFc = bF;
     const int G = gr.G;
+    Tensor FXcur = FXfin;                                                  // sum(conv(X, F)) with the bank in force (:294, :305, :321)
     for (int t = 0; t < m->hp.num_pass_df; t++) {
         // update_D (:275-290): D_grad = Z'(sumZD + sumYRD + S) + reverse(Y'(...)), only the f_len needed lags
         Tensor sig = e.lin(gr.synD(ZY, bDc), 1.0f, gr.Sone, 1.0f, 0.0f);
@@ -207,8 +209,8 @@ static Tensor forward_loss(motifs_model* m, Graph& gr, bool train) {
         Dc = e.norm4(e.mul(ex, Dc));
         gD = G;
         bDc = gr.bankD(Dc, gD);
-        // update_F (:292-308)
-        Tensor FXc = gr.synF(X, bFc);
+        // update_F (:292-308); the synthesis with the current bank was formed once (before the loop / as FXn below)
+        Tensor FXc = FXcur;
         Tensor R = e.lin3(FXc, 1.0f, ZYm, -1.0f, theta, -1.0f);
         Tensor Fgrad = e.swap02(e.wgrad_sp(R, X, gr.spd(G)), G, m->h, m->twoM, m->K);
         Fc = e.norml2(e.f_step(Fc, Fgrad, sc.kst[t], sc.ks[t]), m->h * m->twoM);   // relu(F - kst*Fgrad - kst*ks), normalised
@@ -217,13 +219,14 @@ static Tensor forward_loss(motifs_model* m, Graph& gr, bool train) {
         // theta (:370)
         Tensor FXn = gr.synF(X, bFc);
         theta = e.lin3(FXn, 1.0f, ZYm, -1.0f, theta, 1.0f);
+        FXcur = FXn;                                                       // the same tensor the next pass (and the loss) starts from
     }
     e.note("Dfinal", Dc);
     e.note("Ffinal", Fc);
     // loss (:310-325)
     const float nf = 1.0f / (float)m->B;
     Tensor r1 = e.lin(gr.synD(ZY, bDc), 1.0f, gr.Sone, -1.0f, 0.0f);
-    Tensor r2 = e.lin(gr.synF(X, bFc), 1.0f, ZYm, -1.0f, 0.0f);
+    Tensor r2 = e.lin(FXcur, 1.0f, ZYm, -1.0f, 0.0f);
     Tensor Lv = e.lin(e.sumsq_groups(r1, nf, G), 1.0f, e.sumsq_groups(r2, nf, G), 1.0f, 0.0f);
     (void)gD;
     (void)gF;
