@@ -46,6 +46,8 @@ struct Graph {
     int G, S;
     ToepGeom gD1, gD2, gF1, gF2;
     Tensor Sone;
+    Tensor thr_of = nullptr;          // the codes whose medians were taken last, and where they are
+    const float* thr_last = nullptr;
 
     Graph(motifs_model* mm, int groups) : m(mm), e(mm->eng), G(groups), S(groups * mm->B) {
         const int L4 = m->L4, c = m->c, l = m->l, twoM = m->twoM, K = m->K, h = m->h, fl = m->fl;
@@ -71,10 +73,13 @@ struct Graph {
     // the medians behind cat_ZY's mask, one per mini-batch (constants in the backward, @ignore :208): consumers compare
     // against them in their own pass instead of reading a 0/1 mask
     const float* zy_thr(Tensor ZY) {
+        if (ZY == thr_of) return thr_last;                                // the final codes are thresholded twice (:251, :364)
         Tensor thr = e.make((size_t)G + 64, false);
         float* ws = e.zeros(median_workspace_bytes(G) / 4 + 64);
         if (e.failed) return nullptr;
         median_threshold(e.st, ZY->v, thr->v, G, (int)(ZY->n / G), ws);
+        thr_of = ZY;
+        thr_last = thr->v;
         return thr->v;
     }
     // project_X (model.jl:181-192): keep the entries >= the q-th largest of each sequence
