@@ -381,18 +381,19 @@ __global__ void k_x_step_bwd(const float* go, const float* xg, const float* ost,
 }
 
 // The proximal step of update_F (model.jl:298-303) before the normalisation, with the arithmetic of the separate
-// passes it replaces: out = relu((Fc - Fgrad * kst) - kst * ks); Fc may be one bank shared by all groups (n_c < n).
-// VJP in one pass: dt = go * [out > 0]; dFgrad (+)= -kst dt; dFc (+)= dt (same size) or dt is written out for the
-// reduction over groups; d kst += -sum(dt (Fgrad + ks)); d ks += -kst sum(dt).
-__global__ void k_f_step(const float* Fc, size_t nc, const float* Fgrad, const float* kst, const float* ks, size_t n, float* out) {
+// passes it replaces: out = relu((Fc - sg * Fgrad * kst) - kst * ks); Fc may be one bank shared by all groups
+// (n_c < n); sg = +-1 (the gradient may arrive negated), Fgrad may be absent (identically zero).
+// VJP in one pass: dt = go * [out > 0]; dFgrad (+)= -sg kst dt; dFc (+)= dt (same size) or dt is written out for the
+// reduction over groups; d kst += -sum(dt (sg Fgrad + ks)); d ks += -kst sum(dt).
+__global__ void k_f_step(const float* Fc, size_t nc, const float* Fgrad, float sg, const float* kst, const float* ks, size_t n, float* out) {
     const float a = *kst, m2 = *kst * *ks;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const float m1 = Fgrad[i] * a;
+        const float m1 = Fgrad ? (sg * Fgrad[i]) * a : 0.0f;
         const float t3 = (Fc[nc == n ? i : i % nc] - m1) - m2;
         out[i] = t3 > 0.0f ? t3 : 0.0f;
     }
 }
-__global__ void k_f_step_bwd(const float* go, const float* out, const float* Fgrad, const float* kst, const float* ks, size_t n,
+__global__ void k_f_step_bwd(const float* go, const float* out, const float* Fgrad, float sg, const float* kst, const float* ks, size_t n,
                              float* dFc, int aFc, float* dFg, int aFg, float* dt_out, float* dkst, float* dks) {
     const float a = *kst, b = *ks;
     double sk = 0, ss = 0;
@@ -400,8 +401,8 @@ __global__ void k_f_step_bwd(const float* go, const float* out, const float* Fgr
         const float dt = out[i] > 0.0f ? go[i] : 0.0f;
         if (dFc) dFc[i] = (aFc ? dFc[i] : 0.0f) + dt;
         if (dt_out) dt_out[i] = dt;
-        if (dFg) dFg[i] = (aFg ? dFg[i] : 0.0f) - a * dt;
-        sk -= (double)dt * (double)(Fgrad[i] + b);
+        if (dFg) dFg[i] = (aFg ? dFg[i] : 0.0f) - (sg * a) * dt;
+        sk -= (double)dt * (double)((Fgrad ? sg * Fgrad[i] : 0.0f) + b);
         ss -= (double)dt * (double)a;
     }
     for (int d = 32; d >= 1; d >>= 1) {
@@ -597,17 +598,17 @@ Tensor Engine::lin3_zy(Tensor FX, Tensor zy, float b, Tensor abn, const float* t
     return out;
 }
 
-Tensor Engine::f_step(Tensor Fc, Tensor Fgrad, Tensor kst, Tensor ks) {
-    Tensor out = make(Fgrad->n, Fc->needs_grad || Fgrad->needs_grad || kst->needs_grad || ks->needs_grad);
+Tensor Engine::f_step(Tensor Fc, Tensor Fgrad, float sg, Tensor kst, Tensor ks, size_t n) {
+    Tensor out = make(n, Fc->needs_grad || (Fgrad && Fgrad->needs_grad) || kst->needs_grad || ks->needs_grad);
     if (failed) return out;
-    EW(k_f_step, out->n, Fc->v, Fc->n, Fgrad->v, kst->v, ks->v, out->n, out->v);
+    EW(k_f_step, out->n, Fc->v, Fc->n, Fgrad ? Fgrad->v : nullptr, sg, kst->v, ks->v, out->n, out->v);
     if (recording && out->needs_grad)
-        tape.push_back([this, out, Fc, Fgrad, kst, ks]() {
+        tape.push_back([this, out, Fc, Fgrad, sg, kst, ks]() {
             if (!out->g) return;
             const bool same = Fc->n == out->n;
             int a0 = 1, a1 = 1;
             float* d0 = (Fc->needs_grad && same) ? grad_first(Fc, a0) : nullptr;
-            float* d1 = Fgrad->needs_grad ? grad_first(Fgrad, a1) : nullptr;
+            float* d1 = (Fgrad && Fgrad->needs_grad) ? grad_first(Fgrad, a1) : nullptr;
             float* dt = (Fc->needs_grad && !same) ? arena.alloc(out->n) : nullptr;
             float* dk = kst->needs_grad ? grad(kst) : nullptr;
             float* ds = ks->needs_grad ? grad(ks) : nullptr;
@@ -615,8 +616,8 @@ Tensor Engine::f_step(Tensor Fc, Tensor Fgrad, Tensor kst, Tensor ks) {
                 failed = true;
                 return;
             }
-            hipLaunchKernelGGL(k_f_step_bwd, dim3(nblocks(out->n, 256, 2048)), dim3(256), 0, st, out->g, out->v, Fgrad->v, kst->v, ks->v, out->n, d0,
-                               a0, d1, a1, dt, dk, ds);
+            hipLaunchKernelGGL(k_f_step_bwd, dim3(nblocks(out->n, 256, 2048)), dim3(256), 0, st, out->g, out->v, Fgrad ? Fgrad->v : nullptr, sg,
+                               kst->v, ks->v, out->n, d0, a0, d1, a1, dt, dk, ds);
             if (dt) bcast_reduce(st, dt, nullptr, out->n, Fc->n, 1.0f, grad(Fc));   // the shared bank: sum over the groups
         });
     return out;

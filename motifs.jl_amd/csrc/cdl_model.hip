@@ -206,7 +206,18 @@ static Tensor forward_loss(motifs_model* m, Graph& gr, bool train) {
     Graph::Bank bDc = bD, bFc = bF;
     const int G = gr.G;
     Tensor FXcur = FXfin;                                                  // sum(conv(X, F)) with the bank in force (:294, :305, :321)
-    for (int t = 0; t < m->hp.num_pass_df; t++) {
+    // The residual of update_F, R_t = FX(F_t) - ZYm - theta_{t-1} (:294-296), with theta_t = theta_{t-1} + FX(F_{t+1}) - ZYm
+    // (:370), telescopes: the synthesis that closes pass t is the one that opens pass t + 1, so
+    //     R_0 = FX(F_0) - ZYm,   R_t = -theta_{t-2}  (t >= 1, theta_{-1} = 0: R_1 is identically zero),
+    // in any precision up to the rounding of one addition.  The literal sequence forms R_t from three image-sized
+    // tensors and keeps every theta and every closing synthesis; here only what a later pass or the loss consumes is
+    // formed (theta_t for t <= P - 3, the closing synthesis of those passes and of the last).  MOTIFS_DF_LITERAL=1 runs
+    // the literal sequence (tests/test_model_gpu.py compares the two).
+    static const bool literal = getenv("MOTIFS_DF_LITERAL") != nullptr;
+    const int P = m->hp.num_pass_df;
+    const size_t nbank = (size_t)G * m->h * m->twoM * m->K;
+    std::vector<Tensor> thetas;                                            // theta_0 ..
+    for (int t = 0; t < P; t++) {
         // update_D (:275-290): D_grad = Z'(sumZD + sumYRD + S) + reverse(Y'(...)), only the f_len needed lags
         Tensor sig = e.lin(gr.synD(ZY, bDc), 1.0f, gr.Sone, 1.0f, 0.0f);
         Tensor Dgrad = e.collapseD(e.wgrad(sig, ZY, gr.gD1), G, m->M, m->fl);
@@ -214,17 +225,30 @@ static Tensor forward_loss(motifs_model* m, Graph& gr, bool train) {
         Dc = e.norm4(e.mul(ex, Dc));
         gD = G;
         bDc = gr.bankD(Dc, gD);
-        // update_F (:292-308); the synthesis with the current bank was formed once (before the loop / as FXn below)
-        Tensor FXc = FXcur;
-        Tensor R = e.lin3(FXc, 1.0f, ZYm, -1.0f, theta, -1.0f);
-        Tensor Fgrad = e.swap02(e.wgrad_sp(R, X, gr.spd(G)), G, m->h, m->twoM, m->K);
-        Fc = e.norml2(e.f_step(Fc, Fgrad, sc.kst[t], sc.ks[t]), m->h * m->twoM);   // relu(F - kst*Fgrad - kst*ks), normalised
+        // update_F (:292-308)
+        if (literal) {
+            Tensor R = e.lin3(FXcur, 1.0f, ZYm, -1.0f, theta, -1.0f);
+            Tensor Fgrad = e.swap02(e.wgrad_sp(R, X, gr.spd(G)), G, m->h, m->twoM, m->K);
+            Fc = e.norml2(e.f_step(Fc, Fgrad, 1.0f, sc.kst[t], sc.ks[t], nbank), m->h * m->twoM);
+        } else if (t == 0) {
+            Tensor R = e.lin3(FXcur, 1.0f, ZYm, -1.0f, nullptr, 0.0f);
+            Tensor Fgrad = e.swap02(e.wgrad_sp(R, X, gr.spd(G)), G, m->h, m->twoM, m->K);
+            Fc = e.norml2(e.f_step(Fc, Fgrad, 1.0f, sc.kst[t], sc.ks[t], nbank), m->h * m->twoM);
+        } else if (t == 1) {                                               // R_1 = 0: the gradient of F vanishes identically
+            Fc = e.norml2(e.f_step(Fc, nullptr, 1.0f, sc.kst[t], sc.ks[t], nbank), m->h * m->twoM);
+        } else {                                                           // R_t = -theta_{t-2}: the sign goes into the step
+            Tensor Fgrad = e.swap02(e.wgrad_sp(thetas[t - 2], X, gr.spd(G)), G, m->h, m->twoM, m->K);
+            Fc = e.norml2(e.f_step(Fc, Fgrad, -1.0f, sc.kst[t], sc.ks[t], nbank), m->h * m->twoM);
+        }
         gF = G;
         bFc = gr.bankF(Fc, gF);
-        // theta (:370)
-        Tensor FXn = gr.synF(X, bFc);
-        theta = e.lin3(FXn, 1.0f, ZYm, -1.0f, theta, 1.0f);
-        FXcur = FXn;                                                       // the same tensor the next pass (and the loss) starts from
+        // theta (:370) and the synthesis with the new bank, where something consumes them
+        const bool need_theta = literal || t + 2 < P;
+        if (need_theta || t == P - 1) FXcur = gr.synF(X, bFc);
+        if (need_theta) {
+            theta = e.lin3(FXcur, 1.0f, ZYm, -1.0f, theta, 1.0f);
+            thetas.push_back(theta);
+        }
     }
     e.note("Dfinal", Dc);
     e.note("Ffinal", Fc);

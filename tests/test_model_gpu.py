@@ -193,6 +193,23 @@ def test_cfg2_groups_are_independent(ctx, pkg):
     cdl.model.close()
 
 
+def test_df_telescoping_equals_literal_sequence(ctx, pkg, tmp_path):
+    """ADMM_DF forms only the residuals / duals / syntheses that something consumes (R_1 = 0, R_t = -theta_{t-2}); the
+    literal sequence of model.jl:362-373 (MOTIFS_DF_LITERAL=1, read once per process) gives the same loss and gradient."""
+    import subprocess
+    import sys
+    outs = {}
+    for tag, env in (("short", {}), ("literal", {"MOTIFS_DF_LITERAL": "1"})):
+        path = str(tmp_path / (tag + ".npz"))
+        e = dict(os.environ)
+        e.pop("MOTIFS_DF_LITERAL", None)
+        e.update(env)
+        subprocess.run([sys.executable, os.path.join(HERE, "_df_literal_helper.py"), path], check=True, env=e, timeout=300)
+        outs[tag] = np.load(path)
+    assert abs(outs["short"]["loss"][0] - outs["literal"]["loss"][0]) <= 1e-6 * abs(outs["literal"]["loss"][0])
+    assert rel_inf(outs["short"]["flat"], outs["literal"]["flat"]) <= 1e-5
+
+
 def test_train_step_matches_adabelief_oracle(ctx, pkg):
     hp, codes, cdl_o = tiny(5, G=1)
     cdl = to_model(pkg, ctx, hp, codes.shape[1], cdl_o)
