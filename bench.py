@@ -273,6 +273,10 @@ def main():
             "loss_first_group": float(tloss[0].item()),
             "grad_allreduce_floats": int(cdl.model.nP) if world > 1 else 0,
             "reference_schedule_equivalent": f"{Gt * world} reference steps (batch 6) worth of reads per step",
+            "graph": ("the reference's graph with its common subexpressions formed once (the syntax-layer synthesis with an unchanged "
+                      "bank) and ADMM_DF's residuals telescoped (R_1 = 0, R_t = -theta_{t-2}; identical values, "
+                      "tests/test_model_gpu.py::test_df_telescoping_equals_literal_sequence); MOTIFS_DF_LITERAL=1 runs the literal "
+                      "sequence (+1.4 ms per step at this shape)"),
         }
         cdl.model.close()
 
