@@ -193,6 +193,30 @@ def test_cfg2_groups_are_independent(ctx, pkg):
     cdl.model.close()
 
 
+@pytest.mark.parametrize("passes", [(1, 1), (3, 4), (2, 5)])
+def test_tiny_other_pass_counts(ctx, pkg, passes):
+    """Pass counts other than the default: the dual-update folding of ADMM_XYZ and the telescoped residuals of ADMM_DF
+    (R_t = -theta_{t-2}) for one, four and five DF passes, against the oracle's literal sequence."""
+    px, pdf = passes
+    G, B = 2, 3
+    hp = mo.Hyperparam(filter_len=4, M=5, h=3, K=4, q=6, batch_size=B, num_pass_xyz=px, num_pass_df=pdf)
+    rng = np.random.default_rng(100 + 10 * px + pdf)
+    codes = rng.integers(0, 4, size=(G * B, 30)).astype(np.uint8)
+    cdl_o = mo.UCDL(hp, rng).to(torch.float64)
+    cdl = to_model(pkg, ctx, hp, codes.shape[1], cdl_o)
+    loss, flat = gpu_loss_grad(pkg, ctx, cdl, codes, G)
+    got = split_grad(cdl, flat)
+    want = {n: 0.0 for n in NAMES}
+    for g in range(G):
+        val, grads = mo.loss_and_grads(codes[g * B:(g + 1) * B], cdl_o, hp, torch.float64)
+        assert abs(loss[g] - val.item()) <= RTOL * abs(val.item()), (g, loss[g], val.item())
+        for n, gr in zip(NAMES, grads):
+            want[n] = want[n] + gr.numpy()
+    for n in NAMES:
+        assert rel_inf(got[n], want[n]) <= 5 * RTOL, (n, rel_inf(got[n], want[n]))
+    cdl.model.close()
+
+
 def test_df_telescoping_equals_literal_sequence(ctx, pkg, tmp_path):
     """ADMM_DF forms only the residuals / duals / syntheses that something consumes (R_1 = 0, R_t = -theta_{t-2}); the
     literal sequence of model.jl:362-373 (MOTIFS_DF_LITERAL=1, read once per process) gives the same loss and gradient."""
