@@ -1837,10 +1837,10 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ A, cons
 // rows at a time (rows to LDS with 16-byte accesses, the next 32 already in flight in registers); wave w owns the
 // 16-row blocks w, w+4, .. of q for all column blocks (v_mfma_f32_16x16x4_f32, the accumulators stay in registers
 // for the whole sequence).  Row strides of both LDS tiles are 16 mod 32 floats: conflict-free operand reads.
-template <int QW>
-__global__ __launch_bounds__(256) void k_rowwgrad_lds(const float* __restrict__ A, const float* __restrict__ C, float* __restrict__ part,
+template <int QW, int NW>
+__global__ __launch_bounds__(NW * 64) void k_rowwgrad_lds(const float* __restrict__ A, const float* __restrict__ C, float* __restrict__ part,
                                                       int R, int Q, int N, int ST, int SN) {
-    constexpr int NT = 3, NVA = 15, NVC = 2;       // 16-byte loads per thread: 32 x Q (Q <= 480) of A, 32 x N (N <= 64) of C
+    constexpr int NT = 3, TH = NW * 64, NVA = (32 * 120 + TH - 1) / TH, NVC = (32 * 16 + TH - 1) / TH;   // 16-byte loads per thread: 32 x Q (Q <= 480) of A, 32 x N (N <= 64) of C
     extern __shared__ float lds[];                 // A tile [32][ST], C tile [32][SN]
     float* Cs = lds + 32 * ST;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1852,29 +1852,29 @@ __global__ __launch_bounds__(256) void k_rowwgrad_lds(const float* __restrict__ 
         const int na = min(32, R - r0) * Q4, nc = min(32, R - r0) * N4;
 #pragma unroll
         for (int i = 0; i < NVA; i++) {
-            const int idx = tid + i * 256;
+            const int idx = tid + i * TH;
             const float4 x = Ag[(size_t)r0 * Q4 + (idx < na ? idx : 0)];
             va[i] = idx < na ? x : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int i = 0; i < NVC; i++) {
-            const int idx = tid + i * 256;
+            const int idx = tid + i * TH;
             const float4 x = Cg[(size_t)r0 * N4 + (idx < nc ? idx : 0)];
             vc[i] = idx < nc ? x : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     auto lstore = [&]() {
         int row = tid / Q4, c4 = tid - row * Q4;
-        const int drow = 256 / Q4, dc = 256 - drow * Q4;
+        const int drow = TH / Q4, dc = TH - drow * Q4;
 #pragma unroll
         for (int i = 0; i < NVA; i++) {
-            if (tid + i * 256 < 32 * Q4) *(float4*)(lds + row * ST + c4 * 4) = va[i];
+            if (tid + i * TH < 32 * Q4) *(float4*)(lds + row * ST + c4 * 4) = va[i];
             row += drow, c4 += dc;
             if (c4 >= Q4) c4 -= Q4, row++;
         }
 #pragma unroll
         for (int i = 0; i < NVC; i++) {
-            const int idx = tid + i * 256;
+            const int idx = tid + i * TH;
             if (idx < 32 * N4) {
                 const int r = idx / N4, c = idx - r * N4;
                 *(float4*)(Cs + r * SN + c * 4) = vc[i];
@@ -1887,7 +1887,7 @@ __global__ __launch_bounds__(256) void k_rowwgrad_lds(const float* __restrict__ 
 #pragma unroll
         for (int cb = 0; cb < NT; cb++) accv[i][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
     // columns N .. 16 NT - 1 of the C tile stay zero
-    for (int i = tid; i < 32 * SN; i += 256) Cs[i] = 0.0f;
+    for (int i = tid; i < 32 * SN; i += TH) Cs[i] = 0.0f;
     const float* ap = lds + (lane >> 4) * ST + (lane & 15) + wave * 16;     // A'[q][r] = tile[r][q]
     const float* cp = Cs + (lane >> 4) * SN + (lane & 15);
     gload(0);
@@ -1903,8 +1903,8 @@ __global__ __launch_bounds__(256) void k_rowwgrad_lds(const float* __restrict__ 
             for (int cb = 0; cb < NT; cb++) bv[cb] = cp[ks * 4 * SN + cb * 16];
 #pragma unroll
             for (int i = 0; i < QW; i++) {
-                if (wave + 4 * i < QB) {
-                    const float av = ap[ks * 4 * ST + i * 64];
+                if (wave + NW * i < QB) {
+                    const float av = ap[ks * 4 * ST + i * (16 * NW)];
 #pragma unroll
                     for (int cb = 0; cb < NT; cb++) accv[i][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[cb], accv[i][cb], 0, 0, 0);
                 }
@@ -1914,13 +1914,13 @@ __global__ __launch_bounds__(256) void k_rowwgrad_lds(const float* __restrict__ 
     float* out = part + (size_t)s * Q * N;
 #pragma unroll
     for (int i = 0; i < QW; i++) {
-        if (wave + 4 * i < QB) {
+        if (wave + NW * i < QB) {
 #pragma unroll
             for (int cb = 0; cb < NT; cb++) {
                 const int n = cb * 16 + (lane & 15);
                 if (n < N) {
 #pragma unroll
-                    for (int r = 0; r < 4; r++) out[(size_t)((wave + 4 * i) * 16 + 4 * (lane >> 4) + r) * N + n] = accv[i][cb][r];
+                    for (int r = 0; r < 4; r++) out[(size_t)((wave + NW * i) * 16 + 4 * (lane >> 4) + r) * N + n] = accv[i][cb][r];
                 }
             }
         }
@@ -1934,13 +1934,15 @@ static bool launch_rowwgrad_lds(Engine& e, const float* A, const float* C, float
     auto pad16 = [](int x) { return x + ((16 - x % 32) + 32) % 32; };     // smallest stride >= x that is 16 mod 32
     const int ST = pad16(rg.Q), SN = pad16(48);
     const size_t lds = (size_t)32 * (ST + SN) * 4;
-    const int QB = rg.Q / 16, QW = (QB + 3) / 4;
+    const int QB = rg.Q / 16;
     if (lds > 64 * 1024) return false;
-#define ROWWGRAD(QWV) hipLaunchKernelGGL((k_rowwgrad_lds<QWV>), dim3(rg.S), dim3(256), lds, e.st, A, C, part, rg.P, rg.Q, rg.N, ST, SN)
-    if (QW <= 4) ROWWGRAD(4);
-    else if (QW <= 6) ROWWGRAD(6);
-    else if (QW == 7) ROWWGRAD(7);
-    else ROWWGRAD(8);
+    // 8 waves per block (each owns every 8th block of 16 rows of q): a read is walked twice as fast as by 4, and reads are
+    // few (54 -> 48 us; 16 waves: 53 us)
+    const int QW = (QB + 7) / 8;
+#define ROWWGRAD(QWV) hipLaunchKernelGGL((k_rowwgrad_lds<QWV, 8>), dim3(rg.S), dim3(512), lds, e.st, A, C, part, rg.P, rg.Q, rg.N, ST, SN)
+    if (QW <= 2) ROWWGRAD(2);
+    else if (QW == 3) ROWWGRAD(3);
+    else ROWWGRAD(4);
 #undef ROWWGRAD
     return true;
 }
