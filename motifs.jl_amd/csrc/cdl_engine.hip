@@ -1592,7 +1592,23 @@ __global__ __launch_bounds__(256) void k_toep_wide(const float* __restrict__ A, 
     const int s = blockIdx.x / tps, p0 = (blockIdx.x - s * tps) * 32;
     const float* sig = A + (size_t)s * gm.lda;
     float a[4 * KG];
-    {
+    // the block's windows overlap: their span (31 sa + Q floats) goes through LDS once, coalesced, instead of one
+    // strided 4-byte gather per operand and wave
+    const int span = 31 * gm.sa + 8 * KG;
+    if (span <= 32 * SO) {
+        const int e0 = gm.a0 + p0 * gm.sa;
+        for (int i = tid; i < span; i += 256) {
+            const int e = e0 + i;
+            const bool ok = e >= 0 && e < gm.amax;
+            const float x = sig[ok ? e : 0];
+            lds[i] = ok ? x : 0.0f;
+        }
+        __syncthreads();
+        const float* w = lds + (lane & 31) * gm.sa + (lane >> 5);
+#pragma unroll
+        for (int ks = 0; ks < 4 * KG; ks++) a[ks] = w[2 * ks];
+        __syncthreads();                           // the tile stores below reuse the space
+    } else {
         const int base = gm.a0 + (p0 + (lane & 31)) * gm.sa + (lane >> 5);
 #pragma unroll
         for (int ks = 0; ks < 4 * KG; ks++) {
