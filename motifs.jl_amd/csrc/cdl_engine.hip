@@ -2118,7 +2118,15 @@ __global__ void k_sum_groups(const float* x, size_t per, int G, float* y) {
     const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= per) return;
     double acc = 0;
-    for (int g = 0; g < G; g++) acc += x[(size_t)g * per + j];
+    int g = 0;
+    for (; g + 16 <= G; g += 16) {                   // sixteen loads in flight, added in group order
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) v[u] = x[(size_t)(g + u) * per + j];
+#pragma unroll
+        for (int u = 0; u < 16; u++) acc += v[u];
+    }
+    for (; g < G; g++) acc += x[(size_t)g * per + j];
     y[j] += (float)acc;
 }
 
