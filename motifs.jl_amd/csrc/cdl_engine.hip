@@ -2131,14 +2131,29 @@ __global__ void k_sum_groups(const float* x, size_t per, int G, float* y) {
 }
 
 // per group [H][W][N] -> out[i'][n][j] = in[H-1-i'][j][n]
-__global__ void k_flipT(const float* x, int g, int H, int W, int N, float* out, int acc) {
-    const size_t per = (size_t)H * W * N, total = per * g;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const size_t gg = i / per, r = i % per;      // r indexes the OUTPUT [H][N][W]
-        const int j = (int)(r % W), n = (int)((r / W) % N), ip = (int)(r / ((size_t)W * N));
-        const float v = x[gg * per + ((size_t)(H - 1 - ip) * W + j) * N + n];
-        out[i] = acc ? out[i] + v : v;
+// out[g][ip][n][j] (+)= x[g][H-1-ip][j][n]: the rows of a bank reversed and each [W][N] slice transposed, through a
+// 64 x 64 LDS tile so that both sides move in contiguous runs.
+__global__ __launch_bounds__(256) void k_flipT(const float* __restrict__ x, int H, int W, int N, float* __restrict__ out, int acc) {
+    __shared__ float tile[64][65];
+    const int tn = (N + 63) / 64;
+    const int j0 = (blockIdx.x / tn) * 64, n0 = (blockIdx.x % tn) * 64, ip = blockIdx.y;
+    const size_t per = (size_t)H * W * N;
+    const float* xs = x + (size_t)blockIdx.z * per + (size_t)(H - 1 - ip) * W * N;
+    float* os = out + (size_t)blockIdx.z * per + (size_t)ip * N * W;
+    const int nj = min(64, W - j0), nn = min(64, N - n0);
+    for (int i = threadIdx.x; i < nj * nn; i += 256) {
+        const int jj = i / nn, n = i - jj * nn;
+        tile[jj][n] = xs[(size_t)(j0 + jj) * N + n0 + n];
     }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nj * nn; i += 256) {
+        const int n = i / nj, jj = i - n * nj;
+        float* o = &os[(size_t)(n0 + n) * W + j0 + jj];
+        *o = acc ? *o + tile[jj][n] : tile[jj][n];
+    }
+}
+static void launch_flipT(hipStream_t st, const float* x, int g, int H, int W, int N, float* out, int acc) {
+    hipLaunchKernelGGL(k_flipT, dim3(((W + 63) / 64) * ((N + 63) / 64), H, g), dim3(256), 0, st, x, H, W, N, out, acc);
 }
 
 // dA[s][e] += sum_{p,q: a0 + p*sa + q = e} sum_n dC[s][p][n] * Bm[g][q][n]  (adjoint of the Toeplitz
@@ -2151,7 +2166,7 @@ static bool toep_adjoint_a(Engine& e, const float* dC, const float* Bm, float* d
     bool fresh;
     float* tmp = e.relayout(Bm, 5, per * gB, fresh);
     if (!tmp) return false;
-    if (fresh) hipLaunchKernelGGL(k_flipT, dim3(nblocks(per * gB)), dim3(256), 0, e.st, Bm, gB, H, W, gm.N, tmp, 0);
+    if (fresh) launch_flipT(e.st, Bm, gB, H, W, gm.N, tmp, 0);
     ToepGeom g2;
     g2.S = gm.S;
     g2.P = gm.amax / W;
@@ -2340,13 +2355,13 @@ Tensor Engine::swap02(Tensor x, int g, int d0, int d1, int d2) {
 Tensor Engine::flipT(Tensor Bm, int g, int H, int W, int N) {
     Tensor out = make(Bm->n, Bm->needs_grad);
     if (failed) return out;
-    EW(k_flipT, Bm->n, Bm->v, g, H, W, N, out->v, 0);
+    launch_flipT(st, Bm->v, g, H, W, N, out->v, 0);
     if (recording && out->needs_grad)
         tape.push_back([this, out, Bm, g, H, W, N]() {
             // adjoint: dIn[i][j][n] += dOut[H-1-i][n][j]  == flipT with the roles of W and N exchanged
             int acc;
             float* dx = out->g ? grad_first(Bm, acc) : nullptr;
-            if (dx) EW(k_flipT, Bm->n, out->g, g, H, N, W, dx, acc);
+            if (dx) launch_flipT(st, out->g, g, H, N, W, dx, acc);
         });
     return out;
 }
@@ -2760,7 +2775,7 @@ Tensor Engine::wgrad_sp(Tensor img, Tensor T, const SpDims& d) {
                     failed = failed || !tmp;
                     return;
                 }
-                hipLaunchKernelGGL(k_flipT, dim3(nblocks(per * G)), dim3(256), 0, st, out->g, G, d.h, d.W, d.K, tmp, 0);
+                launch_flipT(st, out->g, G, d.h, d.W, d.K, tmp, 0);
                 launch_sp_syn(st, nz, tmp, di, dg, a);
             }
             if (T->needs_grad) {
