@@ -2318,17 +2318,19 @@ __global__ __launch_bounds__(256) void k_swap02_tiled(const float* __restrict__ 
     const float* xs = x + (size_t)gg * per;
     float* os = out + (size_t)gg * per;
     const int run_in = nj * d2, p2 = d2 + 1;
-    for (int i = threadIdx.x; i < d0 * run_in; i += 256) {       // x[i0][j0 + jj][i2], contiguous in (jj, i2)
-        const int i0 = i / run_in, r = i - i0 * run_in, jj = r / d2, i2 = r - jj * d2;
-        tile[(i0 * SWAP_T1 + jj) * p2 + i2] = xs[((size_t)i0 * d1 + j0) * d2 + r];
+    for (int r = threadIdx.x; r < run_in; r += 256) {            // x[i0][j0 + jj][i2], contiguous in (jj, i2): one division per thread
+        const int jj = r / d2, i2 = r - jj * d2;
+        for (int i0 = 0; i0 < d0; i0++) tile[(i0 * SWAP_T1 + jj) * p2 + i2] = xs[((size_t)i0 * d1 + j0) * d2 + r];
     }
     __syncthreads();
     const int run_out = nj * d0;
-    for (int i = threadIdx.x; i < d2 * run_out; i += 256) {      // out[i2][j0 + jj][i0], contiguous in (jj, i0)
-        const int i2 = i / run_out, r = i - i2 * run_out, jj = r / d0, i0 = r - jj * d0;
-        float* o = &os[((size_t)i2 * d1 + j0) * d0 + r];
-        const float v = tile[(i0 * SWAP_T1 + jj) * p2 + i2];
-        *o = acc ? *o + v : v;
+    for (int r = threadIdx.x; r < run_out; r += 256) {           // out[i2][j0 + jj][i0], contiguous in (jj, i0)
+        const int jj = r / d0, i0 = r - jj * d0;
+        for (int i2 = 0; i2 < d2; i2++) {
+            float* o = &os[((size_t)i2 * d1 + j0) * d0 + r];
+            const float v = tile[(i0 * SWAP_T1 + jj) * p2 + i2];
+            *o = acc ? *o + v : v;
+        }
     }
 }
 static void launch_swap02(hipStream_t st, const float* x, int g, int d0, int d1, int d2, float* out, int acc) {
