@@ -2378,28 +2378,31 @@ Tensor Engine::flipT(Tensor Bm, int g, int H, int W, int N) {
 // Non-zero list of a [S][n] tensor: one block per read, entries in memory order (deterministic sums).
 __global__ __launch_bounds__(256) void k_build_nz(const float* __restrict__ x, int n, int* __restrict__ cnt,
                                                   uint2* __restrict__ ent) {
+    // every wave owns a contiguous quarter of the read: count, meet once, then write in ascending order
     __shared__ int wcnt[4];
-    __shared__ int run_sh;
     const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const float* xs = x + (size_t)s * n;
     uint2* es = ent + (size_t)s * n;
-    if (tid == 0) run_sh = 0;
+    const int q = (((n + 3) / 4) + 63) & ~63, lo = wv * q, hi = min(n, lo + q);
+    int c = 0;
+    for (int e0 = lo; e0 < hi; e0 += 64) {
+        const int e = e0 + lane;
+        const float v = e < hi ? xs[e] : 0.0f;
+        c += __builtin_popcountll(__builtin_amdgcn_ballot_w64(v != 0.0f));
+    }
+    if (lane == 0) wcnt[wv] = c;
     __syncthreads();
-    for (int e0 = 0; e0 < n; e0 += 256) {
-        const int e = e0 + tid;
-        const float v = e < n ? xs[e] : 0.0f;
+    int base = 0;
+    for (int w = 0; w < wv; w++) base += wcnt[w];
+    for (int e0 = lo; e0 < hi; e0 += 64) {
+        const int e = e0 + lane;
+        const float v = e < hi ? xs[e] : 0.0f;
         const bool hit = v != 0.0f;
         const uint64_t m = __builtin_amdgcn_ballot_w64(hit);
-        if (lane == 0) wcnt[wv] = __builtin_popcountll(m);
-        __syncthreads();
-        int base = run_sh;
-        for (int w = 0; w < wv; w++) base += wcnt[w];
         if (hit) es[base + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = make_uint2((unsigned)e, __float_as_uint(v));
-        __syncthreads();
-        if (tid == 0) run_sh += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
-        __syncthreads();
+        base += __builtin_popcountll(m);
     }
-    if (tid == 0) cnt[s] = run_sh;
+    if (tid == 0) cnt[s] = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
 }
 
 // S1: out[s][r][j] (+)= sum_nz v * FAf[g][p - r + h - 1][k][j]      (block = (read, 128 columns), thread = column j)
