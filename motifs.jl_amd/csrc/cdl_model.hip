@@ -200,7 +200,10 @@ static Tensor forward_loss(motifs_model* m, Graph& gr, bool train) {
     admm_xyz(m, gr, sc, bD, bF, ZY, X, &FXfin);
 
     // ADMM_DF (:362-373)
-    Tensor ZYm = gr.cat_ZY(ZY);
+    // ZYm = cat_ZY(ZY) (:364) is never materialised: its consumers take ZY, the factor and the medians of the mini-batches
+    // and apply the mask in their own pass (the same products, -mag * ZY where ZY >= median)
+    const float* zmt = gr.zy_thr(ZY);
+    const float zmf = -m->hp.magnifying_factor;
     Tensor Dc = Dp, Fc = Fp, theta = nullptr;
     int gD = 1, gF = 1;
     Graph::Bank bDc = bD, bFc = bF;
@@ -227,11 +230,11 @@ static Tensor forward_loss(motifs_model* m, Graph& gr, bool train) {
         bDc = gr.bankD(Dc, gD);
         // update_F (:292-308)
         if (literal) {
-            Tensor R = e.lin3(FXcur, 1.0f, ZYm, -1.0f, theta, -1.0f);
+            Tensor R = e.lin3(FXcur, 1.0f, ZY, zmf, theta, -1.0f, zmt, G);
             Tensor Fgrad = e.swap02(e.wgrad_sp(R, X, gr.spd(G)), G, m->h, m->twoM, m->K);
             Fc = e.norml2(e.f_step(Fc, Fgrad, 1.0f, sc.kst[t], sc.ks[t], nbank), m->h * m->twoM);
         } else if (t == 0) {
-            Tensor R = e.lin3(FXcur, 1.0f, ZYm, -1.0f, nullptr, 0.0f);
+            Tensor R = e.lin3(FXcur, 1.0f, ZY, zmf, nullptr, 0.0f, zmt, G);
             Tensor Fgrad = e.swap02(e.wgrad_sp(R, X, gr.spd(G)), G, m->h, m->twoM, m->K);
             Fc = e.norml2(e.f_step(Fc, Fgrad, 1.0f, sc.kst[t], sc.ks[t], nbank), m->h * m->twoM);
         } else if (t == 1) {                                               // R_1 = 0: the gradient of F vanishes identically
@@ -246,7 +249,7 @@ static Tensor forward_loss(motifs_model* m, Graph& gr, bool train) {
         const bool need_theta = literal || t + 2 < P;
         if (need_theta || t == P - 1) FXcur = gr.synF(X, bFc);
         if (need_theta) {
-            theta = e.lin3(FXcur, 1.0f, ZYm, -1.0f, theta, 1.0f);
+            theta = e.lin3(FXcur, 1.0f, ZY, zmf, theta, 1.0f, zmt, G);
             thetas.push_back(theta);
         }
     }
@@ -255,7 +258,7 @@ static Tensor forward_loss(motifs_model* m, Graph& gr, bool train) {
     // loss (:310-325)
     const float nf = 1.0f / (float)m->B;
     Tensor r1 = e.lin(gr.synD(ZY, bDc), 1.0f, gr.Sone, -1.0f, 0.0f);
-    Tensor r2 = e.lin(FXcur, 1.0f, ZYm, -1.0f, 0.0f);
+    Tensor r2 = e.lin3(FXcur, 1.0f, ZY, zmf, nullptr, 0.0f, zmt, G);
     Tensor Lv = e.lin(e.sumsq_groups(r1, nf, G), 1.0f, e.sumsq_groups(r2, nf, G), 1.0f, 0.0f);
     (void)gD;
     (void)gF;
