@@ -135,6 +135,8 @@ struct Engine {
     Tensor norm4(Tensor x);                                               // x / sum over each 4 consecutive
     Tensor norml2(Tensor x, int seg);                                     // x / ||x|| per segment
     Tensor sumsq_groups(Tensor x, float coef, int groups);                // [groups]: coef * sum x^2 per group
+    // coef * sum_group (x + b*[y >= thr[group]]*y)^2 without writing the residual
+    Tensor resid_sumsq_groups(Tensor x, Tensor y, float b, const float* thr, float coef, int groups);
     Tensor toep(Tensor A, Tensor Bm, const ToepGeom& gm);                 // Toeplitz GEMM
     Tensor wgrad(Tensor A, Tensor C, const ToepGeom& gm);                 // [G][Q][N] = sum_{s,p} Aw * C
     // syntax layer with sparse codes (X keeps ~q entries per read; gradients into it are masked):

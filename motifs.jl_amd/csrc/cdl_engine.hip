@@ -269,6 +269,44 @@ __global__ void k_sumsq_groups_bwd(const float* gout, const float* x, size_t per
         dx[i] = (acc ? dx[i] : 0.0f) + coef2 * x[i] * gout[i / per_group];
 }
 
+// coef * sum over a group of (x + b*[y >= thr]*y)^2: the syntax-layer term of the loss (model.jl:321-323) without the
+// residual ever being written; the VJP recomputes it.
+__global__ void k_resid_sumsq(const float* x, const float* y, const float* thr, float b, size_t per_group, float coef, float* out) {
+    const int g = blockIdx.y;
+    const size_t base = (size_t)g * per_group;
+    const float t = thr[g];
+    double acc = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < per_group; i += (size_t)gridDim.x * blockDim.x) {
+        const float yv = y[base + i];
+        const float r = 1.0f * x[base + i] + b * (!(yv >= t) ? 0.0f : yv);
+        acc += (double)r * r;
+    }
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+    __shared__ double red[16];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0;
+        for (int i = 0; i < (int)(blockDim.x >> 6); i++) s += red[i];
+        atomicAdd(&out[g], (float)(coef * s));
+    }
+}
+__global__ void k_resid_sumsq_bwd(const float* gout, const float* x, const float* y, const float* thr, float b, size_t per_group, float coef2,
+                                  float* dx, int ax, float* dy, int ay) {
+    const int g = blockIdx.y;
+    const size_t base = (size_t)g * per_group;
+    const float t = thr[g], w = coef2 * gout[g];
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < per_group; j += (size_t)gridDim.x * blockDim.x) {
+        const size_t i = base + j;
+        const float yv = y[i];
+        const bool on = yv >= t;
+        const float r = 1.0f * x[i] + b * (on ? yv : 0.0f);
+        const float gr = w * r;
+        if (dx) dx[i] = (ax ? dx[i] : 0.0f) + gr;
+        if (dy) dy[i] = (ay ? dy[i] : 0.0f) + b * (on ? gr : 0.0f);
+    }
+}
+
 // a*x + b*y + c*z in one pass (z optional), one grid row per group of `per` elements.
 // ythr (optional): cat_ZY's median mask folded in as a threshold per group, y counts where y >= ythr[group]
 // (a constant in the backward, @ignore model.jl:208) - no 0/1 mask is ever written or read.
@@ -747,6 +785,25 @@ Tensor Engine::norml2(Tensor x, int seg) {
     if (recording && out->needs_grad)
         tape.push_back([this, out, x, nrm, seg, nseg]() {
             if (out->g) hipLaunchKernelGGL(k_norml2_bwd, dim3(nseg), dim3(256), 0, st, out->g, out->v, nrm->v, seg, grad(x));
+        });
+    return out;
+}
+
+Tensor Engine::resid_sumsq_groups(Tensor x, Tensor y, float b, const float* thr, float coef, int groups) {
+    Tensor out = make(groups, x->needs_grad || y->needs_grad);
+    if (failed) return out;
+    const size_t per = x->n / groups;
+    (void)hipMemsetAsync(out->v, 0, (size_t)groups * 4, st);
+    hipLaunchKernelGGL(k_resid_sumsq, dim3(nblocks(per, 256, 64), groups), dim3(256), 0, st, x->v, y->v, thr, b, per, coef, out->v);
+    if (recording && out->needs_grad)
+        tape.push_back([this, out, x, y, b, thr, per, coef, groups]() {
+            if (!out->g) return;
+            int ax = 1, ay = 1;
+            float* dx = x->needs_grad ? grad_first(x, ax) : nullptr;
+            float* dy = y->needs_grad ? grad_first(y, ay) : nullptr;
+            if (failed) return;
+            hipLaunchKernelGGL(k_resid_sumsq_bwd, dim3(nblocks(per, 256, 128), groups), dim3(256), 0, st, out->g, x->v, y->v, thr, b, per, 2.0f * coef,
+                               dx, ax, dy, ay);
         });
     return out;
 }

@@ -258,8 +258,7 @@ static Tensor forward_loss(motifs_model* m, Graph& gr, bool train) {
     // loss (:310-325)
     const float nf = 1.0f / (float)m->B;
     Tensor r1 = e.lin(gr.synD(ZY, bDc), 1.0f, gr.Sone, -1.0f, 0.0f);
-    Tensor r2 = e.lin3(FXcur, 1.0f, ZY, zmf, nullptr, 0.0f, zmt, G);
-    Tensor Lv = e.lin(e.sumsq_groups(r1, nf, G), 1.0f, e.sumsq_groups(r2, nf, G), 1.0f, 0.0f);
+    Tensor Lv = e.lin(e.sumsq_groups(r1, nf, G), 1.0f, e.resid_sumsq_groups(FXcur, ZY, zmf, zmt, nf, G), 1.0f, 0.0f);
     (void)gD;
     (void)gF;
     return Lv;
