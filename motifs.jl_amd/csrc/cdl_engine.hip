@@ -2462,6 +2462,10 @@ __global__ __launch_bounds__(256) void k_build_nz(const float* __restrict__ x, i
     if (tid == 0) cnt[s] = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
 }
 
+// floor(e / K) for the flat code indices e = p*K + k (e < 2^32 / K): one multiply-high instead of a division.  The entry
+// lists are wave-uniform, so the division ran on the scalar unit - one per CU - and the sparse kernels were bound by
+// it (PMC: 5.4 scalar instructions per vector one in k_sp_wgrad_ana).
+static __device__ __forceinline__ uint32_t kmagic(int K) { return 0xFFFFFFFFu / (uint32_t)K + 1u; }
 // S1: out[s][r][j] (+)= sum_nz v * FAf[g][p - r + h - 1][k][j]      (block = (read, 128 columns), thread = column j)
 // any filter height: read-modify-write of the output rows in memory
 __global__ __launch_bounds__(128) void k_sp_syn_any(NzView nz, const float* __restrict__ FAf, float* __restrict__ out,
@@ -2476,7 +2480,7 @@ __global__ __launch_bounds__(128) void k_sp_syn_any(NzView nz, const float* __re
     const uint2* es = nz.ent + (size_t)s * nz.cap;
     for (int z = 0; z < cnt; z++) {
         const uint2 en = es[z];
-        const int p = (int)(en.x / (unsigned)d.K), k = (int)(en.x - (unsigned)p * d.K);
+        const int p = (int)__umulhi(en.x, kmagic(d.K)), k = (int)(en.x - (unsigned)p * d.K);
         const float v = __uint_as_float(en.y);
         for (int ip = 0; ip < d.h; ip++) {
             const int r = p + d.h - 1 - ip;
@@ -2509,7 +2513,7 @@ __global__ __launch_bounds__(128) void k_sp_syn(NzView nz, const float* __restri
         float v = 0.0f;
         if (z < cnt) {
             const uint2 en = es[z];
-            p = (int)(en.x / (unsigned)d.K);
+            p = (int)__umulhi(en.x, kmagic(d.K));
             k = (int)(en.x - (unsigned)p * d.K);
             v = __uint_as_float(en.y);
         }
@@ -2554,7 +2558,7 @@ __global__ __launch_bounds__(128) void k_sp_wgrad_syn(NzView nz, const float* __
         const uint2* es = nz.ent + (size_t)s * nz.cap;
         for (int z = 0; z < cnt; z++) {                  // block-uniform
             const uint2 en = es[z];
-            const int p = (int)(en.x / (unsigned)d.K), k = (int)(en.x - (unsigned)p * d.K);
+            const int p = (int)__umulhi(en.x, kmagic(d.K)), k = (int)(en.x - (unsigned)p * d.K);
             accs[k * 128 + tx] = fmaf(__uint_as_float(en.y), ds[(size_t)p * d.W], accs[k * 128 + tx]);
         }
     }
@@ -2581,7 +2585,7 @@ __global__ __launch_bounds__(128) void k_sp_wgrad_ana(const float* __restrict__ 
         const uint2* es = nz.ent + (size_t)s * nz.cap;
         for (int z = 0; z < cnt; z++) {
             const uint2 en = es[z];
-            const int p = (int)(en.x / (unsigned)d.K), k = (int)(en.x - (unsigned)p * d.K);
+            const int p = (int)__umulhi(en.x, kmagic(d.K)), k = (int)(en.x - (unsigned)p * d.K);
             my[k] = fmaf(__uint_as_float(en.y), is[(size_t)p * d.W], my[k]);
         }
     }
@@ -2600,7 +2604,7 @@ __global__ __launch_bounds__(256) void k_sp_ana_masked(const float* __restrict__
     const float* is = img + (size_t)s * d.c * d.W;
     for (int z = blockIdx.x * 4 + (threadIdx.x >> 6); z < cnt; z += gridDim.x * 4) {   // wave-uniform
         const uint2 en = nz.ent[(size_t)s * nz.cap + z];
-        const int p = (int)(en.x / (unsigned)d.K), k = (int)(en.x - (unsigned)p * d.K);
+        const int p = (int)__umulhi(en.x, kmagic(d.K)), k = (int)(en.x - (unsigned)p * d.K);
         const float* fk = Fk + (size_t)(s / d.B) * d.ldf + (size_t)k * d.W * d.h;
         float a = 0.0f;
         if (d.h == 12 && (((uintptr_t)fk) & 15) == 0) {      // the lane's 12 filter taps as three 16-byte loads
@@ -2692,7 +2696,7 @@ __global__ __launch_bounds__(256) void k_sp_syn_rows(NzView nz, const float* __r
     if (cached) {
         for (int i = tid; i < ne; i += 256) {
             const uint2 en = es[zb + i];
-            const int p = (int)(en.x / (unsigned)d.K);
+            const int p = (int)__umulhi(en.x, kmagic(d.K));
             ep[i] = p, ek[i] = (int)(en.x - (unsigned)p * d.K), ev[i] = __uint_as_float(en.y);
         }
     }
@@ -2712,7 +2716,7 @@ __global__ __launch_bounds__(256) void k_sp_syn_rows(NzView nz, const float* __r
                 p = ep[z - zb], k = ek[z - zb], v = ev[z - zb];
             } else {
                 const uint2 en = es[z];
-                p = (int)(en.x / (unsigned)d.K), k = (int)(en.x - (unsigned)p * d.K), v = __uint_as_float(en.y);
+                p = (int)__umulhi(en.x, kmagic(d.K)), k = (int)(en.x - (unsigned)p * d.K), v = __uint_as_float(en.y);
             }
             const float4 f = F4[((size_t)(d.h - 1 - (r - p)) * d.K + k) * W4 + c4];
             a.x = fmaf(v, f.x, a.x), a.y = fmaf(v, f.y, a.y), a.z = fmaf(v, f.z, a.z), a.w = fmaf(v, f.w, a.w);
