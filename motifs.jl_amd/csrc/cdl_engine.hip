@@ -2589,9 +2589,14 @@ __global__ __launch_bounds__(128) void k_sp_wgrad_ana(const float* __restrict__ 
             my[k] = fmaf(__uint_as_float(en.y), is[(size_t)p * d.W], my[k]);
         }
     }
-    if (j < d.W) {
-        float* row = dB + (size_t)g * d.h * d.W * d.K + ((size_t)i * d.W + j) * d.K;
-        for (int k = 0; k < d.K; k++) row[k] = acc ? row[k] + my[k] : my[k];
+    // the block's outputs [128 columns][K] are one contiguous span: written by all threads in address order
+    __syncthreads();
+    const int j0 = blockIdx.x * 128, nj = min(128, d.W - j0);
+    float* span = dB + (size_t)g * d.h * d.W * d.K + ((size_t)i * d.W + j0) * d.K;
+    for (int idx = threadIdx.x; idx < nj * d.K; idx += 128) {
+        const int jj = idx / d.K, k = idx - jj * d.K;
+        const float v = accs[jj * (d.K + 1) + k];
+        span[idx] = acc ? span[idx] + v : v;
     }
 }
 
