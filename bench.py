@@ -110,9 +110,9 @@ def main():
             pending[i].wait()
             pending[i] = None
         counts = counts_ring[i]
-        for rc in (0, 1):
-            tot += ctx.pwm_scan_hits_dev(bank, lens, dcodes.data_ptr(), N, L, rc, hits[rc].data_ptr(), hsc[rc].data_ptr(),
-                                         cap, n0=rank * N, counts_ptr=counts[rc].data_ptr())
+        # gpu_scan (_h3_1_alignment.jl:89-99): forward and reverse strand in one call, one host wait
+        tot += sum(ctx.pwm_scan_hits_both_dev(bank, lens, dcodes.data_ptr(), N, L, [hits[0].data_ptr(), hits[1].data_ptr()],
+                                              [hsc[0].data_ptr(), hsc[1].data_ptr()], cap, n0=rank * N, counts_ptr=counts.data_ptr()))
         if world > 1:  # the one real exchange of the scan: the K int64 hit counts of both strands
             pending[i] = dist.all_reduce(counts, async_op=True)
         return tot

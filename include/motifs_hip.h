@@ -146,6 +146,15 @@ int motifs_pwm_scan_hits_dev(motifs_ctx* ctx, const uint16_t* pwms_fp16, const i
                              int64_t n0, int batch, motifs_hit* hits_dev, uint16_t* hit_scores_dev,
                              int64_t cap, int64_t* n_out, int64_t* per_pwm_counts_dev);
 
+/* gpu_scan (src/inference/_h3_1_alignment.jl:89-99): both strands of one shard in one call.  Same arguments as
+ * motifs_pwm_scan_hits_dev, with one record buffer pair per strand (forward, reverse: `cap` records each), n_out2 =
+ * host int64[2] (forward, reverse totals) and per_pwm_counts2_dev = optional 2*K int64 on device ([forward K][reverse K]).
+ * The reverse-strand kernels are enqueued behind the forward ones; the host waits once. */
+int motifs_pwm_scan_hits_both_dev(motifs_ctx* ctx, const uint16_t* pwms_fp16, const int64_t* lens, int K, int maxlen,
+                                  const uint8_t* codes_dev, int64_t N, int L, int64_t n0, int batch,
+                                  motifs_hit* hits_fwd_dev, uint16_t* scores_fwd_dev, motifs_hit* hits_rc_dev,
+                                  uint16_t* scores_rc_dev, int64_t cap, int64_t* n_out2, int64_t* per_pwm_counts2_dev);
+
 /* Host-buffer form of the same call: what Julia's `ccall` binds.  `data` is a
  * host matrix of `kind`; hits / hit_scores / per_pwm_counts are host buffers.
  * hits == NULL or cap too small: returns MOTIFS_ERR_BUFFER_TOO_SMALL (or

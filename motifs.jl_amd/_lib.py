@@ -63,6 +63,10 @@ SIGNATURES = {
         _int,
         [_p, _p, _p, _int, _int, _p, _i64, _int, _int, _i64, _int, _p, _p, _i64, C.POINTER(_i64), _p],
     ),
+    "motifs_pwm_scan_hits_both_dev": (
+        _int,
+        [_p, _p, _p, _int, _int, _p, _i64, _int, _i64, _int, _p, _p, _p, _p, _i64, C.POINTER(_i64), _p],
+    ),
     "motifs_model_create": (_int, [_p, C.POINTER(HParams), _int, C.c_size_t, C.POINTER(_p)]),
     "motifs_model_destroy": (None, [_p]),
     "motifs_model_sizes": (_int, [_p] + [C.POINTER(_i64)] * 5),
@@ -206,6 +210,18 @@ class Context:
             return n_out.value
         check(code)
         return n_out.value
+
+    def pwm_scan_hits_both_dev(self, pwms, lens, codes_ptr, N, L, hits_ptrs, scores_ptrs, cap, n0=0, batch=SCAN_BATCH, counts_ptr=None):
+        """gpu_scan: both strands in one call (one host wait).  hits_ptrs / scores_ptrs: (forward, reverse) device pointers
+        (None, None with cap == 0: count only); counts_ptr: optional 2*K int64 on device.  Returns (n_forward, n_reverse)."""
+        pwms, lens, K, maxlen = _bank(pwms, lens)
+        n_out = (_i64 * 2)(0, 0)
+        hp = hits_ptrs if hits_ptrs is not None else (None, None)
+        sp = scores_ptrs if scores_ptrs is not None else (None, None)
+        check(lib().motifs_pwm_scan_hits_both_dev(
+            self._h, _np_ptr(pwms), _np_ptr(lens), K, maxlen, _p(codes_ptr), int(N), int(L), int(n0), int(batch),
+            _p(hp[0]), _p(sp[0]), _p(hp[1]), _p(sp[1]), int(cap), n_out, _p(counts_ptr)))
+        return int(n_out[0]), int(n_out[1])
 
     # ---- consumers of the hit records (SURVEY §8f) ----
     def hits_minmax_dev(self, hits_ptr, scores_ptr, n, K, min_ptr, max_ptr):

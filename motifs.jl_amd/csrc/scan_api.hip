@@ -322,7 +322,9 @@ static void scan_args(motifs_ctx* c, const BankSlot& bank, int K, const uint8_t*
 // row counts (stage_hits) -> scan -> records (emit_records); no host round trip in between.  The bank has already been uploaded (tab, lim).
 static int scan_hits_mfma(motifs_ctx* c, const BankSlot& bank, int K, const uint8_t* codes_dev, int64_t N, int L, int Lout, int64_t n0,
                           int batch, motifs_hit* hits_dev, uint16_t* hit_scores_dev, int64_t cap, int64_t* n_out,
-                          int64_t* per_pwm_counts_dev) {
+                          int64_t* per_pwm_counts_dev, int slot = 0, bool finish = true) {
+    // slot: which pair of running totals in c->small this strand uses; finish = false: everything is enqueued, the
+    // total stays on the device at totals_of(slot) and the caller reads it after its own synchronisation
     const bool emit = hits_dev != nullptr && cap > 0;
     const int rpr = stage_row_reads(bank.nch);                       // reads per row of cells
     const int parts = (batch + rpr - 1) / rpr;
@@ -340,9 +342,9 @@ static int scan_hits_mfma(motifs_ctx* c, const BankSlot& bank, int K, const uint
     if (emit) MOTIFS_HIP_CHECK(c->staging.reserve((size_t)nb_max * stage_per_batch));
     MOTIFS_HIP_CHECK(c->small.reserve(64));
     // small: [0], [1] record totals (ping-pong between super-batches)
-    int64_t* totals = (int64_t*)c->small.p;
-    MOTIFS_HIP_CHECK(hipMemsetAsync(c->small.p, 0, 64, c->stream));
-    int64_t* h_total = (int64_t*)c->pinned;
+    int64_t* totals = (int64_t*)c->small.p + 2 * slot;
+    MOTIFS_HIP_CHECK(hipMemsetAsync(totals, 0, 16, c->stream));
+    int64_t* h_total = (int64_t*)c->pinned + slot;
 
     int launch_no = 0;
     for (int64_t s0 = 0; s0 < N; s0 += sb, launch_no++) {
@@ -382,6 +384,7 @@ static int scan_hits_mfma(motifs_ctx* c, const BankSlot& bank, int K, const uint
     }
     // records are written up to cap in any case; the total says whether they all fitted
     MOTIFS_HIP_CHECK(hipMemcpyAsync(h_total, totals + (launch_no & 1), 8, hipMemcpyDeviceToHost, c->stream));
+    if (!finish) return MOTIFS_OK;
     MOTIFS_HIP_CHECK(hipStreamSynchronize(c->stream));
     const int64_t emitted = *h_total;
     const bool too_small = emitted > cap;
@@ -720,6 +723,57 @@ int motifs_pwm_scan_hits_dev(motifs_ctx* c, const uint16_t* pwms_fp16, const int
     if (too_small && !(cap == 0 && hits_dev == nullptr)) {
         set_error("hit buffer too small: need %lld records, cap %lld", (long long)emitted, (long long)cap);
         return MOTIFS_ERR_BUFFER_TOO_SMALL;
+    }
+    return MOTIFS_OK;
+}
+
+// gpu_scan (_h3_1_alignment.jl:89-99): both strands of one shard in one call - the reverse-strand kernels are enqueued
+// behind the forward ones and the host waits once.
+int motifs_pwm_scan_hits_both_dev(motifs_ctx* c, const uint16_t* pwms_fp16, const int64_t* lens, int K, int maxlen,
+                                  const uint8_t* codes_dev, int64_t N, int L, int64_t n0, int batch, motifs_hit* hits_fwd_dev,
+                                  uint16_t* scores_fwd_dev, motifs_hit* hits_rc_dev, uint16_t* scores_rc_dev, int64_t cap,
+                                  int64_t* n_out2, int64_t* per_pwm_counts2_dev) {
+    if (!c || !n_out2) {
+        set_error("motifs_pwm_scan_hits_both_dev: bad argument");
+        return MOTIFS_ERR_INVALID;
+    }
+    motifs_hit* hits[2] = {hits_fwd_dev, hits_rc_dev};
+    uint16_t* scores[2] = {scores_fwd_dev, scores_rc_dev};
+    n_out2[0] = n_out2[1] = 0;
+    const bool fast = !c->scan_valu && N > 0 && L > 0 && batch > 0 && cap >= 0 && codes_dev && n0 >= 0 && n0 + N <= 0xffffffffll &&
+                      (cap == 0 || (hits[0] && hits[1] && scores[0] && scores[1]));
+    BankSlot* bs[2] = {nullptr, nullptr};
+    if (fast) {
+        for (int rc = 0; rc < 2; rc++) {
+            const int rcode = cached_bank(c, pwms_fp16, lens, K, maxlen, rc, L, &bs[rc]);
+            if (rcode) return rcode;
+        }
+    }
+    if (!fast || L - bs[0]->minlen + 1 <= 0) {     // anything unusual: the single-strand entry, twice
+        for (int rc = 0; rc < 2; rc++) {
+            const int rcode = motifs_pwm_scan_hits_dev(c, pwms_fp16, lens, K, maxlen, codes_dev, N, L, rc, n0, batch, hits[rc], scores[rc], cap,
+                                                       &n_out2[rc], per_pwm_counts2_dev ? per_pwm_counts2_dev + (size_t)rc * K : nullptr);
+            if (rcode) return rcode;
+        }
+        return MOTIFS_OK;
+    }
+    MOTIFS_HIP_CHECK(hipSetDevice(c->device));
+    if (per_pwm_counts2_dev) MOTIFS_HIP_CHECK(hipMemsetAsync(per_pwm_counts2_dev, 0, (size_t)2 * K * 8, c->stream));
+    for (int rc = 0; rc < 2; rc++) {
+        const int Lout = L - bs[rc]->minlen + 1;
+        int64_t dummy = 0;
+        const int rcode = scan_hits_mfma(c, *bs[rc], K, codes_dev, N, L, Lout, n0, batch, hits[rc], scores[rc], cap, &dummy,
+                                         per_pwm_counts2_dev ? per_pwm_counts2_dev + (size_t)rc * K : nullptr, rc, false);
+        if (rcode) return rcode;
+    }
+    MOTIFS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    const int64_t* h_total = (const int64_t*)c->pinned;
+    for (int rc = 0; rc < 2; rc++) {
+        n_out2[rc] = h_total[rc];
+        if (h_total[rc] > cap && !(cap == 0 && hits[rc] == nullptr)) {
+            set_error("hit buffer too small: strand %d needs %lld records, cap %lld", rc, (long long)h_total[rc], (long long)cap);
+            return MOTIFS_ERR_BUFFER_TOO_SMALL;
+        }
     }
     return MOTIFS_OK;
 }

@@ -86,6 +86,40 @@ def test_hits_match_oracle(torch_cuda, ctx, pkg, N, L, K, lo, hi, batch, alpha, 
     assert np.array_equal(counts, np.bincount(oh[:, 0] - 1, minlength=K))
 
 
+@pytest.mark.parametrize("N,L,K,batch", [(37, 61, 24, 16), (300, 100, 200, 64), (5, 30, 8, 5000)])
+def test_both_strands_entry_equals_two_calls(torch_cuda, ctx, pkg, N, L, K, batch):
+    """gpu_scan in one call (motifs_pwm_scan_hits_both_dev): the same records, scores and histograms as the forward and the
+    reverse scan one after the other, and as the oracle."""
+    torch = torch_cuda
+    lib, sy = pkg._lib, pkg.synth
+    codes = sy.gen_codes(N, L, 300 + N + K, n_plant=2, k=min(8, L))
+    pwms, lens = sy.gen_pwm_bank(K, 400 + K, len_lo=6, len_hi=12, alpha=0.3)
+    bank = sy.pad_bank(pwms, lens)
+    raw = torch.from_numpy(np.ascontiguousarray(codes)).cuda()
+    dcodes = torch.zeros(lib.Context.codes_bytes(N, L), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    ctx.encode_dev(raw.data_ptr(), lib.DATA_CODES_U8, N, L, dcodes.data_ptr())
+    need = ctx.pwm_scan_hits_both_dev(bank, lens, dcodes.data_ptr(), N, L, None, None, 0, n0=3, batch=batch)
+    cap = max(max(need), 1)
+    hits = [torch.zeros((cap, 3), dtype=torch.int32, device="cuda") for _ in range(2)]
+    sc = [torch.zeros(cap, dtype=torch.int16, device="cuda") for _ in range(2)]
+    counts = torch.zeros((2, K), dtype=torch.int64, device="cuda")
+    got = ctx.pwm_scan_hits_both_dev(bank, lens, dcodes.data_ptr(), N, L, [h.data_ptr() for h in hits], [x.data_ptr() for x in sc], cap,
+                                     n0=3, batch=batch, counts_ptr=counts.data_ptr())
+    ctx.synchronize()
+    assert got == need
+    for rc in (0, 1):
+        h1, s1, c1 = dev_scan_hits(torch, ctx, pkg, bank, lens, codes, rc, batch, n0=3, want_counts=True)
+        n = got[rc]
+        assert n == len(h1)
+        assert np.array_equal(hits[rc][:n].cpu().numpy().astype(np.uint32), h1)
+        assert np.array_equal(sc[rc][:n].cpu().numpy().view(np.uint16), s1)
+        assert np.array_equal(counts[rc].cpu().numpy(), c1)
+        ho, so_ = oracle_hits(pkg, bank, lens, codes, rc, batch)
+        ho[:, 1] += 3
+        assert np.array_equal(h1, ho) and np.array_equal(s1, so_)
+
+
 def test_pwm_longer_than_sequence_and_empty(torch_cuda, ctx, pkg):
     sy = pkg.synth
     codes = sy.gen_codes(5, 10, 1)
