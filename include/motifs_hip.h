@@ -93,6 +93,8 @@ enum motifs_kernel_slot {
     MOTIFS_KS_SCAN_FILL = 4,    /* fill_records: (m, n, l) + fp16 score per set mask bit           */
     MOTIFS_KS_TRAIN_STEP = 5    /* the whole forward/backward graph of motifs_model_loss_grad_dev  */
 };
+/* on = 0: off; 1: every slot; otherwise a set of slots, (1 << (slot + 1)) or-ed together (an event pair costs a few
+ * microseconds of stream time per timed section: time only what is being reported). */
 int motifs_ctx_enable_timing(motifs_ctx* ctx, int on);
 int motifs_ctx_reset_timing(motifs_ctx* ctx);
 int motifs_ctx_kernel_ms(motifs_ctx* ctx, int slot, double* ms, int64_t* launches);

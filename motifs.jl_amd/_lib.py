@@ -165,8 +165,14 @@ class Context:
     def synchronize(self):
         check(lib().motifs_ctx_synchronize(self._h))
 
-    def enable_timing(self, on=True):
-        check(lib().motifs_ctx_enable_timing(self._h, int(bool(on))))
+    def enable_timing(self, on=True, slots=None):
+        """on: all kernel slots; slots: only these KS_* slots (each timed section costs a few us of stream time)."""
+        v = int(bool(on))
+        if slots is not None:
+            v = 0
+            for s in slots:
+                v |= 1 << (int(s) + 1)
+        check(lib().motifs_ctx_enable_timing(self._h, v))
 
     def reset_timing(self):
         check(lib().motifs_ctx_reset_timing(self._h))

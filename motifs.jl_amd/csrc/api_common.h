@@ -59,7 +59,7 @@ struct motifs_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    bool timing = false;
+    uint32_t timing = 0;            // bit s set: launches of slot s are timed
     bool scan_valu = false;      // MOTIFS_SCAN_VALU=1: hit records through the all-VALU mask kernel (cross-check path)
     // timing: event pairs are recorded around launches without synchronising and
     // resolved when the totals are read (motifs_ctx_kernel_ms)
@@ -106,14 +106,14 @@ struct KernelTimer {
         return e;
     }
     KernelTimer(motifs_ctx* ctx, int s) : c(ctx), slot(s) {
-        if (c->timing) {
+        if ((c->timing >> slot) & 1u) {
             e0 = get(c);
             e1 = get(c);
             (void)hipEventRecord(e0, c->stream);
         }
     }
     ~KernelTimer() {
-        if (c->timing && e0 && e1) {
+        if (e0 && e1) {
             (void)hipEventRecord(e1, c->stream);
             c->pending.push_back({slot, e0, e1});
         }

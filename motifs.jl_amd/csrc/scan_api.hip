@@ -476,7 +476,7 @@ int motifs_ctx_synchronize(motifs_ctx* c) {
 
 int motifs_ctx_enable_timing(motifs_ctx* c, int on) {
     if (!c) return MOTIFS_ERR_INVALID;
-    c->timing = on != 0;
+    c->timing = on == 0 ? 0u : (on & 1) ? 0xffffffffu : ((uint32_t)on >> 1);
     return MOTIFS_OK;
 }
 
