@@ -154,17 +154,20 @@ static __device__ __forceinline__ void scan_cand_body(const uint4* __restrict__ 
         __builtin_amdgcn_wave_barrier();
         const int64_t bq = n / d.batch;
         const size_t cell0 = ((size_t)bq * d.Lout * d.batch + (size_t)(n - bq * d.batch)) * d.nch + chunk;   // l = 0
-        uint32_t* cp0 = cells + cell0 * 4 + word0;
+        // the lane's cell of window tile 0; the window tiles follow 32 cell lines apart (a running pointer: the 64-bit
+        // multiply per store cost two v_mad_u64_u32 per tile)
+        uint32_t* cp = cells + cell0 * 4 + word0 + (size_t)w * lstride4 + (PG == 4 ? 2 * h : PG == 2 ? h : 0);
+        const size_t tile_step = 32 * lstride4;
         auto store_cells = [&](int l0, uint32_t wa, uint32_t wb) {
             const int l = l0 + w;
-            uint32_t* cp = cp0 + (size_t)l * lstride4;
             if (PG == 4) {
-                if (l < d.Lout && (ng > 2 || h == 0)) *(uint2*)(cp + 2 * h) = make_uint2(wa, wb);
+                if (l < d.Lout && (ng > 2 || h == 0)) *(uint2*)cp = make_uint2(wa, wb);
             } else if (PG == 2) {
-                if (l < d.Lout) cp[h] = wa;
+                if (l < d.Lout) *cp = wa;
             } else {
-                if (l < d.Lout && h == 0) cp[0] = wa;
+                if (l < d.Lout && h == 0) *cp = wa;
             }
+            cp += tile_step;
         };
         switch (ng) {
             case 1: cand_read<T, PG, 1, NC>(A, C0, oh, ntile, w, h, store_cells); break;
