@@ -78,7 +78,8 @@ struct FillArgs {
     struct {
         uint32_t d, m, s;
         __device__ uint32_t div(uint32_t n) const {
-            if (d == 1) return n;
+            if ((d & (d - 1)) == 0) return n >> __builtin_ctz(d);      // 1, 2, 4, .. chunks: a shift
+
             const uint32_t t = __umulhi(n, m);
             return (t + ((n - t) >> 1)) >> (s - 1);
         }

@@ -349,15 +349,15 @@ static __device__ __forceinline__ bool score_candidate(const FillArgs& a, const 
                                                        uint32_t& k, uint32_t& nin, uint16_t& sc) {
     const uint32_t idx = cw >> 7, q = (cw >> 5) & 3u, i = cw & 31u;
     nin = a.div_nch.div(idx);
-    const uint32_t ch = idx - nin * a.nch;
+    const uint32_t ch = idx - __umul24(nin, (uint32_t)a.nch);         // 24-bit multiplies are full rate, 32-bit ones a quarter
     k = (ch * 4 + q) * 32 + i;
     sc = 0;
     if (!(live && nin < g.nvalid && (int)k < a.K && (g.l <= a.lim_min || g.l <= a.lim[k]))) return false;
     uint32_t W[LEN / 4 + 1];
-    const uint32_t* sw = (const uint32_t*)(g.codes + nin * (uint32_t)a.pitch);
+    const uint32_t* sw = (const uint32_t*)(g.codes + __umul24(nin, (uint32_t)a.pitch));
 #pragma unroll
     for (int j = 0; j <= LEN / 4; j++) W[j] = sw[j];
-    sc = exact_score<LEN>(tb + (size_t)k * a.tabk_stride, W, g.l);
+    sc = exact_score<LEN>(tb + __umul24(k, (uint32_t)a.tabk_stride), W, g.l);
     return half_pos(sc);
 }
 
@@ -373,7 +373,7 @@ constexpr int DWIN = 512;         // halves per window (1 KB: one 16-byte store 
 template <int LEN, bool LDS_TAB, int MODE>
 __global__ __launch_bounds__(VF_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void stage_hits(FillArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: the row geometry stays on the scalar unit
     uint16_t* queue = (uint16_t*)smem + wv * QN;                      // [VF_WAVES][QN]
     uint32_t* hist = smem + VF_WAVES * QN / 2;                        // [hist_bins]
     uint32_t* winbase = hist + a.hist_bins;                           // MODE 2: [VF_WAVES][DWIN] halves
@@ -452,7 +452,7 @@ __global__ __launch_bounds__(VF_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
 __global__ __launch_bounds__(1024) void row_scan_local(const uint32_t* __restrict__ row_sum, int64_t nrows, uint32_t* __restrict__ row_excl,
                                                        unsigned long long* __restrict__ blk_total) {
     __shared__ uint32_t wsum[16];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: the row geometry stays on the scalar unit
     const int64_t i = (int64_t)blockIdx.x * 1024 + tid;
     const uint32_t v = i < nrows ? row_sum[i] : 0u;
     const uint32_t inc = wave_incl_scan(v);
@@ -498,7 +498,7 @@ __global__ __launch_bounds__(1024) void row_scan_blocks(unsigned long long* __re
 template <int LEN, bool LDS_TAB>
 __global__ __launch_bounds__(VF_THREADS) void emit_records(FillArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: the row geometry stays on the scalar unit
     uint16_t* queue = (uint16_t*)smem + wv * QN;
     uint32_t* ltab = smem + VF_WAVES * QN / 2;
     const _Float16* tb = nullptr;                                     // staged lazily: only overflowed rows need the bank
