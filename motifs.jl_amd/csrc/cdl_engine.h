@@ -119,14 +119,16 @@ struct Engine {
     // a*x + b*(ymask .* y) + c*z in one pass (z, ymask optional; ymask is a constant 0/1 mask)
     Tensor lin3(Tensor x, float a, Tensor y, float b, Tensor z, float c, const float* ythr = nullptr, int groups = 1);   // ythr: y counts where y >= ythr[group]
     // relu(ZY - lst*(g1 + pen*(ZY - FX - ab)) - ls*lst): the ISTA step of update_ZY fused (ab optional; scalars are 1-element tensors)
-    Tensor zy_step(Tensor ZY, Tensor g1, Tensor FX, Tensor ab, Tensor pen, Tensor lst, Tensor ls);
+    // hist0 (optional): [groups][2*2048] zeroed counters; the kernel adds the top-digit histogram of the new codes (median pass 0)
+    Tensor zy_step(Tensor ZY, Tensor g1, Tensor FX, Tensor ab, Tensor pen, Tensor lst, Tensor ls, uint32_t* hist0 = nullptr, int groups = 1);
     // FX + b*[zy >= thr[group]]*zy + abn for the outputs (zy, abn) of zy_step2(.., FX, ..): no tape entry of its own
     Tensor lin3_zy(Tensor FX, Tensor zy, float b, Tensor abn, const float* thr, int groups);
     // relu((Fc - sg*Fgrad*kst) - kst*ks) with n outputs; Fc is broadcast over groups if smaller, Fgrad may be null (zero)
     Tensor f_step(Tensor Fc, Tensor Fgrad, float sg, Tensor kst, Tensor ks, size_t n);
     Tensor x_step(Tensor X, Tensor xg, Tensor ost);   // X - ost * xg (update_X before the projection), VJP in one pass
     // the same with the dual update folded in: abn = FX - ZY + abp (abp optional), then the step with abn; returns {out, abn}
-    std::pair<Tensor, Tensor> zy_step2(Tensor ZY, Tensor g1, Tensor FX, Tensor abp, Tensor pen, Tensor lst, Tensor ls);
+    std::pair<Tensor, Tensor> zy_step2(Tensor ZY, Tensor g1, Tensor FX, Tensor abp, Tensor pen, Tensor lst, Tensor ls, uint32_t* hist0 = nullptr,
+                                       int groups = 1);
     Tensor mul(Tensor x, Tensor y);                                       // x .* y (y broadcast modulo y.n)
     Tensor relu(Tensor x);
     Tensor maskmul(Tensor x, const float* mask, float c);                 // c * mask .* x, mask constant
@@ -152,7 +154,8 @@ struct Engine {
 // selections (constants in the backward: @ignore, model.jl:190, :208)
 void topq_mask(hipStream_t st, const float* X, float* bitmat, int S, int n_per_seq, int q);
 size_t median_workspace_bytes(int G);
-void median_threshold(hipStream_t st, const float* ZY, float* thr, int G, int n_per_group, void* workspace);
+void median_threshold(hipStream_t st, const float* ZY, float* thr, int G, int n_per_group, void* workspace, bool have_pass0 = false);
+uint32_t* median_hist_ptr(void* workspace, int G);   // the [G][2*2048] counters inside a (zeroed) workspace
 void onehot_from_codes(hipStream_t st, const uint8_t* codes, int pitch, float* S, int nseq, int L);
 void adabelief_step(hipStream_t st, float* x, float* m, float* s, const float* grad, size_t n, float gscale, float eta,
                     float b1, float b2, float eps, float b1p, float b2p);

@@ -345,14 +345,58 @@ __global__ void k_thrmul(const float* src, const float* sel, const float* thr, f
 }
 // The ISTA step of update_ZY (model.jl:240-244) on the compact image, fused:
 //   out = relu(ZY - lst * (g1 + pen * (ZY - FX - ab)) - ls * lst)          (ab optional; pen, lst, ls device scalars)
+// The first pass of the median select over the new codes (the top 11 bits of the positive entries, create_ZY_mask
+// model.jl:194-204) can ride in the kernel that writes them: per thread, runs of equal digits are counted in registers
+// and leave as one LDS atomic; the block's histogram is added to hist0[group][ZH_BINS] at the end.
+constexpr int ZH_BINS = 2048, ZH_SHIFT = 21;
+struct RunHist {
+    uint32_t d = 0xffffffffu, c = 0;
+    __device__ __forceinline__ void take(float v, uint32_t* h) {
+        if (!(v > 0.0f)) return;
+        const uint32_t b = __float_as_uint(v) >> ZH_SHIFT;
+        if (b == d) {
+            c++;
+        } else {
+            if (c) atomicAdd(&h[d], c);
+            d = b, c = 1;
+        }
+    }
+    __device__ __forceinline__ void flush(uint32_t* h) {
+        if (c) atomicAdd(&h[d], c);
+    }
+};
+static __device__ __forceinline__ void zh_begin(uint32_t* zh) {
+    for (int i = threadIdx.x; i < ZH_BINS; i += blockDim.x) zh[i] = 0;
+    __syncthreads();
+}
+static __device__ __forceinline__ void zh_end(uint32_t* zh, uint32_t* hist0) {
+    __syncthreads();
+    uint32_t* hg = hist0 + (size_t)blockIdx.y * 2 * ZH_BINS;
+    for (int i = threadIdx.x; i < ZH_BINS; i += blockDim.x) {
+        const uint32_t c = zh[i];
+        if (c) atomicAdd(&hg[i], c);
+    }
+}
+// (one grid row per group of `per` elements; hist0 optional)
 __global__ void k_zy_step(const float* ZY, const float* g1, const float* FX, const float* ab, const float* pen, const float* lst,
-                          const float* ls, size_t n, float* out) {
+                          const float* ls, size_t per, float* out, uint32_t* hist0) {
+    __shared__ uint32_t zh[ZH_BINS];
     const float p = *pen, s = *lst, l = *ls;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t base = (size_t)blockIdx.y * per;
+    RunHist rh;
+    if (hist0) zh_begin(zh);
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < per; j += (size_t)gridDim.x * blockDim.x) {
+        const size_t i = base + j;
         const float inner = ZY[i] - (FX[i] + (ab ? ab[i] : 0.0f));
         const float grad = g1[i] + inner * p;
         const float u = (ZY[i] - grad * s) - l * s;
-        out[i] = u > 0.0f ? u : 0.0f;
+        const float o = u > 0.0f ? u : 0.0f;
+        out[i] = o;
+        if (hist0) rh.take(o, zh);
+    }
+    if (hist0) {
+        rh.flush(zh);
+        zh_end(zh, hist0);
     }
 }
 // its VJP: one pass over the image for the four tensor gradients and the three scalar gradients
@@ -465,16 +509,27 @@ __global__ void k_f_step_bwd(const float* go, const float* out, const float* Fgr
 //   out = relu(ZY - lst * (g1 + pen * (ZY - FX - abn)) - ls * lst)
 // which saves the separate three-term pass (and its VJP) per ADMM pass.
 __global__ void k_zy_step2(const float* ZY, const float* g1, const float* FX, const float* abp, const float* pen, const float* lst,
-                           const float* ls, size_t n, float* out, float* abn) {
+                           const float* ls, size_t per, float* out, float* abn, uint32_t* hist0) {
+    __shared__ uint32_t zh[ZH_BINS];
     const float p = *pen, s = *lst, l = *ls;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t base = (size_t)blockIdx.y * per;
+    RunHist rh;
+    if (hist0) zh_begin(zh);
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < per; j += (size_t)gridDim.x * blockDim.x) {
+        const size_t i = base + j;
         const float zy = ZY[i], fx = FX[i];
         const float dual = (fx - zy) + (abp ? abp[i] : 0.0f);
         const float inner = zy - (fx + dual);
         const float grad = g1[i] + inner * p;
         const float u = (zy - grad * s) - l * s;
+        const float o = u > 0.0f ? u : 0.0f;
         abn[i] = dual;
-        out[i] = u > 0.0f ? u : 0.0f;
+        out[i] = o;
+        if (hist0) rh.take(o, zh);
+    }
+    if (hist0) {
+        rh.flush(zh);
+        zh_end(zh, hist0);
     }
 }
 // VJP: go = d out (may be null), gab = d abn (may be null).  inner = 2 ZY - 2 FX - abp.
@@ -595,12 +650,17 @@ Tensor Engine::thrmul(Tensor x, const float* thr, int groups, float c) {
     return out;
 }
 
-Tensor Engine::zy_step(Tensor ZY, Tensor g1, Tensor FX, Tensor ab, Tensor pen, Tensor lst, Tensor ls) {
+Tensor Engine::zy_step(Tensor ZY, Tensor g1, Tensor FX, Tensor ab, Tensor pen, Tensor lst, Tensor ls, uint32_t* hist0, int groups) {
     const bool ng = ZY->needs_grad || g1->needs_grad || FX->needs_grad || (ab && ab->needs_grad) || pen->needs_grad ||
                     lst->needs_grad || ls->needs_grad;
     Tensor out = make(ZY->n, ng);
     if (failed) return out;
-    EW(k_zy_step, ZY->n, ZY->v, g1->v, FX->v, ab ? ab->v : nullptr, pen->v, lst->v, ls->v, ZY->n, out->v);
+    {
+        const int G = hist0 ? groups : 1;
+        const size_t per = ZY->n / G;
+        hipLaunchKernelGGL(k_zy_step, dim3(nblocks(per, 256, std::max<size_t>(256 * 32 / G, 1)), G), dim3(256), 0, st, ZY->v, g1->v, FX->v,
+                           ab ? ab->v : nullptr, pen->v, lst->v, ls->v, per, out->v, hist0);
+    }
     if (recording && out->needs_grad)
         tape.push_back([this, out, ZY, g1, FX, ab, pen, lst, ls]() {
             if (!out->g) return;
@@ -678,13 +738,19 @@ Tensor Engine::x_step(Tensor X, Tensor xg, Tensor ost) {
     return out;
 }
 
-std::pair<Tensor, Tensor> Engine::zy_step2(Tensor ZY, Tensor g1, Tensor FX, Tensor abp, Tensor pen, Tensor lst, Tensor ls) {
+std::pair<Tensor, Tensor> Engine::zy_step2(Tensor ZY, Tensor g1, Tensor FX, Tensor abp, Tensor pen, Tensor lst, Tensor ls, uint32_t* hist0,
+                                           int groups) {
     const bool ng = ZY->needs_grad || g1->needs_grad || FX->needs_grad || (abp && abp->needs_grad) || pen->needs_grad ||
                     lst->needs_grad || ls->needs_grad;
     Tensor out = make(ZY->n, ng);
     Tensor abn = make(ZY->n, ng);
     if (failed) return {out, abn};
-    EW(k_zy_step2, ZY->n, ZY->v, g1->v, FX->v, abp ? abp->v : nullptr, pen->v, lst->v, ls->v, ZY->n, out->v, abn->v);
+    {
+        const int G = hist0 ? groups : 1;
+        const size_t per = ZY->n / G;
+        hipLaunchKernelGGL(k_zy_step2, dim3(nblocks(per, 256, std::max<size_t>(256 * 32 / G, 1)), G), dim3(256), 0, st, ZY->v, g1->v, FX->v,
+                           abp ? abp->v : nullptr, pen->v, lst->v, ls->v, per, out->v, abn->v, hist0);
+    }
     if (recording && ng)
         tape.push_back([this, out, abn, ZY, g1, FX, abp, pen, lst, ls]() {
             // the combination formed after the step (lin3_zy), if any, and its gradient
@@ -3067,12 +3133,17 @@ __global__ void k_med_thr(const MedState* __restrict__ state, int G, float* __re
     thr[g] = med;
 }
 
-void median_threshold(hipStream_t st, const float* ZY, float* thr, int G, int n_per_group, void* workspace) {
+static_assert(MED_BINS == ZH_BINS, "the fused first pass (zy_step kernels) fills the same histogram");
+uint32_t* median_hist_ptr(void* workspace, int G) {
+    return (uint32_t*)((char*)workspace + (((size_t)G * sizeof(MedState) + 255) & ~(size_t)255));
+}
+void median_threshold(hipStream_t st, const float* ZY, float* thr, int G, int n_per_group, void* workspace, bool have_pass0) {
     MedState* state = (MedState*)workspace;
-    uint32_t* hist = (uint32_t*)((char*)workspace + (((size_t)G * sizeof(MedState) + 255) & ~(size_t)255));
+    uint32_t* hist = median_hist_ptr(workspace, G);
     const unsigned nb = (unsigned)std::min<size_t>((n_per_group + 256 * 16 - 1) / (256 * 16), 64);
     for (int pass = 0; pass < 3; pass++) {            // the workspace arrives zeroed (Engine::zeros)
-        hipLaunchKernelGGL(k_med_hist, dim3(nb, G), dim3(256), 0, st, ZY, n_per_group, state, hist, pass);
+        if (!(pass == 0 && have_pass0))               // the kernel that wrote the codes may have counted the top digits already
+            hipLaunchKernelGGL(k_med_hist, dim3(nb, G), dim3(256), 0, st, ZY, n_per_group, state, hist, pass);
         hipLaunchKernelGGL(k_med_select, dim3(G), dim3(256), 0, st, state, hist, pass);
     }
     hipLaunchKernelGGL(k_med_thr, dim3((G + 63) / 64), dim3(64), 0, st, state, G, thr);

@@ -46,6 +46,9 @@ struct Graph {
     int G, S;
     ToepGeom gD1, gD2, gF1, gF2;
     Tensor Sone;
+    Tensor pre_of = nullptr;          // codes written by a step kernel that filled pass 0 of their median select, and its workspace
+    float* pre_ws = nullptr;
+    float* med_ws() { return e.zeros(median_workspace_bytes(G) / 4 + 64); }
     Tensor thr_of = nullptr;          // the codes whose medians were taken last, and where they are
     const float* thr_last = nullptr;
 
@@ -75,9 +78,10 @@ struct Graph {
     const float* zy_thr(Tensor ZY) {
         if (ZY == thr_of) return thr_last;                                // the final codes are thresholded twice (:251, :364)
         Tensor thr = e.make((size_t)G + 64, false);
-        float* ws = e.zeros(median_workspace_bytes(G) / 4 + 64);
+        const bool pre = ZY == pre_of && pre_ws;                          // the step kernel counted the top digits on the way
+        float* ws = pre ? pre_ws : e.zeros(median_workspace_bytes(G) / 4 + 64);
         if (e.failed) return nullptr;
-        median_threshold(e.st, ZY->v, thr->v, G, (int)(ZY->n / G), ws);
+        median_threshold(e.st, ZY->v, thr->v, G, (int)(ZY->n / G), ws, pre);
         thr_of = ZY;
         thr_last = thr->v;
         return thr->v;
@@ -161,14 +165,18 @@ static void admm_xyz(motifs_model* m, Graph& gr, const Scalars& sc, const Graph:
         // update_ZY (:237-245)
         Tensor diff = e.lin(gr.synD(ZY, bD), 1.0f, gr.Sone, -1.0f, 0.0f);
         Tensor g1 = gr.anaD(diff, bD);
+        float* mws = gr.med_ws();                                         // the median select of the new codes starts in the step kernel
+        uint32_t* h0 = mws ? median_hist_ptr(mws, gr.G) : nullptr;
         if (t == 0) {
-            ZY = e.zy_step(ZY, g1, FX, nullptr, sc.pen[t], sc.lst[t], sc.ls[t]);   // z_grad/y_grad + the shrinkage (:240-244)
+            ZY = e.zy_step(ZY, g1, FX, nullptr, sc.pen[t], sc.lst[t], sc.ls[t], h0, gr.G);   // z_grad/y_grad + the shrinkage (:240-244)
         } else {
             // the dual update that closes the previous pass (:263-266: ab += FX - ZY) rides in the same kernel
-            auto r = e.zy_step2(ZY, g1, FX, ab, sc.pen[t], sc.lst[t], sc.ls[t]);
+            auto r = e.zy_step2(ZY, g1, FX, ab, sc.pen[t], sc.lst[t], sc.ls[t], h0, gr.G);
             ZY = r.first;
             ab = r.second;
         }
+        gr.pre_of = h0 ? ZY : nullptr;
+        gr.pre_ws = mws;
         // update_X (:247-254); `sum(FX, dims=3)` is a no-op on the already summed FX
         // FX - (cat_ZY(ZY) - [alpha beta]); the magnified, median-masked image is formed inside the same pass
         const float* zt = gr.zy_thr(ZY);
