@@ -84,6 +84,7 @@ float* Engine::grad(Tensor t) {
     return t->g;
 }
 
+// kind: low 4 bits = which re-layout, the rest = its dimensions (a bank pointer seen with other dimensions is another entry)
 float* Engine::relayout(const float* src, int kind, size_t n, bool& fresh) {
     auto key = std::make_pair((const void*)src, kind);
     auto it = derived.find(key);
@@ -1356,7 +1357,7 @@ static bool launch_ana_lds(Engine& e, const float* A, const float* Bm, float* C,
     const int gB = gm.ldb == 0 ? 1 : gm.S / gm.B;
     const size_t perf = (size_t)(gm.Q / 8) * 256;
     bool fresh;
-    float* Bf = e.relayout(Bm, 1, perf * gB, fresh);
+    float* Bf = e.relayout(Bm, 1 | ((gm.Q << 4) ^ (gm.N << 20)), perf * gB, fresh);
     if (!Bf) return true;
     if (fresh) hipLaunchKernelGGL(k_frag_b, dim3(nblocks(perf * gB)), dim3(256), 0, e.st, Bm, gB, gm.Q, gm.N, Bf);
     // blocks per CU: the count whose rounds x resident waves is smallest (all blocks take the same time)
@@ -1674,7 +1675,7 @@ static bool launch_rowgemm_lds(Engine& e, const float* A, const float* Bm, float
     const int tpg = (int)((rpg + 31) / 32);
     const size_t perf = (size_t)(rg.Q / 4) * 256;
     bool fresh;
-    float* Bf = e.relayout(Bm, 2, perf * groups, fresh);
+    float* Bf = e.relayout(Bm, 2 | ((rg.Q << 4) ^ (rg.N << 20)), perf * groups, fresh);
     if (!Bf) return true;
     if (fresh) hipLaunchKernelGGL(k_frag_b16, dim3(nblocks(perf * groups)), dim3(256), 0, e.st, Bm, groups, rg.Q, rg.N, Bf);
     const int NT = (rg.N + 15) / 16;
@@ -1802,7 +1803,7 @@ static bool launch_toep_wide(Engine& e, const float* A, const float* Bm, float* 
     const int gB = gm.ldb == 0 ? 1 : gm.S / gm.B;
     const size_t perf = (size_t)NCT * KG * 256;
     bool fresh;
-    float* Bf = e.relayout(Bm, 3, perf * gB, fresh);
+    float* Bf = e.relayout(Bm, 3 | ((gm.Q << 4) ^ (gm.N << 20)), perf * gB, fresh);
     if (!Bf) return true;
     if (fresh) hipLaunchKernelGGL(k_frag_bw, dim3(nblocks(perf * gB)), dim3(256), 0, e.st, Bm, gB, gm.Q, gm.N, Bf);
     const int tps = (gm.P + 31) / 32;
@@ -1850,7 +1851,7 @@ static void launch_toep(Engine& e, const float* A, const float* Bm, float* C, co
         const int gB = gm.ldb == 0 ? 1 : gm.S / gm.B;
         const size_t per = (size_t)gm.Q * gm.N;
         bool fresh;
-        float* Bt = e.relayout(Bm, 4, per * gB, fresh);
+        float* Bt = e.relayout(Bm, 4 | ((gm.sa << 4) ^ (gm.N << 20) ^ (H << 26)), per * gB, fresh);
         float* Wt = e.arena.alloc((size_t)gm.S * R * H * gm.N);
         if (!Bt || !Wt) {
             e.failed = true;
@@ -2287,7 +2288,7 @@ static bool toep_adjoint_a(Engine& e, const float* dC, const float* Bm, float* d
     const int gB = gm.ldb == 0 ? 1 : gm.S / gm.B;
     const size_t per = (size_t)gm.Q * gm.N;
     bool fresh;
-    float* tmp = e.relayout(Bm, 5, per * gB, fresh);
+    float* tmp = e.relayout(Bm, 5 | ((W << 4) ^ (gm.N << 20) ^ (H << 26)), per * gB, fresh);
     if (!tmp) return false;
     if (fresh) launch_flipT(e.st, Bm, gB, H, W, gm.N, tmp, 0);
     ToepGeom g2;
