@@ -536,34 +536,63 @@ __global__ void k_zy_step2(const float* ZY, const float* g1, const float* FX, co
 // VJP: go = d out (may be null), gab = d abn (may be null).  inner = 2 ZY - 2 FX - abp.
 // g3 (optional) = d of the combination img = FX + b3*[out >= thr]*out + abn formed after the step (lin3_zy): its
 // three contributions (to d out, d abn and d FX) are folded in here instead of a pass of their own.
+template <int V>   // V = 4: 16-byte accesses (per % 4 == 0, 16-byte aligned tensors); V = 1: scalar
 __global__ void k_zy_step2_bwd(const float* go, const float* gab, const float* g3, float b3, const float* thr, const float* out,
                                const float* ZY, const float* g1, const float* FX, const float* abp, const float* pen, const float* lst,
                                const float* ls, size_t per, float* dZY, int aZY, float* dg1, int ag1, float* dFX, int aFX, float* dabp,
                                int aabp, float* dpen, float* dlst, float* dls) {
+    struct VF {
+        float e[V];
+    };
     const float p = *pen, s = *lst, l = *ls;
     const size_t base = (size_t)blockIdx.y * per;
     const float t3 = thr ? thr[blockIdx.y] : 0.0f;
     double sp = 0, ss = 0, sl = 0;
-    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < per; j += (size_t)gridDim.x * blockDim.x) {
+    auto ld = [&](const float* q, size_t i) {
+        VF r;
+        if (V == 4) {
+            const float4 x = *(const float4*)(q + i);
+            r.e[0] = x.x, r.e[1 % V] = x.y, r.e[2 % V] = x.z, r.e[3 % V] = x.w;
+        } else {
+            r.e[0] = q[i];
+        }
+        return r;
+    };
+    auto st = [&](float* q, size_t i, const VF& r) {
+        if (V == 4) *(float4*)(q + i) = make_float4(r.e[0], r.e[1 % V], r.e[2 % V], r.e[3 % V]);
+        else q[i] = r.e[0];
+    };
+    for (size_t j = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * V; j < per; j += (size_t)gridDim.x * blockDim.x * V) {
         const size_t i = base + j;
-        const float o = out[i];
-        const float g3v = g3 ? g3[i] : 0.0f;
-        float gz = go ? go[i] : 0.0f;
-        if (g3) gz += b3 * ((thr && !(o >= t3)) ? 0.0f : g3v);
-        const float du = o > 0.0f ? gz : 0.0f;
-        const float gb = (gab ? gab[i] : 0.0f) + g3v;
-        const float zy = ZY[i], fx = FX[i];
-        const float dual = (fx - zy) + (abp ? abp[i] : 0.0f);
-        const float inner = zy - (fx + dual);
-        const float grad = g1[i] + inner * p;
-        const float t = s * p * du;
-        if (dZY) dZY[i] = (aZY ? dZY[i] : 0.0f) + (du - 2.0f * t) - gb;
-        if (dg1) dg1[i] = (ag1 ? dg1[i] : 0.0f) - s * du;
-        if (dFX) dFX[i] = (aFX ? dFX[i] : 0.0f) + (2.0f * t + gb) + g3v;
-        if (dabp) dabp[i] = (aabp ? dabp[i] : 0.0f) + t + gb;
-        sp -= (double)du * (double)(s * inner);
-        ss -= (double)du * (double)(grad + l);
-        sl -= (double)du * (double)s;
+        VF z{};
+        const VF vo = ld(out, i), vg3 = g3 ? ld(g3, i) : z, vgo = go ? ld(go, i) : z, vgab = gab ? ld(gab, i) : z;
+        const VF vzy = ld(ZY, i), vfx = ld(FX, i), vabp = abp ? ld(abp, i) : z, vg1 = ld(g1, i);
+        VF oZY = (dZY && aZY) ? ld(dZY, i) : z, og1 = (dg1 && ag1) ? ld(dg1, i) : z, oFX = (dFX && aFX) ? ld(dFX, i) : z,
+           oab = (dabp && aabp) ? ld(dabp, i) : z;
+#pragma unroll
+        for (int u = 0; u < V; u++) {
+            const float o = vo.e[u], g3v = vg3.e[u];
+            float gz = vgo.e[u];
+            if (g3) gz += b3 * ((thr && !(o >= t3)) ? 0.0f : g3v);
+            const float du = o > 0.0f ? gz : 0.0f;
+            const float gb = vgab.e[u] + g3v;
+            const float zy = vzy.e[u], fx = vfx.e[u];
+            const float dual = (fx - zy) + vabp.e[u];
+            const float inner = zy - (fx + dual);
+            const float grad = vg1.e[u] + inner * p;
+            const float t = s * p * du;
+            oZY.e[u] = oZY.e[u] + (du - 2.0f * t) - gb;
+            og1.e[u] = og1.e[u] - s * du;
+            oFX.e[u] = oFX.e[u] + (2.0f * t + gb) + g3v;
+            oab.e[u] = oab.e[u] + t + gb;
+            sp -= (double)du * (double)(s * inner);
+            ss -= (double)du * (double)(grad + l);
+            sl -= (double)du * (double)s;
+        }
+        if (dZY) st(dZY, i, oZY);
+        if (dg1) st(dg1, i, og1);
+        if (dFX) st(dFX, i, oFX);
+        if (dabp) st(dabp, i, oab);
     }
     for (int d = 32; d >= 1; d >>= 1) {
         sp += __shfl_xor(sp, d);
@@ -769,9 +798,17 @@ std::pair<Tensor, Tensor> Engine::zy_step2(Tensor ZY, Tensor g1, Tensor FX, Tens
             if (failed) return;
             const int G = g3 ? out->fl_groups : 1;
             const size_t per = out->n / G;
-            hipLaunchKernelGGL(k_zy_step2_bwd, dim3(nblocks(per, 256, std::max<size_t>(2048 / G, 1)), G), dim3(256), 0, st, out->g, abn->g, g3,
-                               out->fl_b, g3 ? out->fl_thr : nullptr, out->v, ZY->v, g1->v, FX->v, abp ? abp->v : nullptr, pen->v, lst->v, ls->v,
-                               per, d0, a0, d1, a1, d2, a2, d3, a3, dp, ds, dl);
+            auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+            const bool v4 = (per & 3) == 0 && al16(out->g) && al16(abn->g) && al16(g3) && al16(out->v) && al16(ZY->v) && al16(g1->v) &&
+                            al16(FX->v) && al16(abp ? abp->v : nullptr) && al16(d0) && al16(d1) && al16(d2) && al16(d3);
+            if (v4)
+                hipLaunchKernelGGL(k_zy_step2_bwd<4>, dim3(nblocks(per / 4, 256, std::max<size_t>(2048 / G, 1)), G), dim3(256), 0, st, out->g, abn->g,
+                                   g3, out->fl_b, g3 ? out->fl_thr : nullptr, out->v, ZY->v, g1->v, FX->v, abp ? abp->v : nullptr, pen->v, lst->v,
+                                   ls->v, per, d0, a0, d1, a1, d2, a2, d3, a3, dp, ds, dl);
+            else
+                hipLaunchKernelGGL(k_zy_step2_bwd<1>, dim3(nblocks(per, 256, std::max<size_t>(2048 / G, 1)), G), dim3(256), 0, st, out->g, abn->g, g3,
+                                   out->fl_b, g3 ? out->fl_thr : nullptr, out->v, ZY->v, g1->v, FX->v, abp ? abp->v : nullptr, pen->v, lst->v,
+                                   ls->v, per, d0, a0, d1, a1, d2, a2, d3, a3, dp, ds, dl);
         });
     return {out, abn};
 }
