@@ -1,23 +1,28 @@
 #!/usr/bin/env python3
 """bench.py — headline benchmark of the hot path (BASELINE.json).
 
-metric   bases scanned / second: the PWM log-odds scan of a18 (both strands:
-         scan + `> 0` threshold + ordered hit records, everything resident in
-         HBM), on BASELINE configs[1]: 100k sequences x 200 bp against 200 PWMs
-         of length 12 per GPU.
-step     one pass of that scan over the rank's shard (forward + reverse strand),
-         followed, when N > 1, by the all-reduce of the K-entry hit histogram.
-scaling  weak: every rank scans its own 100k x 200 bp shard (sequences shard with
-         no data-path collective).
+metric   bases scanned / second: the PWM log-odds scan of a18 (both strands: scan + `> 0` threshold + ordered
+         hit records, everything resident in HBM), on BASELINE configs[1]: 100k sequences x 200 bp against
+         200 PWMs of length 12 per GPU.
+step     one pass of that scan over the rank's shard (forward + reverse strand), followed, when N > 1, by the sum
+         of the 2 x K hit histogram over the ranks (RCCL through the C ABI, on the scan's stream).
+scaling  weak (the headline line): every rank scans its own 100k x 200 bp shard (reads shard with no data-path
+         collective).  The same run also times BASELINE configs[2] as written — the SAME 100k
+         reads split over the N ranks on whole 5000-read ordering batches — and reports it under "strong";
+         at N = 1 the two are the same workload.
 
-One JSON line on stdout (rank 0).  `roofline` is measured with HIP events on the
-stream the kernels run on, inside the timed region; `cpu_baseline` is the CPU
-oracle (a port of the reference algorithm, not the reference itself — Julia is
-not installed) timed on a bounded sample on rank 0 at N == 1.
+`python bench.py --gpus N` without a launcher starts the N rank processes itself (the parent never touches the
+GPU); under `torch.distributed.run` (RANK / WORLD_SIZE set) it is one of the ranks.
+
+One JSON line on stdout (rank 0).  `roofline` is measured with HIP events on the stream the kernels run on, inside
+the timed region; `cpu_baseline` is the CPU port of the reference algorithm (Julia is not installed, so not the
+reference itself) timed on a bounded sample on rank 0 at N == 1.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,6 +33,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_F16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak (no sparsity)
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_scan_hbm_traffic.json")   # written by tools/pmc_scan.sh
 
 
 def parse():
@@ -35,22 +41,70 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--seqs", type=int, default=100_000, help="sequences per GPU")
+    ap.add_argument("--seqs", type=int, default=100_000, help="sequences per GPU (weak) / in total (strong)")
     ap.add_argument("--len", type=int, default=200)
     ap.add_argument("--pwms", type=int, default=200)
     ap.add_argument("--pwm-len", type=int, default=12)
-    ap.add_argument("--cpu-sample", type=int, default=600, help="sequences in the CPU-baseline sample")
+    ap.add_argument("--cpu-sample", type=int, default=20_000, help="sequences in the CPU-baseline sample (vectorised port)")
+    ap.add_argument("--cpu-literal-sample", type=int, default=300, help="sequences timed with the literal soft-float port")
     ap.add_argument("--train-groups", type=int, default=64, help="mini-batches (of 6 reads) per optimiser step per GPU")
     ap.add_argument("--train-steps", type=int, default=5)
     ap.add_argument("--filters", type=int, default=200)
     ap.add_argument("--filter-len", type=int, default=12)
     ap.add_argument("--no-train", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="only the timed scan (+ train): skip dense / consumers / host-entry legs")
     return ap.parse_args()
+
+
+def spawn_ranks(args):
+    """`bench.py --gpus N` with no launcher around it: start N rank processes of this script, one per GPU.  The
+    parent initialises no GPU and replaces no process image; it waits and returns the worst exit code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        while procs:
+            for p in list(procs):
+                code = p.poll()
+                if code is None:
+                    continue
+                procs.remove(p)
+                if code != 0:
+                    rc = rc or code
+                    for q in procs:           # a dead rank leaves the others waiting in a collective
+                        q.terminate()
+            time.sleep(0.2)
+    finally:
+        for p in procs:
+            p.kill()
+    return rc
+
+
+def timed_region(step, steps, sync, barrier):
+    barrier()
+    sync()
+    t0 = time.perf_counter()
+    out = None
+    for _ in range(steps):
+        out = step()
+    sync()
+    barrier()
+    sync()
+    return time.perf_counter() - t0, out
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
+
     import torch
     import torch.distributed as dist
 
@@ -58,8 +112,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU: the product path has no CPU fallback"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     # MOTIFS_BENCH_REHEARSE=1: every rank on device 0 over gloo — a rehearsal of the N > 1 control flow on a
-    # one-GPU box (numbers meaningless); the real N > 1 run is one rank per GPU over RCCL.
+    # one-GPU box (numbers meaningless); the real N > 1 run is one rank per GPU, RCCL over xGMI.
     rehearse = os.environ.get("MOTIFS_BENCH_REHEARSE") == "1"
     if rehearse:
         local_rank = 0
@@ -70,210 +125,245 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from _pkg import load_pkg
 
     pkg = load_pkg()
-    lib, sy = pkg._lib, pkg.synth
+    lib, sy, par = pkg._lib, pkg.synth, pkg.parallel
     N, L, K, PL = args.seqs, args.len, args.pwms, args.pwm_len
+    dev = torch.device("cuda", local_rank)
 
-    # ---- synthetic inputs, one shard per rank -------------------------------
+    def sync():
+        torch.cuda.synchronize(dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    ctx = lib.Context(local_rank)
+    # The context enqueues on HIP's null stream = torch's default current stream: torch allocations / fills and the
+    # library's kernels are then ordered by the stream itself (ABI 1 silently made a private stream here).
+    ctx.set_stream(0)
+    reducer, reducer_note = par.make_reducer(ctx, prefer_rccl=not rehearse)
+
+    # ---- synthetic inputs ------------------------------------------------------
     seed = sy.SEED_BASE + 2
-    codes = sy.gen_codes(N, L, seed + 1000 * rank, n_plant=5, k=PL)
     pwms, lens = sy.gen_pwm_bank(K, seed, len_lo=PL, len_hi=PL, alpha=0.3)
     bank = sy.pad_bank(pwms, lens)
 
-    ctx = lib.Context(local_rank)
-    stream = torch.cuda.current_stream()
-    ctx.set_stream(stream.cuda_stream)
+    def make_shard(codes_np, n0):
+        n = codes_np.shape[0]
+        raw = torch.from_numpy(codes_np).to(dev)
+        dcodes = torch.zeros(lib.Context.codes_bytes(n, L), dtype=torch.uint8, device=dev)
+        ctx.encode_dev(raw.data_ptr(), lib.DATA_CODES_U8, n, L, dcodes.data_ptr())
+        need = ctx.pwm_scan_hits_both_dev(bank, lens, dcodes.data_ptr(), n, L, None, None, 0, n0=n0) if n else (0, 0)
+        cap = int(max(need) * 1.05) + 1024
+        hits = [torch.empty((cap, 3), dtype=torch.int32, device=dev) for _ in range(2)]
+        hsc = [torch.empty(cap, dtype=torch.int16, device=dev) for _ in range(2)]
+        counts = torch.zeros((2, K), dtype=torch.int64, device=dev)
+        sync()
+        return {"n": n, "n0": n0, "codes": dcodes, "need": need, "cap": cap, "hits": hits, "hsc": hsc, "counts": counts}
 
-    raw = torch.from_numpy(codes).cuda()
-    dcodes = torch.zeros(lib.Context.codes_bytes(N, L), dtype=torch.uint8, device="cuda")
-    ctx.encode_dev(raw.data_ptr(), lib.DATA_CODES_U8, N, L, dcodes.data_ptr())
-    # per-strand hit histograms, two sets: the all-reduce of step i runs beside the scan of step i + 1
-    counts_ring = [torch.zeros((2, K), dtype=torch.int64, device="cuda") for _ in range(2)]
-    pending = [None, None]
-    step_no = [0]
-    # size the record buffers once (count-only pass), with head-room
-    need = [ctx.pwm_scan_hits_dev(bank, lens, dcodes.data_ptr(), N, L, rc, None, None, 0, n0=rank * N) for rc in (0, 1)]
-    cap = int(max(need) * 1.05) + 1024
-    hits = [torch.empty((cap, 3), dtype=torch.int32, device="cuda") for _ in range(2)]
-    hsc = [torch.empty(cap, dtype=torch.int16, device="cuda") for _ in range(2)]
-    torch.cuda.synchronize()
-
-    def step():
+    def scan_step(sh):
         tot = 0
-        i = step_no[0] & 1
-        step_no[0] += 1
-        if pending[i] is not None:          # the all-reduce that last used this set of counters
-            pending[i].wait()
-            pending[i] = None
-        counts = counts_ring[i]
-        # gpu_scan (_h3_1_alignment.jl:89-99): forward and reverse strand in one call, one host wait
-        tot += sum(ctx.pwm_scan_hits_both_dev(bank, lens, dcodes.data_ptr(), N, L, [hits[0].data_ptr(), hits[1].data_ptr()],
-                                              [hsc[0].data_ptr(), hsc[1].data_ptr()], cap, n0=rank * N, counts_ptr=counts.data_ptr()))
-        if world > 1:  # the one real exchange of the scan: the K int64 hit counts of both strands
-            pending[i] = dist.all_reduce(counts, async_op=True)
+        if sh["n"]:
+            # gpu_scan (_h3_1_alignment.jl:89-99): forward and reverse strand in one call, one host wait
+            tot = sum(ctx.pwm_scan_hits_both_dev(bank, lens, sh["codes"].data_ptr(), sh["n"], L, [h.data_ptr() for h in sh["hits"]],
+                                                 [s.data_ptr() for s in sh["hsc"]], sh["cap"], n0=sh["n0"], counts_ptr=sh["counts"].data_ptr()))
+        if world > 1:   # the one real exchange of the scan: the K int64 hit counts of both strands, queued on the
+            reducer.sum_i64_(sh["counts"])   # scan's stream behind the kernels that wrote them; the next scan queues behind it
         return tot
 
-    def drain():
-        for i in (0, 1):
-            if pending[i] is not None:
-                pending[i].wait()
-                pending[i] = None
-
+    # weak: one 100k shard per rank
+    codes = sy.gen_codes(N, L, seed + 1000 * rank, n_plant=5, k=PL)
+    weak = make_shard(codes, rank * N)
     for _ in range(args.warmup):
-        step()
-    drain()
-    torch.cuda.synchronize()
+        scan_step(weak)
+    sync()
     # HIP events inside the timed region only around the roofline kernel (the candidate filter): an event pair costs a few
-    # microseconds of stream time per section (all three sections timed: +0.04 ms per step); the other kernels are timed in
-    # an extra pass of the same steps after the clock has stopped
+    # microseconds of stream time per section; the other kernels are timed in an extra pass after the clock has stopped
     ctx.enable_timing(slots=[lib.KS_SCAN_COUNT])
     ctx.reset_timing()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    nhits = 0
-    for _ in range(args.steps):
-        nhits = step()
-    drain()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    dt, nhits = timed_region(lambda: scan_step(weak), args.steps, sync, barrier)
     ctx.enable_timing(False)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt = float(par.host_all_reduce(torch.tensor([dt], dtype=torch.float64), dist.ReduceOp.MAX).item())
+    tot_hits = torch.tensor([nhits], dtype=torch.int64)
+    if world > 1:
+        par.HostReducer(ctx).sum_i64_(tot_hits)
 
     kms = {"count": ctx.kernel_ms(lib.KS_SCAN_COUNT)}
     ctx.enable_timing(slots=[lib.KS_SCAN_OFFSETS, lib.KS_SCAN_FILL])
     ctx.reset_timing()
     for _ in range(args.steps):
-        step()
-    drain()
-    torch.cuda.synchronize()
+        scan_step(weak)
+    sync()
     ctx.enable_timing(False)
     kms["offsets"] = ctx.kernel_ms(lib.KS_SCAN_OFFSETS)
     kms["fill"] = ctx.kernel_ms(lib.KS_SCAN_FILL)
 
-    # ---- the a17 kernel on its own: dense (K, nb, L-len+1) fp16 scores (untimed extra leg) ----
+    # ---- strong scaling: BASELINE configs[2] as written (the same N reads split over the ranks) -------------------
+    strong = None
+    if world > 1:
+        all_codes = sy.gen_codes(N, L, seed, n_plant=5, k=PL)          # the rank-0 shard of the weak run, on every rank
+        lo, hi = par.shard_range(N, rank, world, align=lib.SCAN_BATCH)
+        sh = make_shard(np.ascontiguousarray(all_codes[lo:hi]), lo)
+        for _ in range(args.warmup):
+            scan_step(sh)
+        sdt, sh_hits = timed_region(lambda: scan_step(sh), args.steps, sync, barrier)
+        sdt = float(par.host_all_reduce(torch.tensor([sdt], dtype=torch.float64), dist.ReduceOp.MAX).item())
+        sizes = [b - a for a, b in (par.shard_range(N, r, world, align=lib.SCAN_BATCH) for r in range(world))]
+        strong = {"value": float(N) * L * args.steps / sdt, "unit": "bases/s", "ms_per_step": sdt / args.steps * 1e3,
+                  "scaling": "strong", "seqs_total": N, "shard_sizes": sizes,
+                  "hist_total_hits": int(sh["counts"].sum().item()),
+                  "note": "BASELINE configs[2]: the same reads split on whole 5000-read ordering batches, so that the records "
+                          "concatenated in rank order are the single-device records; the step is launch- and host-wait-bound at "
+                          "these shard sizes"}
+        del sh, all_codes
+    else:
+        strong = {"value": float(N) * L * args.steps / dt, "unit": "bases/s", "ms_per_step": dt / args.steps * 1e3, "scaling": "strong",
+                  "seqs_total": N, "shard_sizes": [N], "note": "N = 1: the same workload as the headline line"}
+
+    extras = {}
     Lout = L - PL + 1
-    nb = min(N, 20_000)                        # 20k x 189 x 200 x 2 B = 1.5 GB per launch
-    dense = torch.empty((Lout, nb, K), dtype=torch.int16, device="cuda")
-    ctx.enable_timing(False)
-    for _ in range(2):
-        ctx.pwm_scan_dense_dev(bank, lens, dcodes.data_ptr(), nb, L, dense.data_ptr(), Lout)
-    ctx.enable_timing(True)
-    ctx.reset_timing()
-    for _ in range(5):
-        ctx.pwm_scan_dense_dev(bank, lens, dcodes.data_ptr(), nb, L, dense.data_ptr(), Lout)
-    dense_ms, dense_n = ctx.kernel_ms(lib.KS_SCAN_DENSE)
-    ctx.enable_timing(False)
-    dense_bytes = nb * L + K * 4 * PL * 2 + nb * K * Lout * 2      # SURVEY §8d dense-score contract
-    dense_gbs = dense_bytes / (dense_ms / dense_n * 1e-3) / 1e9
-    # full-size check of the dense tensor against the hit records of the same reads (forward strand): the same
-    # number of positive entries and the same sum of score bit patterns
-    nrec = ctx.pwm_scan_hits_dev(bank, lens, dcodes.data_ptr(), nb, L, 0, hits[0].data_ptr(), hsc[0].data_ptr(), cap, n0=rank * N)
-    pos = dense > 0
-    dense_pos = int(pos.sum().item())
-    dense_sum = int(dense[pos].to(torch.int64).sum().item())
-    rec_sum = int(hsc[0][:nrec].to(torch.int64).sum().item())
-    assert dense_pos == nrec and dense_sum == rec_sum, f"dense tensor disagrees with the hit records: {dense_pos} vs {nrec}"
-    del dense, pos
+    hits, hsc, need, cap, dcodes = weak["hits"], weak["hsc"], weak["need"], weak["cap"], weak["codes"]
+    if not args.no_extras:
+        # ---- the a17 kernel on its own: dense (K, nb, L-len+1) fp16 scores (untimed extra leg) ----
+        nb = min(N, 20_000)                        # 20k x 189 x 200 x 2 B = 1.5 GB per launch
+        dense = torch.empty((Lout, nb, K), dtype=torch.int16, device=dev)
+        for _ in range(2):
+            ctx.pwm_scan_dense_dev(bank, lens, dcodes.data_ptr(), nb, L, dense.data_ptr(), Lout)
+        ctx.enable_timing(True)
+        ctx.reset_timing()
+        for _ in range(5):
+            ctx.pwm_scan_dense_dev(bank, lens, dcodes.data_ptr(), nb, L, dense.data_ptr(), Lout)
+        dense_ms, dense_n = ctx.kernel_ms(lib.KS_SCAN_DENSE)
+        ctx.enable_timing(False)
+        dense_bytes = nb * L + K * 4 * PL * 2 + nb * K * Lout * 2      # SURVEY §8d dense-score contract
+        dense_gbs = dense_bytes / (dense_ms / dense_n * 1e-3) / 1e9
+        # full-size check of the dense tensor against the hit records of the same reads (forward strand): the same
+        # number of positive entries and the same sum of score bit patterns
+        nrec = ctx.pwm_scan_hits_dev(bank, lens, dcodes.data_ptr(), nb, L, 0, hits[0].data_ptr(), hsc[0].data_ptr(), cap, n0=rank * N)
+        pos = dense > 0
+        dense_pos = int(pos.sum().item())
+        dense_sum = int(dense[pos].to(torch.int64).sum().item())
+        rec_sum = int(hsc[0][:nrec].to(torch.int64).sum().item())
+        assert dense_pos == nrec and dense_sum == rec_sum, f"dense tensor disagrees with the hit records: {dense_pos} vs {nrec}"
+        del dense, pos
 
-    # ---- the consumers of the records on the forward-strand records of this shard ----
-    post = pkg.post
-    nrec = ctx.pwm_scan_hits_dev(bank, lens, dcodes.data_ptr(), N, L, 0, hits[0].data_ptr(), hsc[0].data_ptr(), cap, n0=0)
+        # ---- the consumers of the records on the forward-strand records of this shard ----
+        post = pkg.post
+        nrec = ctx.pwm_scan_hits_dev(bank, lens, dcodes.data_ptr(), N, L, 0, hits[0].data_ptr(), hsc[0].data_ptr(), cap, n0=0)
 
-    def _ms(fn, reps=3):
-        fn()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(reps):
+        def _ms(fn, reps=3):
             fn()
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / reps * 1e3
-    mn, mx = post.score_range(ctx, hits[0], hsc[0], nrec, K)
-    thr, _ = post.sweep_thresholds(mn, mx)
-    thr_t = torch.from_numpy(np.ascontiguousarray(thr).view(np.int16)).cuda()
-    cnt_t = torch.zeros(thr.shape, dtype=torch.int64, device="cuda")
-    mn_t = torch.empty(K, dtype=torch.int16, device="cuda")
-    mx_t = torch.empty(K, dtype=torch.int16, device="cuda")
-    th_t = torch.from_numpy(np.ascontiguousarray(thr[:, thr.shape[1] // 2]).view(np.int16)).cuda()
-    oh_t, os_t = torch.empty_like(hits[0]), torch.empty_like(hsc[0])
-    cm_t = torch.zeros((K, int(lens.max()), 4), dtype=torch.int32, device="cuda")
-    consumers = {
-        "records": int(nrec),
-        "score_range_ms": _ms(lambda: ctx.hits_minmax_dev(hits[0].data_ptr(), hsc[0].data_ptr(), nrec, K, mn_t.data_ptr(), mx_t.data_ptr())),
-        "threshold_sweep_ms": _ms(lambda: ctx.hits_threshold_counts_dev(hits[0].data_ptr(), hsc[0].data_ptr(), nrec, K, thr_t.data_ptr(),
-                                                                         thr.shape[1], cnt_t.data_ptr())),
-        "threshold_sweep_steps": int(thr.shape[1]),
-        "filter_ms": _ms(lambda: ctx.hits_filter_dev(hits[0].data_ptr(), hsc[0].data_ptr(), nrec, K, th_t.data_ptr(), oh_t.data_ptr(),
-                                                      os_t.data_ptr())),
-        "count_matrices_ms": _ms(lambda: ctx.hits_count_matrices_dev(hits[0].data_ptr(), nrec, dcodes.data_ptr(), L, 0, lens, K,
-                                                                      int(lens.max()), 0, cm_t.data_ptr())),
-        "note": "SURVEY 8f rows 2-3 on the forward-strand records of the shard, wall time per call incl. launch and sync",
-    }
-    del oh_t, os_t
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            sync()
+            return (time.perf_counter() - t0) / reps * 1e3
+        mn, mx = post.score_range(ctx, hits[0], hsc[0], nrec, K)
+        thr, _ = post.sweep_thresholds(mn, mx)
+        thr_t = torch.from_numpy(np.ascontiguousarray(thr).view(np.int16)).to(dev)
+        cnt_t = torch.zeros(thr.shape, dtype=torch.int64, device=dev)
+        mn_t = torch.empty(K, dtype=torch.int16, device=dev)
+        mx_t = torch.empty(K, dtype=torch.int16, device=dev)
+        th_t = torch.from_numpy(np.ascontiguousarray(thr[:, thr.shape[1] // 2]).view(np.int16)).to(dev)
+        oh_t, os_t = torch.empty_like(hits[0]), torch.empty_like(hsc[0])
+        cm_t = torch.zeros((K, int(lens.max()), 4), dtype=torch.int32, device=dev)
+        extras["record_consumers"] = {
+            "records": int(nrec),
+            "score_range_ms": _ms(lambda: ctx.hits_minmax_dev(hits[0].data_ptr(), hsc[0].data_ptr(), nrec, K, mn_t.data_ptr(), mx_t.data_ptr())),
+            "threshold_sweep_ms": _ms(lambda: ctx.hits_threshold_counts_dev(hits[0].data_ptr(), hsc[0].data_ptr(), nrec, K, thr_t.data_ptr(),
+                                                                             thr.shape[1], cnt_t.data_ptr())),
+            "threshold_sweep_steps": int(thr.shape[1]),
+            "filter_ms": _ms(lambda: ctx.hits_filter_dev(hits[0].data_ptr(), hsc[0].data_ptr(), nrec, K, th_t.data_ptr(), oh_t.data_ptr(),
+                                                          os_t.data_ptr())),
+            "count_matrices_ms": _ms(lambda: ctx.hits_count_matrices_dev(hits[0].data_ptr(), nrec, dcodes.data_ptr(), L, 0, lens, K,
+                                                                          int(lens.max()), 0, cm_t.data_ptr())),
+            "note": "SURVEY 8f rows 2-3 on the forward-strand records of the shard, wall time per call incl. launch and sync",
+        }
+        del oh_t, os_t
 
-    # ---- attainable HBM rates in this run: a device copy and a fill of ~1 GB, torch kernels ----
-    def _rate(fn, nbytes, reps=10):
-        for _ in range(3):
-            fn()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        return nbytes / (e0.elapsed_time(e1) / reps * 1e-3) / 1e9
-    hx = torch.empty(1 << 29, dtype=torch.int16, device="cuda")
-    hy = torch.empty_like(hx)
-    hbm_fill_gbs = _rate(lambda: hx.zero_(), hx.numel() * 2)
-    hbm_copy_gbs = _rate(lambda: hy.copy_(hx), 2 * hx.numel() * 2)
-    del hx, hy
+        # ---- attainable HBM rates in this run: a device copy and a fill of ~1 GB, torch kernels ----
+        def _rate(fn, nbytes, reps=10):
+            for _ in range(3):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            sync()
+            return nbytes / (e0.elapsed_time(e1) / reps * 1e-3) / 1e9
+        hx = torch.empty(1 << 29, dtype=torch.int16, device=dev)
+        hy = torch.empty_like(hx)
+        hbm_fill_gbs = _rate(lambda: hx.zero_(), hx.numel() * 2)
+        hbm_copy_gbs = _rate(lambda: hy.copy_(hx), 2 * hx.numel() * 2)
+        del hx, hy
+        extras["dense_kernel"] = {
+            "kernel": "scan_cand_kernel_u<3,4> + stage_hits<12,.,2> (a17 greedy_search! drop-in, writes (K,nb,L-len+1) fp16: zeros + exact scores of the hits, every byte once)",
+            "checked": "positive entries == hit records of the same reads, score checksums equal",
+            "bound": "hbm", "achieved": dense_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": dense_gbs / HBM_PEAK_GBS, "frac_of_measured_fill": dense_gbs / hbm_fill_gbs,
+            "avg_launch_ms": dense_ms / dense_n, "seqs_per_launch": nb,
+            "bases_per_s_one_strand": nb * L / (dense_ms / dense_n * 1e-3),
+        }
+        extras["hbm_measured"] = {"fill_gbs": hbm_fill_gbs, "copy_gbs_read_plus_write": hbm_copy_gbs,
+                                  "note": "torch zero_() / copy_() of 1 GiB in this run; nominal peak 8000 GB/s"}
+
+        # ---- the entry a Julia `ccall` binds: host f32 one-hot in, host records out (_h3_1_alignment.jl:57-87, x2 strands) ----
+        if rank == 0:
+            onehot = sy.codes_to_onehot(codes)                          # (N, 4L) f32 = the bytes of data.data_matrix (4L,1,N)
+            cap_h = int(max(need))
+            ctx.pwm_scan(bank, lens, onehot, lib.DATA_ONEHOT_F32, N, L, False, cap=cap_h)      # warm-up (buffers, bank cache)
+            t0 = time.perf_counter()
+            n_h = 0
+            for rc in (False, True):
+                f, _ = ctx.pwm_scan(bank, lens, onehot, lib.DATA_ONEHOT_F32, N, L, rc, cap=cap_h)
+                n_h += len(f)
+            hdt = time.perf_counter() - t0
+            assert n_h == sum(need), (n_h, need)
+            extras["host_entry"] = {
+                "entry": "motifs_pwm_scan (host Float32 one-hot matrix in, host records out), one call per strand as gpu_scan makes them",
+                "bases_per_s": N * L / hdt, "ms_both_strands": hdt * 1e3,
+                "h2d_bytes_per_strand": int(onehot.nbytes), "d2h_bytes_both_strands": int(n_h * 14),
+                "note": "PCIe-inclusive and pageable host memory: upload of 16 B/base per strand, download of 14 B/hit; never `value`",
+            }
+            del onehot
 
     # ---- conv-train step (BASELINE metric, second half): unrolled-ADMM forward/backward + AdaBelief ----
     train = None
     if not args.no_train:
-        md, par = pkg.model, pkg.parallel
+        md = pkg.model
         hp = md.Hyperparam(filter_len=args.filter_len, M=args.filters)
         Gt = args.train_groups
         St = Gt * hp.batch_size
         cdl = md.ucdl(hp, L, ctx=ctx, seed=seed, arena_bytes=int((1.3 * Gt + 2) * (1 << 30)))
         tcodes = sy.gen_codes(St, L, seed + 77 + 1000 * rank, n_plant=5, k=args.filter_len)
-        traw = torch.from_numpy(tcodes).cuda()
-        tdev = torch.zeros(lib.Context.codes_bytes(St, L), dtype=torch.uint8, device="cuda")
+        traw = torch.from_numpy(tcodes).to(dev)
+        tdev = torch.zeros(lib.Context.codes_bytes(St, L), dtype=torch.uint8, device=dev)
         ctx.encode_dev(traw.data_ptr(), lib.DATA_CODES_U8, St, L, tdev.data_ptr())
-        tloss = torch.zeros(Gt, dtype=torch.float32, device="cuda")
-        tgrad = torch.zeros(cdl.model.nP, dtype=torch.float32, device="cuda")
-        par.dp_train_step(cdl.model, tdev.data_ptr(), Gt, tloss, tgrad, Gt * world)        # warm-up
-        torch.cuda.synchronize()
+        tloss = torch.zeros(Gt, dtype=torch.float32, device=dev)
+        tgrad = torch.zeros(cdl.model.nP, dtype=torch.float32, device=dev)
+
+        def tstep(g):
+            par.dp_train_step(cdl.model, tdev.data_ptr(), g, tloss, tgrad, g * world, reducer=reducer)
+        tstep(Gt)                                                   # warm-up
+        sync()
         ctx.enable_timing(True)
         ctx.reset_timing()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.train_steps):
-            par.dp_train_step(cdl.model, tdev.data_ptr(), Gt, tloss, tgrad, Gt * world)
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        tdt = time.perf_counter() - t0
+        tdt, _ = timed_region(lambda: tstep(Gt), args.train_steps, sync, barrier)
         ctx.enable_timing(False)
         if world > 1:
-            tt = torch.tensor([tdt], dtype=torch.float64, device="cuda")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            tdt = float(tt.item())
+            tdt = float(par.host_all_reduce(torch.tensor([tdt], dtype=torch.float64), dist.ReduceOp.MAX).item())
         gms, gn = ctx.kernel_ms(lib.KS_TRAIN_STEP)
+        # the reference's own schedule: one optimiser step per 6-read mini-batch (train.jl:40-46)
+        for _ in range(3):
+            tstep(1)
+        g1_steps = 20
+        g1dt, _ = timed_region(lambda: tstep(1), g1_steps, sync, barrier)
         train = {
             "workload": f"unrolled-ADMM sparse coding, {Gt} mini-batches x {hp.batch_size} reads x {L} bp per GPU per "
                         f"optimiser step, {args.filters} filters len {args.filter_len}, h=12 K=24 q=32, 6+3 passes, f32",
@@ -281,13 +371,16 @@ def main():
             "seqs_per_s": St * world * args.train_steps / tdt,
             "bases_per_s": St * world * L * args.train_steps / tdt,
             "device_ms_fwd_bwd": gms / max(gn, 1),
+            "ms_per_step_g1": g1dt / g1_steps * 1e3,
+            "seqs_per_s_g1": hp.batch_size * world * g1_steps / g1dt,
+            "g1_note": "reference schedule (train.jl:40-46): one AdaBelief step per mini-batch of 6 reads per GPU; launch-bound",
             "loss_first_group": float(tloss[0].item()),
             "grad_allreduce_floats": int(cdl.model.nP) if world > 1 else 0,
             "reference_schedule_equivalent": f"{Gt * world} reference steps (batch 6) worth of reads per step",
             "graph": ("the reference's graph with its common subexpressions formed once (the syntax-layer synthesis with an unchanged "
                       "bank) and ADMM_DF's residuals telescoped (R_1 = 0, R_t = -theta_{t-2}; identical values, "
                       "tests/test_model_gpu.py::test_df_telescoping_equals_literal_sequence); MOTIFS_DF_LITERAL=1 runs the literal "
-                      "sequence (+1.4 ms per step at this shape)"),
+                      "sequence"),
         }
         cdl.model.close()
 
@@ -313,11 +406,12 @@ def main():
     pass_gbs = alg_bytes / (pass_ms * 1e-3) / 1e9
     cand_flops = 2.0 * 4 * PL * K * float(N) * Lout
     cand_tflops = cand_flops / (cand_ms * 1e-3) / 1e12
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_scan_hbm_traffic.json")       # separate --pmc passes (tools/pmc_scan.sh)
-    if os.path.exists(tpath) and (N, L, K, PL) == (100_000, 200, 200, 12):
-        with open(tpath) as fh:
-            traffic = json.load(fh).get("scan_cand_kernel", {}).get("hbm_bytes_per_launch")
+    traffic, traffic_src = None, None
+    if os.path.exists(TRAFFIC_FILE) and (N, L, K, PL) == (100_000, 200, 200, 12):
+        with open(TRAFFIC_FILE) as fh:
+            tj = json.load(fh)
+        traffic = tj.get("scan_cand_kernel", {}).get("hbm_bytes_per_launch")
+        traffic_src = {"file": os.path.relpath(TRAFFIC_FILE, ROOT), "commit": tj.get("commit"), "command": tj.get("command")}
     out = {
         "metric": "bases scanned/sec",
         "value": value,
@@ -334,8 +428,8 @@ def main():
         "config": {
             "workload": f"PWM log-odds scan, both strands, {N} seqs x {L} bp per GPU vs {K} PWMs len {PL} "
                         "(BASELINE configs[1]); hits thresholded (>0) and compacted on device in reference order",
-            "seqs_per_gpu": N, "seq_len": L, "pwms": K, "pwm_len": PL, "hits_per_step": int(nhits),
-            "parallelism": f"sequence shards x{world}, all-reduce of the {K}-entry hit histogram only",
+            "seqs_per_gpu": N, "seq_len": L, "pwms": K, "pwm_len": PL, "hits_per_step": int(tot_hits.item()),
+            "parallelism": f"sequence shards x{world}; per step one sum of the 2 x {K} hit histogram: {reducer.kind} ({reducer_note})",
         },
         "roofline": {
             "kernel": "scan_cand_kernel_u<3,4> (v_mfma_f32_32x32x16_f16 candidate filter, one strand of the shard per launch)",
@@ -345,6 +439,7 @@ def main():
             "unit": "TFLOP/s",
             "frac": cand_tflops / MFMA_F16_PEAK_TFLOPS,
             "traffic": traffic,
+            "traffic_source": traffic_src,
             "flops_per_launch": cand_flops,
             "avg_launch_ms": cand_ms,
         },
@@ -355,54 +450,58 @@ def main():
             "note": "fused-hits contract (N*L codes in, 14 B per hit out, no dense score tensor): the pass is bound "
                     "by the matrix cores and the exact re-scoring, not by HBM; dense_kernel is the a17 dense-score contract",
         },
-        "dense_kernel": {
-            "kernel": "scan_cand_kernel_u<3,4> + stage_hits<12,.,2> (a17 greedy_search! drop-in, writes (K,nb,L-len+1) fp16: zeros + exact scores of the hits, every byte once)",
-            "checked": "positive entries == hit records of the same reads, score checksums equal",
-            "bound": "hbm", "achieved": dense_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": dense_gbs / HBM_PEAK_GBS, "frac_of_measured_fill": dense_gbs / hbm_fill_gbs,
-            "avg_launch_ms": dense_ms / dense_n, "seqs_per_launch": nb,
-            "bases_per_s_one_strand": nb * L / (dense_ms / dense_n * 1e-3),
-        },
-        "record_consumers": consumers,
-        "hbm_measured": {"fill_gbs": hbm_fill_gbs, "copy_gbs_read_plus_write": hbm_copy_gbs,
-                         "note": "torch zero_() / copy_() of 1 GiB in this run; nominal peak 8000 GB/s"},
+        "strong": strong,
         "kernel_ms_per_step": {"scan_cand": kms["count"][0] / args.steps, "stage_hits_row_scan": kms["offsets"][0] / args.steps,
                                "emit_records": kms["fill"][0] / args.steps},
     }
-
+    out.update(extras)
     if train is not None:
         out["train"] = train
 
     if not args.no_cpu and world == 1:
         from oracle import scan_oracle as so
 
+        # (1) the optimised port: AVX2/F16C, 8 PWMs per register, same rounding sequence, OpenMP on every host core;
+        #     one warm-up, best of three
         ns = min(args.cpu_sample, N)
-        onehot = sy.codes_to_onehot(codes[:ns])
+        best, c_hits = None, 0
+        for rep in range(4):
+            t0 = time.perf_counter()
+            got = [so.get_pos_scores_arr_fast(bank, lens, codes[:ns], rc=rc, cap_hint=int(max(need) * ns / N * 1.2) + 1024) for rc in (False, True)]
+            t = time.perf_counter() - t0
+            if got[0] is None:
+                break
+            c_hits = sum(len(g[0]) for g in got)
+            if rep > 0:
+                best = t if best is None else min(best, t)
+        # (2) the literal restatement (dense (K, nb, 4L) tensor, soft binary16 per multiply and add, findall), one run
+        nl = min(args.cpu_literal_sample, N)
+        onehot = sy.codes_to_onehot(codes[:nl])
         t0 = time.perf_counter()
-        c_hits = 0
-        for rc in (False, True):
-            f, _ = so.get_pos_scores_arr(bank, lens, onehot, rc=rc)
-            c_hits += len(f)
-        cdt = time.perf_counter() - t0
-        # cross-check the sample against the GPU records of the same sequences
-        g = sum(int((hits[rc][: need[rc], 1] <= ns).sum().item()) for rc in (0, 1))
-        t0 = time.perf_counter()
-        for rc in (False, True):
-            so.scan_gather(bank if not rc else bank, lens, codes[:ns])
-        gdt = time.perf_counter() - t0
-        out["cpu_baseline"] = {
-            "value": ns * L / cdt, "unit": "bases/s", "cores": so.num_threads(), "kind": "port",
-            "sample": f"first {ns} sequences x {L} bp, both strands, reference-faithful C restatement "
-                      f"(dense fp16 tensor + findall, OpenMP), {cdt:.2f} s; hits {c_hits} (GPU on the same "
-                      f"sequences: {g})",
-            "optimised_port_value": ns * L / gdt,
-            "optimised_port_note": "gather formulation (one add per position, no dense 4L dim), same threads",
-        }
-        out["gpu_over_cpu"] = value / (ns * L / cdt)
+        lit = [so.get_pos_scores_arr(bank, lens, onehot, rc=rc) for rc in (False, True)]
+        ldt = time.perf_counter() - t0
+        # both against the GPU records of the same reads
+        g_ns = sum(int((hits[rc][: need[rc], 1] <= ns).sum().item()) for rc in (0, 1))
+        g_nl = sum(int((hits[rc][: need[rc], 1] <= nl).sum().item()) for rc in (0, 1))
+        assert sum(len(x[0]) for x in lit) == g_nl, "literal CPU port and GPU disagree on the sample"
+        if best is not None:
+            assert c_hits == g_ns, "vectorised CPU port and GPU disagree on the sample"
+            out["cpu_baseline"] = {
+                "value": ns * L / best, "unit": "bases/s", "cores": so.num_threads(), "kind": "port",
+                "sample": f"first {ns} sequences x {L} bp, both strands; AVX2/F16C port of the reference arithmetic (8 PWMs per register, "
+                          f"binary16 rounding after every add, records in findall order), OpenMP, 1 warm-up + best of 3: {best:.2f} s; "
+                          f"hits {c_hits} == GPU on the same reads",
+                "literal": {"value": nl * L / ldt, "unit": "bases/s", "kind": "port-literal", "cores": so.num_threads(),
+                            "sample": f"first {nl} sequences, dense (K, nb, 4L) soft-binary16 tensor + findall as the reference does it, one run: {ldt:.2f} s"},
+            }
+        else:
+            out["cpu_baseline"] = {"value": nl * L / ldt, "unit": "bases/s", "cores": so.num_threads(), "kind": "port",
+                                   "sample": f"host CPU lacks AVX2/F16C: literal soft-binary16 port on the first {nl} sequences, {ldt:.2f} s"}
+        out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
         if train is not None:
-            # the reference-faithful oracle (full-lag conv_code_diff etc.) needs ~220 s per mini-batch at
-            # configs[1] on 8 cores, so the CPU leg of the train step is timed at configs[0] shape
-            # (100 bp, 32 filters of length 8) for BOTH sides
+            # the reference-faithful float64 restatement (full-lag conv_code_diff etc.) needs ~50 minutes per mini-batch at
+            # configs[1], so the CPU leg of the train step is timed at configs[0] shape (100 bp, 32 filters of length 8)
+            # for BOTH sides
             from oracle import model_oracle as mo
             import torch as _t
 

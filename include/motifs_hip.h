@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MOTIFS_ABI_VERSION 1
+#define MOTIFS_ABI_VERSION 2
 
 enum motifs_status {
     MOTIFS_OK = 0,
@@ -39,7 +39,8 @@ enum motifs_status {
     MOTIFS_ERR_BUFFER_TOO_SMALL = 4, /* *n_out holds the required record count           */
     MOTIFS_ERR_NOT_ONEHOT = 5,   /* a data column is not exactly one-hot / all-zero      */
     MOTIFS_ERR_NONFINITE = 6,    /* PWM bank holds NaN/Inf (reference semantics differ)  */
-    MOTIFS_ERR_UNSUPPORTED = 7   /* e.g. maxlen > MOTIFS_SCAN_MAX_LEN                    */
+    MOTIFS_ERR_UNSUPPORTED = 7,  /* e.g. maxlen > MOTIFS_SCAN_MAX_LEN                    */
+    MOTIFS_ERR_COMM = 8          /* RCCL missing or a collective failed                  */
 };
 
 /* Encodings accepted for a sequence matrix. */
@@ -57,7 +58,8 @@ enum motifs_hit_order {
     MOTIFS_ORDER_REFERENCE = 0
 };
 
-#define MOTIFS_SCAN_MAX_LEN 32          /* longest PWM supported by the scan kernels */
+#define MOTIFS_SCAN_MAX_LEN 64          /* longest PWM supported by the scan kernels (the reference has no cap,
+                                         * _h3_1_alignment.jl:25-31; motif length is d13 + h, _2_enumerate.jl:43) */
 #define MOTIFS_SCAN_BATCH 5000          /* batch_size_greedy, _h3_1_alignment.jl:12  */
 
 typedef struct motifs_ctx motifs_ctx;   /* opaque: device id, stream, workspaces */
@@ -78,9 +80,16 @@ const char* motifs_last_error(void);
 /* Fails with MOTIFS_ERR_NO_DEVICE when no GPU is visible. */
 int motifs_ctx_create(int device, motifs_ctx** out);
 void motifs_ctx_destroy(motifs_ctx* ctx);
-/* Use an existing hipStream_t (e.g. torch's current stream); NULL = own stream. */
+/* A context starts on a private non-blocking stream.  motifs_ctx_set_stream makes it enqueue on the caller's
+ * hipStream_t instead (NULL = HIP's null stream, which is what torch's default "current stream" is);
+ * motifs_ctx_get_stream returns the stream in use, so a host framework can order its own work against it
+ * (e.g. torch.cuda.ExternalStream).  Every `*_dev` entry point and every collective below runs on that stream. */
 int motifs_ctx_set_stream(motifs_ctx* ctx, void* hip_stream);
+int motifs_ctx_get_stream(motifs_ctx* ctx, void** hip_stream_out);
 int motifs_ctx_synchronize(motifs_ctx* ctx);
+/* Upper bound in bytes for the scan's candidate / staging workspace (0 = the default, 8 GiB).  A scan that needs
+ * more walks the reads in super-batches of whole ordering batches; the records do not depend on the bound. */
+int motifs_ctx_set_workspace_limit(motifs_ctx* ctx, size_t bytes);
 /* Per-kernel device time, measured with HIP events on the context stream
  * around every launch of that kernel (each timed launch synchronises, so leave
  * timing off outside measurements).  `slot` is a motifs_kernel_slot; *ms is the
@@ -214,11 +223,50 @@ int motifs_model_l1_syntax(motifs_model* m, float* out);
 /* Host-buffer form of one loop body of train.jl:40-52 (what Julia's ccall binds): codes = n_groups *
  * batch_size rows of L bytes (0..3).  n_groups == 1 is exactly the reference's step. */
 int motifs_model_train_step(motifs_model* m, const uint8_t* codes, int n_groups, float* loss_out, float* l1F_out);
+/* The same step on the reference's own batch format: S = `data.data_matrix[:, :, batch]`, the bytes of a
+ * (4L, 1, n_groups*batch_size) Float32 one-hot array (train.jl:33,41; loadfasta/helpers.jl:110-139), so a Julia
+ * caller passes the DataLoader's batch unchanged.  MOTIFS_ERR_NOT_ONEHOT if a column is neither one-hot nor zero. */
+int motifs_model_train_step_onehot(motifs_model* m, const float* S, int n_groups, float* loss_out, float* l1F_out);
 /* Replaces code_retrieval (_1_code_retrieval.jl:33-56).  data: host matrix of `kind`, N sequences. */
 int motifs_model_retrieve_codes(motifs_model* m, const void* data, int kind, int64_t N, motifs_code_rec* out,
                                 int64_t cap, int64_t* n_out);
 /* Test hook: a named intermediate of the last loss_grad call made with keep_intermediates != 0. */
 int motifs_model_dump(motifs_model* m, const char* name, float* out, int64_t cap, int64_t* n);
+
+/* ---- multi-GPU: RCCL over xGMI behind the ABI (SURVEY.md §5 last row, §8e) ----------------------------- */
+
+/* The reference is single-GPU (src/MOTIFs.jl:4-8 imports no communication package): these entry points are new.
+ * Reads shard over devices in contiguous blocks; parameters and the PWM bank are replicated; the only exchanges are
+ * one sum of the flat gradient [dD | dF | dvecs] per optimiser step and one sum of the K hit counts per scan.
+ * librccl.so is opened on first use (MOTIFS_ERR_COMM if it cannot be); every collective is in place and is
+ * enqueued on the stream of the communicator's context, behind the kernels that produced its operand. */
+typedef struct motifs_comm motifs_comm;
+#define MOTIFS_COMM_ID_BYTES 128
+/* ncclGetUniqueId: rank 0 makes the id, the host carries it to the other ranks (any channel). */
+int motifs_comm_unique_id(uint8_t id[MOTIFS_COMM_ID_BYTES]);
+/* One rank of an nranks communicator on ctx's device (ncclCommInitRank): one process per GPU, or one host thread
+ * per device.  Collective: returns when every rank has joined. */
+int motifs_comm_create(motifs_ctx* ctx, const uint8_t id[MOTIFS_COMM_ID_BYTES], int nranks, int rank, motifs_comm** out);
+/* All ranks of a single-process communicator over the devices of ctxs[0..n_dev) (ncclCommInitAll): the form a
+ * single Julia process driving the 8 GPUs of a node uses; bracket the per-device collective calls of one step
+ * with motifs_comm_group_start / _end (ncclGroupStart / ncclGroupEnd). */
+int motifs_comm_create_all(motifs_ctx* const* ctxs, int n_dev, motifs_comm** out);
+void motifs_comm_destroy(motifs_comm* comm);
+int motifs_comm_rank(motifs_comm* comm, int* rank, int* nranks);
+int motifs_comm_group_start(void);
+int motifs_comm_group_end(void);
+int motifs_comm_allreduce_sum_f32_dev(motifs_comm* comm, float* buf_dev, int64_t n);
+int motifs_comm_allreduce_sum_i64_dev(motifs_comm* comm, int64_t* buf_dev, int64_t n);
+/* Sum over ranks of the flat gradient motifs_model_loss_grad_dev wrote (nD + nF + nV floats). */
+int motifs_model_allreduce_grad(motifs_model* m, motifs_comm* comm, float* grad_flat_dev);
+/* Sum over ranks of the per-PWM hit counts of a scan (K int64 per strand, n_strands = 1 or 2). */
+int motifs_hist_allreduce(motifs_comm* comm, int64_t* per_pwm_counts_dev, int K, int n_strands);
+/* One data-parallel optimiser step: gradient of this rank's n_groups_local mini-batches (0 is allowed: the rank
+ * contributes zeros and still takes part in the exchange) -> sum over ranks -> AdaBelief with the mean over the
+ * n_groups_total mini-batches of all ranks, identical on every rank, so the replicas stay bit-identical.
+ * comm == NULL: single device.  grad_flat_dev: nD + nF + nV floats of scratch; loss_dev: n_groups_local floats. */
+int motifs_model_dp_train_step_dev(motifs_model* m, motifs_comm* comm, const uint8_t* codes_dev, int n_groups_local,
+                                   int64_t n_groups_total, float* loss_dev, float* grad_flat_dev);
 
 /* ---- either side of the scan ----------------------------------------------------- */
 

@@ -1,69 +1,294 @@
-# MotifsHIP.jl — thin ccall shim over libmotifs_hip.so (include/motifs_hip.h).
-# NOT executed in the build image (Julia is not installed there); it transliterates the four call sites of
-# INTEGRATION.md.  No CUDA.jl / AMDGPU.jl / Flux / NNlib on the path.
+# MotifsHIP.jl — ccall shim over libmotifs_hip.so (include/motifs_hip.h, ABI 2).
+#
+# Host code stays in Julia; no CUDA.jl / AMDGPU.jl / Flux / NNlib on the path.  The functions below carry the
+# reference's names and argument meaning, so `discover_motifs` (src/wrap.jl:1-11) needs the four substitutions shown
+# in INTEGRATION.md and nothing else.  Julia is not installed in the build image: this file is checked there by
+# tests/test_julia_shim.py (every ccall against the header: symbol, arity, argument and return types), not executed.
 module MotifsHIP
 
+import Random
+
 const lib = get(ENV, "MOTIFS_HIP_LIB", "libmotifs_hip.so")
+const float_type = Float32                      # src/MOTIFs.jl:14
+const float_type_retrieval = Float16            # src/inference/_0_const.jl:1
+const batch_size_greedy = 5000                  # src/inference/_h3_1_alignment.jl:12
+const COMM_ID_BYTES = 128
 
 struct HParams           # motifs_hparams == Hyperparam (src/model.jl:1-14)
     filter_len::Int32; M::Int32; h::Int32; K::Int32; q::Int32; batch_size::Int32
     num_pass_xyz::Int32; num_pass_df::Int32; magnifying_factor::Float32; gamma::Float32
 end
-HParams(; filter_len=8, M=50, h=12, K=24, q=32, batch_size=6, num_pass_xyz=6, num_pass_df=3,
-        magnifying_factor=10f0, gamma=0.1f0) =
+Hyperparam(; filter_len=8, M=50, h=12, K=24, q=32, batch_size=6, num_pass_xyz=6, num_pass_df=3,
+           magnifying_factor=10f0, gamma=0.1f0) =
     HParams(filter_len, M, h, K, q, batch_size, num_pass_xyz, num_pass_df, magnifying_factor, gamma)
 
-const CodeRec = NamedTuple{(:position, :fil, :seq, :mag), Tuple{UInt16, UInt16, UInt32, Float16}}  # _0_const.jl:3-4
+# stored_code_component_t (_0_const.jl:3-4): 12-byte isbits records, the layout of motifs_code_rec
+const stored_code_component_t = NamedTuple{(:position, :fil, :seq, :mag), Tuple{UInt16, UInt16, UInt32, Float16}}
+const record_t = NTuple{3, UInt32}              # _h3_1_alignment.jl:10 == motifs_hit
 
-check(rc) = rc == 0 || error(unsafe_string(ccall((:motifs_last_error, lib), Cstring, ())))
+last_error() = unsafe_string(ccall((:motifs_last_error, lib), Cstring, ()))
+check(rc) = rc == 0 || error("libmotifs_hip status $rc: " * last_error())
+abi_version() = ccall((:motifs_abi_version, lib), Cint, ())
 
-function context(device::Integer=0)
-    h = Ref{Ptr{Cvoid}}(C_NULL)
-    check(ccall((:motifs_ctx_create, lib), Cint, (Cint, Ref{Ptr{Cvoid}}), device, h))
-    h[]
+# ---- context ---------------------------------------------------------------------------------------------------
+mutable struct Context
+    h::Ptr{Cvoid}
+    device::Int
+    function Context(device::Integer=0)
+        r = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:motifs_ctx_create, lib), Cint, (Cint, Ref{Ptr{Cvoid}}), device, r))
+        c = new(r[], device)
+        finalizer(close, c)
+        c
+    end
+end
+function Base.close(c::Context)
+    c.h == C_NULL || ccall((:motifs_ctx_destroy, lib), Cvoid, (Ptr{Cvoid},), c.h)
+    c.h = C_NULL
+    nothing
+end
+synchronize(c::Context) = check(ccall((:motifs_ctx_synchronize, lib), Cint, (Ptr{Cvoid},), c.h))
+set_stream!(c::Context, stream::Ptr{Cvoid}) = check(ccall((:motifs_ctx_set_stream, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), c.h, stream))
+function get_stream(c::Context)
+    r = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:motifs_ctx_get_stream, lib), Cint, (Ptr{Cvoid}, Ref{Ptr{Cvoid}}), c.h, r))
+    r[]
+end
+set_workspace_limit!(c::Context, bytes::Integer) =
+    check(ccall((:motifs_ctx_set_workspace_limit, lib), Cint, (Ptr{Cvoid}, Csize_t), c.h, bytes))
+
+const default_context = Ref{Union{Nothing, Context}}(nothing)
+context() = (default_context[] === nothing && (default_context[] = Context(0)); default_context[])
+
+# ---- the model: train.jl:29-35 (Hyperparam(), length_info, projectors, ucdl(hp), Flux.params, AdaBelief()) -------------
+mutable struct ucdl
+    h::Ptr{Cvoid}
+    ctx::Context
+    hp::HParams
+    L::Int
+    nD::Int64; nF::Int64; nV::Int64; c::Int64; l::Int64
+    function ucdl(hp::HParams, L::Integer; ctx::Context=context(), seed=rand(UInt64), arena_bytes::Integer=0)
+        r = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:motifs_model_create, lib), Cint, (Ptr{Cvoid}, Ref{HParams}, Cint, Csize_t, Ref{Ptr{Cvoid}}),
+                    ctx.h, Ref(hp), L, arena_bytes, r))
+        nD = Ref{Int64}(0); nF = Ref{Int64}(0); nV = Ref{Int64}(0); c = Ref{Int64}(0); l = Ref{Int64}(0)
+        check(ccall((:motifs_model_sizes, lib), Cint, (Ptr{Cvoid}, Ref{Int64}, Ref{Int64}, Ref{Int64}, Ref{Int64}, Ref{Int64}),
+                    r[], nD, nF, nV, c, l))
+        m = new(r[], ctx, hp, L, nD[], nF[], nV[], c[], l[])
+        finalizer(close, m)
+        check(ccall((:motifs_model_init_random, lib), Cint, (Ptr{Cvoid}, UInt64), m.h, seed))   # ucdl(hp), model.jl:84-100
+        m
+    end
+end
+function Base.close(m::ucdl)
+    (m.h == C_NULL || m.ctx.h == C_NULL) || ccall((:motifs_model_destroy, lib), Cvoid, (Ptr{Cvoid},), m.h)
+    m.h = C_NULL
+    nothing
 end
 
-function model(ctx, hp::HParams, L::Integer; seed=nothing, arena_bytes=0)
-    h = Ref{Ptr{Cvoid}}(C_NULL)
-    check(ccall((:motifs_model_create, lib), Cint, (Ptr{Cvoid}, Ref{HParams}, Cint, Csize_t, Ref{Ptr{Cvoid}}),
-                ctx, Ref(hp), L, arena_bytes, h))
-    seed === nothing || check(ccall((:motifs_model_init_random, lib), Cint, (Ptr{Cvoid}, UInt64), h[], seed))
-    h[]
+# cdl.D (f_len, 1, M) and cdl.F (h, twoM, 1, K) in the reference's layouts (model.jl:84-90); also .warmup (3) and .vecs
+function get_params(m::ucdl)
+    hp = m.hp
+    D = Array{Float32}(undef, 4 * hp.filter_len, 1, hp.M)
+    F = Array{Float32}(undef, hp.h, 2 * hp.M, 1, hp.K)
+    warm = Vector{Float32}(undef, 3); vecs = Vector{Float32}(undef, m.nV)
+    GC.@preserve D F warm vecs check(ccall((:motifs_model_get_params, lib), Cint,
+        (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}), m.h, D, F, warm, vecs))
+    (D=D, F=F, warmup=warm, vecs=vecs)
+end
+function set_params!(m::ucdl; D=nothing, F=nothing, warmup=nothing, vecs=nothing)
+    p(x) = x === nothing ? Ptr{Float32}(C_NULL) : pointer(x)
+    a = map(x -> x === nothing ? nothing : Array{Float32}(x), (D, F, warmup, vecs))
+    GC.@preserve a check(ccall((:motifs_model_set_params, lib), Cint,
+        (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}), m.h, p(a[1]), p(a[2]), p(a[3]), p(a[4])))
+end
+function Base.getproperty(m::ucdl, s::Symbol)
+    s === :D && return get_params(m).D
+    s === :F && return get_params(m).F
+    getfield(m, s)
 end
 
-# train.jl:40-52 — codes: (L, n_groups*batch_size) UInt8 matrix, bases 0..3, one read per column
-function train_step!(m, codes::Matrix{UInt8}, n_groups::Integer)
+function l1_syntax(m::ucdl)                       # sum(abs.(prep_syntax_filters(cdl.F))), train.jl:47
+    r = Ref{Float32}(0)
+    check(ccall((:motifs_model_l1_syntax, lib), Cint, (Ptr{Cvoid}, Ref{Float32}), getfield(m, :h), r))
+    r[]
+end
+
+# train.jl:41-52 for one DataLoader batch S = data.data_matrix[:, :, idx]: (4L, 1, n_groups * batch_size) Float32
+function train_step!(m::ucdl, S::Array{Float32,3}, n_groups::Integer=1)
+    loss = Vector{Float32}(undef, n_groups); l1 = Ref{Float32}(0)
+    GC.@preserve S loss check(ccall((:motifs_model_train_step_onehot, lib), Cint,
+        (Ptr{Cvoid}, Ptr{Float32}, Cint, Ptr{Float32}, Ref{Float32}), getfield(m, :h), S, n_groups, loss, l1))
+    loss, l1[]
+end
+# the same on base codes: (L, n_groups * batch_size) UInt8, 0..3 = A,C,G,T, one read per column
+function train_step!(m::ucdl, codes::Matrix{UInt8}, n_groups::Integer=1)
     loss = Vector{Float32}(undef, n_groups); l1 = Ref{Float32}(0)
     GC.@preserve codes loss check(ccall((:motifs_model_train_step, lib), Cint,
-        (Ptr{Cvoid}, Ptr{UInt8}, Cint, Ptr{Float32}, Ref{Float32}), m, codes, n_groups, loss, l1))
+        (Ptr{Cvoid}, Ptr{UInt8}, Cint, Ptr{Float32}, Ref{Float32}), getfield(m, :h), codes, n_groups, loss, l1))
     loss, l1[]
 end
 
-# _1_code_retrieval.jl:33-56 — data_matrix: (4L, 1, N) Float32 one-hot
-function code_retrieval(m, data_matrix::Array{Float32,3}; cap=size(data_matrix, 3) * 128)
-    out = Vector{CodeRec}(undef, cap); n = Ref{Int64}(0)
-    GC.@preserve data_matrix out check(ccall((:motifs_model_retrieve_codes, lib), Cint,
-        (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Int64, Ptr{Cvoid}, Int64, Ref{Int64}),
-        m, data_matrix, 1, size(data_matrix, 3), out, cap, n))
+function setup_num_epochs(number_training_samples)  # train.jl:1-11
+    number_training_samples < 1000 && return 25
+    number_training_samples < 10000 && return 10
+    number_training_samples < 100000 && return 5
+    return 3
+end
+
+# train.jl:13-58.  Returns (cdl, hp, len, projs) like the reference; len and projs only encode "stride 4" and
+# "needed lags" and have no counterpart here (nothing), the callers below do not use them.
+# groups_per_step = 1 is the reference's schedule (one AdaBelief step per mini-batch of hp.batch_size reads).
+function train_ucdl(data; num_epochs=nothing, l1_loss_thresh=float_type(95.0), hp::HParams=Hyperparam(),
+                    groups_per_step::Integer=1, ctx::Context=context(), verbose::Bool=false)
+    L4, _, N = size(data.data_matrix)
+    cdl = ucdl(hp, L4 ÷ 4; ctx=ctx)
+    num_epochs = isnothing(num_epochs) ? setup_num_epochs(N) : num_epochs
+    B = Int(hp.batch_size); per_step = B * groups_per_step
+    nfull = (N ÷ B) * B                              # DataLoader(partial=false)
+    break_condition = false
+    for i in 1:num_epochs
+        order = Random.randperm(N)                   # DataLoader(shuffle=true)
+        for i0 in 1:per_step:nfull
+            idx = order[i0:min(i0 + per_step - 1, nfull)]
+            g = length(idx) ÷ B
+            S = data.data_matrix[:, :, idx[1:g * B]]
+            loss, l1_loss = train_step!(cdl, S, g)
+            verbose && println("loss $(sum(loss) / g)")   # model.jl:392
+            if l1_loss < l1_loss_thresh
+                break_condition = true
+                break
+            end
+        end
+        break_condition && break
+        println("Epoch: $i completed")
+    end
+    return cdl, hp, nothing, nothing
+end
+
+# _1_code_retrieval.jl:33-56 — same signature; data.data_matrix: (4L, 1, N) Float32 one-hot
+function code_retrieval(data, cdl::ucdl, hp=nothing, len=nothing, projs=nothing)
+    dm = data.data_matrix
+    N = size(dm, 3)
+    cap = N * max(4 * Int(getfield(cdl, :hp).q), 64)
+    out = Vector{stored_code_component_t}(undef, cap); n = Ref{Int64}(0)
+    rc = GC.@preserve dm out ccall((:motifs_model_retrieve_codes, lib), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Int64, Ptr{Cvoid}, Int64, Ref{Int64}), getfield(cdl, :h), dm, 1, N, out, cap, n)
+    if rc == 4                                       # MOTIFS_ERR_BUFFER_TOO_SMALL: n holds the required count
+        cap = n[]; resize!(out, cap)
+        rc = GC.@preserve dm out ccall((:motifs_model_retrieve_codes, lib), Cint,
+            (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Int64, Ptr{Cvoid}, Int64, Ref{Int64}), getfield(cdl, :h), dm, 1, N, out, cap, n)
+    end
+    check(rc)
     resize!(out, n[])
 end
 
-# _h3_1_alignment.jl:57-87
-function get_pos_scores_arr(ctx, pwm_list::Vector{Matrix{Float16}}, lens::Vector{Int}, data_matrix::Array{Float32,3}; rc=false)
-    L4, _, N = size(data_matrix); K = length(pwm_list); maxlen = maximum(lens)
-    pwms = zeros(Float16, K, 4, maxlen)
-    for i in 1:K; pwms[i, :, 1:lens[i]] = pwm_list[i]; end
-    lens64 = Int64.(lens); n = Ref{Int64}(0)
-    sig = (Ptr{Cvoid}, Ptr{UInt16}, Ptr{Int64}, Cint, Cint, Ptr{Cvoid}, Cint, Int64, Cint, Cint, Ptr{Cvoid}, Ptr{UInt16},
-           Int64, Ref{Int64}, Ptr{Int64})
-    GC.@preserve pwms lens64 data_matrix begin
-        check(ccall((:motifs_pwm_scan, lib), Cint, sig, ctx, pwms, lens64, K, maxlen, data_matrix, 1, N, L4 ÷ 4, rc,
-                    C_NULL, C_NULL, 0, n, C_NULL))
-        found = Vector{NTuple{3,UInt32}}(undef, n[]); score = Vector{Float16}(undef, n[])
-        check(ccall((:motifs_pwm_scan, lib), Cint, sig, ctx, pwms, lens64, K, maxlen, data_matrix, 1, N, L4 ÷ 4, rc,
-                    found, score, n[], n, C_NULL))
-        return found, score
+# ---- PWM scan: _h3_1_alignment.jl:38-112 -------------------------------------------------------------------------
+data_(data; test=false) = test ? data.data_matrix_test : data.data_matrix
+data_bg(data; test=false) = test ? data.data_matrix_bg_test : data.data_matrix_bg
+
+function get_pos_scores_arr(ms, data; rc=false, bg=false, test=false, ctx::Context=context())
+    data_matrix = bg ? data_bg(data; test=test) : data_(data; test=test)
+    length(size(data_matrix)) == 2 && (data_matrix = reshape(data_matrix, (size(data_matrix, 1), 1, size(data_matrix, 2))))
+    data_matrix = Array{Float32}(data_matrix)
+    L4, _, N = size(data_matrix)
+    K = ms.num_motifs; maxlen = maximum(ms.lens)
+    pwms = zeros(float_type_retrieval, K, 4, maxlen)            # :65-67, forward bank; the library applies reverse() for rc
+    for i in 1:K; pwms[i, :, 1:ms.lens[i]] = ms.pwms[i]; end
+    lens = Int64.(ms.lens); n = Ref{Int64}(0)
+    cap = max(1024, (N * (L4 ÷ 4) * K) ÷ 64)                    # first guess; a too-small buffer costs one more call
+    found = Vector{record_t}(undef, cap); score = Vector{float_type_retrieval}(undef, cap)
+    status = GC.@preserve pwms lens data_matrix found score ccall((:motifs_pwm_scan, lib), Cint,
+        (Ptr{Cvoid}, Ptr{UInt16}, Ptr{Int64}, Cint, Cint, Ptr{Cvoid}, Cint, Int64, Cint, Cint, Ptr{Cvoid}, Ptr{UInt16},
+         Int64, Ref{Int64}, Ptr{Int64}),
+        ctx.h, pwms, lens, K, maxlen, data_matrix, 1, N, L4 ÷ 4, rc, found, score, cap, n, C_NULL)
+    if status == 4                                              # MOTIFS_ERR_BUFFER_TOO_SMALL
+        cap = n[]; resize!(found, cap); resize!(score, cap)
+        status = GC.@preserve pwms lens data_matrix found score ccall((:motifs_pwm_scan, lib), Cint,
+            (Ptr{Cvoid}, Ptr{UInt16}, Ptr{Int64}, Cint, Cint, Ptr{Cvoid}, Cint, Int64, Cint, Cint, Ptr{Cvoid}, Ptr{UInt16},
+             Int64, Ref{Int64}, Ptr{Int64}),
+            ctx.h, pwms, lens, K, maxlen, data_matrix, 1, N, L4 ÷ 4, rc, found, score, cap, n, C_NULL)
+    end
+    check(status)
+    resize!(found, n[]); resize!(score, n[])
+    return found, score
+end
+
+motifs_prep(ms) = ([Dict{Int, Vector{Int}}() for _ in 1:ms.num_motifs], [Dict{Int, Vector{float_type_retrieval}}() for _ in 1:ms.num_motifs],
+                   [Dict{Int, Vector{Bool}}() for _ in 1:ms.num_motifs])     # _s1_make_motifs.jl:185-190
+
+function modify_w_found!(found_record, score_record, positions, scores, use_comp; rc=false)   # :38-52, unchanged
+    comp = rc ? true : false
+    @inbounds for (f, s) in zip(found_record, score_record)
+        m, n, l = f[1], f[2], f[3]
+        if haskey(positions[m], n)
+            push!(positions[m][n], l); push!(scores[m][n], s); push!(use_comp[m][n], comp)
+        else
+            positions[m][n] = [l]; scores[m][n] = [s]; use_comp[m][n] = [comp]
+        end
     end
 end
+
+function gpu_scan(ms, data; bg=false, test=false, ctx::Context=context())      # :89-99
+    found_record, score_record = get_pos_scores_arr(ms, data; rc=false, bg=bg, test=test, ctx=ctx)
+    found_record_rc, score_record_rc = get_pos_scores_arr(ms, data; rc=true, bg=bg, test=test, ctx=ctx)
+    positions, scores, use_comp = motifs_prep(ms)
+    modify_w_found!(found_record, score_record, positions, scores, use_comp; rc=false)
+    modify_w_found!(found_record_rc, score_record_rc, positions, scores, use_comp; rc=true)
+    return positions, scores, use_comp
+end
+
+function scan_w_gpu!(ms, data; bg=false, ctx::Context=context())               # :101-112
+    positions, scores, use_comp = gpu_scan(ms, data; bg=bg, ctx=ctx)
+    if bg
+        ms.positions_bg = positions; ms.scores_bg = scores; ms.use_comp_bg = use_comp
+    else
+        ms.positions = positions; ms.scores = scores; ms.use_comp = use_comp
+    end
+end
+
+# ---- multi-GPU: one Context per device, RCCL behind the ABI (no reference counterpart; SURVEY.md §8e) -----------------------
+mutable struct Comm
+    h::Ptr{Cvoid}
+    ctx::Context
+end
+# one Julia process driving the n devices of a node (ncclCommInitAll)
+function comm_create_all(ctxs::Vector{Context})
+    hs = [c.h for c in ctxs]; out = fill(Ptr{Cvoid}(C_NULL), length(ctxs))
+    GC.@preserve hs out check(ccall((:motifs_comm_create_all, lib), Cint, (Ptr{Ptr{Cvoid}}, Cint, Ptr{Ptr{Cvoid}}), hs, length(ctxs), out))
+    [Comm(out[i], ctxs[i]) for i in eachindex(ctxs)]
+end
+# one process (or task) per device: rank 0 makes the id, the host carries it to the others
+function comm_unique_id()
+    id = Vector{UInt8}(undef, COMM_ID_BYTES)
+    GC.@preserve id check(ccall((:motifs_comm_unique_id, lib), Cint, (Ptr{UInt8},), id))
+    id
+end
+function comm_create(ctx::Context, id::Vector{UInt8}, nranks::Integer, rank::Integer)
+    r = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve id check(ccall((:motifs_comm_create, lib), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Cint, Cint, Ref{Ptr{Cvoid}}), ctx.h, id, nranks, rank, r))
+    Comm(r[], ctx)
+end
+Base.close(c::Comm) = (c.h == C_NULL || ccall((:motifs_comm_destroy, lib), Cvoid, (Ptr{Cvoid},), c.h); c.h = C_NULL; nothing)
+function comm_rank(c::Comm)
+    r = Ref{Cint}(0); n = Ref{Cint}(0)
+    check(ccall((:motifs_comm_rank, lib), Cint, (Ptr{Cvoid}, Ref{Cint}, Ref{Cint}), c.h, r, n))
+    Int(r[]), Int(n[])
+end
+group_start() = check(ccall((:motifs_comm_group_start, lib), Cint, ()))
+group_end() = check(ccall((:motifs_comm_group_end, lib), Cint, ()))
+allreduce_sum_f32!(c::Comm, buf_dev::Ptr{Cvoid}, n::Integer) =
+    check(ccall((:motifs_comm_allreduce_sum_f32_dev, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64), c.h, buf_dev, n))
+allreduce_sum_i64!(c::Comm, buf_dev::Ptr{Cvoid}, n::Integer) =
+    check(ccall((:motifs_comm_allreduce_sum_i64_dev, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64), c.h, buf_dev, n))
+allreduce_grad!(m::ucdl, c::Comm, grad_flat_dev::Ptr{Cvoid}) =
+    check(ccall((:motifs_model_allreduce_grad, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), getfield(m, :h), c.h, grad_flat_dev))
+hist_allreduce!(c::Comm, counts_dev::Ptr{Cvoid}, K::Integer, n_strands::Integer=1) =
+    check(ccall((:motifs_hist_allreduce, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cint), c.h, counts_dev, K, n_strands))
+# one data-parallel optimiser step on device-resident codes of this rank's mini-batches (motifs_encode_dev layout)
+dp_train_step!(m::ucdl, c::Union{Comm, Nothing}, codes_dev::Ptr{Cvoid}, n_groups_local::Integer, n_groups_total::Integer,
+               loss_dev::Ptr{Cvoid}, grad_flat_dev::Ptr{Cvoid}) =
+    check(ccall((:motifs_model_dp_train_step_dev, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Int64, Ptr{Cvoid}, Ptr{Cvoid}),
+                getfield(m, :h), c === nothing ? C_NULL : c.h, codes_dev, n_groups_local, n_groups_total, loss_dev, grad_flat_dev))
 
 end # module

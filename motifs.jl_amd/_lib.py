@@ -12,11 +12,13 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libmotifs_hip.so")
 
-OK, ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_BUFFER_TOO_SMALL, ERR_NOT_ONEHOT, ERR_NONFINITE, ERR_UNSUPPORTED = range(8)
+OK, ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_BUFFER_TOO_SMALL, ERR_NOT_ONEHOT, ERR_NONFINITE, ERR_UNSUPPORTED, ERR_COMM = range(9)
+ABI_VERSION = 2
+COMM_ID_BYTES = 128
 DATA_CODES_U8, DATA_ONEHOT_F32, DATA_ONEHOT_F16 = 0, 1, 2
 KS_ENCODE, KS_SCAN_DENSE, KS_SCAN_COUNT, KS_SCAN_OFFSETS, KS_SCAN_FILL, KS_TRAIN_STEP = range(6)
 SCAN_BATCH = 5000
-SCAN_MAX_LEN = 32
+SCAN_MAX_LEN = 64
 
 HIT_DTYPE = np.dtype([("m", "<u4"), ("n", "<u4"), ("l", "<u4")])
 # stored_code_component_t (_0_const.jl:3-4) with Julia's 12-byte isbits layout
@@ -51,6 +53,8 @@ SIGNATURES = {
     "motifs_ctx_create": (_int, [_int, C.POINTER(_p)]),
     "motifs_ctx_destroy": (None, [_p]),
     "motifs_ctx_set_stream": (_int, [_p, _p]),
+    "motifs_ctx_get_stream": (_int, [_p, C.POINTER(_p)]),
+    "motifs_ctx_set_workspace_limit": (_int, [_p, C.c_size_t]),
     "motifs_ctx_synchronize": (_int, [_p]),
     "motifs_ctx_enable_timing": (_int, [_p, _int]),
     "motifs_ctx_reset_timing": (_int, [_p]),
@@ -77,6 +81,19 @@ SIGNATURES = {
     "motifs_model_adabelief_dev": (_int, [_p, _p, C.c_float]),
     "motifs_model_l1_syntax": (_int, [_p, C.POINTER(C.c_float)]),
     "motifs_model_train_step": (_int, [_p, _p, _int, _p, C.POINTER(C.c_float)]),
+    "motifs_model_train_step_onehot": (_int, [_p, _p, _int, _p, C.POINTER(C.c_float)]),
+    "motifs_comm_unique_id": (_int, [_p]),
+    "motifs_comm_create": (_int, [_p, _p, _int, _int, C.POINTER(_p)]),
+    "motifs_comm_create_all": (_int, [C.POINTER(_p), _int, C.POINTER(_p)]),
+    "motifs_comm_destroy": (None, [_p]),
+    "motifs_comm_rank": (_int, [_p, C.POINTER(_int), C.POINTER(_int)]),
+    "motifs_comm_group_start": (_int, []),
+    "motifs_comm_group_end": (_int, []),
+    "motifs_comm_allreduce_sum_f32_dev": (_int, [_p, _p, _i64]),
+    "motifs_comm_allreduce_sum_i64_dev": (_int, [_p, _p, _i64]),
+    "motifs_model_allreduce_grad": (_int, [_p, _p, _p]),
+    "motifs_hist_allreduce": (_int, [_p, _p, _int, _int]),
+    "motifs_model_dp_train_step_dev": (_int, [_p, _p, _p, _int, _i64, _p, _p]),
     "motifs_model_retrieve_codes": (_int, [_p, _p, _int, _i64, _p, _i64, C.POINTER(_i64)]),
     "motifs_model_dump": (_int, [_p, C.c_char_p, _p, _i64, C.POINTER(_i64)]),
     "motifs_fasta_read": (_int, [C.c_char_p, _i64, _p, _i64, C.POINTER(_i64), C.POINTER(C.c_int32)]),
@@ -160,7 +177,18 @@ class Context:
             pass
 
     def set_stream(self, hip_stream_ptr):
-        check(lib().motifs_ctx_set_stream(self._h, _p(hip_stream_ptr)))
+        """Enqueue on the caller's hipStream_t; 0 / None = HIP's null stream (torch's default current stream)."""
+        check(lib().motifs_ctx_set_stream(self._h, _p(hip_stream_ptr or None)))
+
+    def get_stream(self):
+        """The hipStream_t in use as an integer (0 = the null stream), e.g. for torch.cuda.ExternalStream."""
+        out = _p()
+        check(lib().motifs_ctx_get_stream(self._h, C.byref(out)))
+        return out.value or 0
+
+    def set_workspace_limit(self, nbytes):
+        """Bound of the scan's candidate/staging workspace (0 = default 8 GiB); larger scans run in super-batches."""
+        check(lib().motifs_ctx_set_workspace_limit(self._h, int(nbytes)))
 
     def synchronize(self):
         check(lib().motifs_ctx_synchronize(self._h))
@@ -378,6 +406,24 @@ class Model:
                                             C.byref(l1) if want_l1 else None))
         return loss, l1.value
 
+    def train_step_onehot(self, S, n_groups, want_l1=True):
+        """train.jl:41-52 on the reference's batch format: S = bytes of the (4L, 1, n_groups*batch_size) Float32 array."""
+        S = np.ascontiguousarray(S, dtype=np.float32)
+        assert S.size == n_groups * self.hp.batch_size * 4 * self.L, S.shape
+        loss = np.zeros(n_groups, np.float32)
+        l1 = C.c_float(0)
+        check(lib().motifs_model_train_step_onehot(self._h, _np_ptr(S), int(n_groups), _np_ptr(loss),
+                                                   C.byref(l1) if want_l1 else None))
+        return loss, l1.value
+
+    def dp_train_step_dev(self, comm, codes_ptr, n_groups_local, n_groups_total, loss_ptr, grad_ptr):
+        """One data-parallel optimiser step (comm: a Comm or None for a single device)."""
+        check(lib().motifs_model_dp_train_step_dev(self._h, comm._h if comm is not None else None, _p(codes_ptr), int(n_groups_local),
+                                                   int(n_groups_total), _p(loss_ptr), _p(grad_ptr)))
+
+    def allreduce_grad(self, comm, grad_ptr):
+        check(lib().motifs_model_allreduce_grad(self._h, comm._h, _p(grad_ptr)))
+
     def retrieve_codes(self, data, kind, N, cap=None):
         data = np.ascontiguousarray(data)
         n_out = _i64(0)
@@ -393,3 +439,41 @@ class Model:
         out = np.zeros(n.value, np.float32)
         check(lib().motifs_model_dump(self._h, name.encode(), _np_ptr(out), n.value, C.byref(n)))
         return out
+
+
+class Comm:
+    """Owns a motifs_comm: one rank of an RCCL communicator on a context's device (collectives run on its stream)."""
+
+    def __init__(self, ctx, uid, nranks, rank):
+        self.ctx = ctx
+        self._h = _p()
+        uid = np.frombuffer(bytes(uid), dtype=np.uint8)
+        assert uid.size == COMM_ID_BYTES
+        check(lib().motifs_comm_create(ctx._h, _np_ptr(uid), int(nranks), int(rank), C.byref(self._h)))
+        self.rank, self.nranks = int(rank), int(nranks)
+
+    @staticmethod
+    def unique_id():
+        uid = np.zeros(COMM_ID_BYTES, dtype=np.uint8)
+        check(lib().motifs_comm_unique_id(_np_ptr(uid)))
+        return uid.tobytes()
+
+    def allreduce_sum_f32(self, ptr, n):
+        check(lib().motifs_comm_allreduce_sum_f32_dev(self._h, _p(ptr), int(n)))
+
+    def allreduce_sum_i64(self, ptr, n):
+        check(lib().motifs_comm_allreduce_sum_i64_dev(self._h, _p(ptr), int(n)))
+
+    def hist_allreduce(self, counts_ptr, K, n_strands=1):
+        check(lib().motifs_hist_allreduce(self._h, _p(counts_ptr), int(K), int(n_strands)))
+
+    def close(self):
+        if getattr(self, "_h", None) and getattr(self.ctx, "_h", None):
+            lib().motifs_comm_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

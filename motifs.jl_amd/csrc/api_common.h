@@ -60,6 +60,7 @@ struct motifs_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     uint32_t timing = 0;            // bit s set: launches of slot s are timed
+    size_t ws_limit = (size_t)8 << 30;   // bound of the scan's candidate/staging workspace (motifs_ctx_set_workspace_limit)
     bool scan_valu = false;      // MOTIFS_SCAN_VALU=1: hit records through the all-VALU mask kernel (cross-check path)
     // timing: event pairs are recorded around launches without synchronising and
     // resolved when the totals are read (motifs_ctx_kernel_ms)

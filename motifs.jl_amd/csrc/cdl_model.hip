@@ -528,6 +528,45 @@ int motifs_model_adabelief_dev(motifs_model* m, const float* grad_flat_dev, floa
     return MOTIFS_OK;
 }
 
+// The exchange of the data-parallel step: one in-place sum of the flat gradient over the ranks, on the
+// context's stream, i.e. behind the backward kernels that wrote it and in front of the AdaBelief kernel.
+int motifs_model_allreduce_grad(motifs_model* m, motifs_comm* comm, float* grad_flat_dev) {
+    int r = check_model(m, "motifs_model_allreduce_grad");
+    if (r) return r;
+    if (!comm || !grad_flat_dev) {
+        set_error("motifs_model_allreduce_grad: comm or gradient is NULL");
+        return MOTIFS_ERR_INVALID;
+    }
+    return motifs_comm_allreduce_sum_f32_dev(comm, grad_flat_dev, (int64_t)m->nP);
+}
+
+// train.jl:42-46 for a shard: local summed gradient -> sum over ranks -> AdaBelief on the mean over all mini-batches.
+// Every rank applies the same update to the same parameters, so the replicas never diverge.  A rank without
+// mini-batches (more ranks than mini-batches, or the tail of an uneven split) contributes zeros and still joins
+// the exchange: skipping it would leave the other ranks waiting in the all-reduce.
+int motifs_model_dp_train_step_dev(motifs_model* m, motifs_comm* comm, const uint8_t* codes_dev, int n_groups_local,
+                                   int64_t n_groups_total, float* loss_dev, float* grad_flat_dev) {
+    int r = check_model(m, "motifs_model_dp_train_step_dev");
+    if (r) return r;
+    if (!grad_flat_dev || n_groups_local < 0 || n_groups_total < 1 || n_groups_total < n_groups_local ||
+        (!comm && n_groups_local != n_groups_total)) {
+        set_error("motifs_model_dp_train_step_dev: bad argument (local=%d total=%lld)", n_groups_local, (long long)n_groups_total);
+        return MOTIFS_ERR_INVALID;
+    }
+    MOTIFS_HIP_CHECK(hipSetDevice(m->ctx->device));
+    if (n_groups_local > 0) {
+        r = motifs_model_loss_grad_dev(m, codes_dev, n_groups_local, loss_dev, grad_flat_dev, 0);
+        if (r) return r;
+    } else {
+        MOTIFS_HIP_CHECK(hipMemsetAsync(grad_flat_dev, 0, m->nP * 4, m->ctx->stream));
+    }
+    if (comm) {
+        r = motifs_model_allreduce_grad(m, comm, grad_flat_dev);
+        if (r) return r;
+    }
+    return motifs_model_adabelief_dev(m, grad_flat_dev, (float)(1.0 / (double)n_groups_total));
+}
+
 // sum(abs.(prep_syntax_filters(cdl.F))) (train.jl:47): the early-stop statistic
 int motifs_model_l1_syntax(motifs_model* m, float* out) {
     int r = check_model(m, "motifs_model_l1_syntax");
@@ -549,21 +588,31 @@ int motifs_model_l1_syntax(motifs_model* m, float* out) {
 }
 
 // One optimiser step on host data: the body of the loop at train.jl:40-52 for n_groups mini-batches
-// (n_groups = 1 is exactly the reference step).  codes: n_groups*batch_size rows of L bytes (0..3).
-int motifs_model_train_step(motifs_model* m, const uint8_t* codes, int n_groups, float* loss_out, float* l1F_out) {
-    int r = check_model(m, "motifs_model_train_step");
-    if (r) return r;
-    if (!codes || n_groups < 1) return MOTIFS_ERR_INVALID;
+// (n_groups = 1 is exactly the reference step).  data: n_groups*batch_size reads of `kind`.
+static int train_step_host(motifs_model* m, const void* data, int kind, int n_groups, float* loss_out, float* l1F_out) {
     MOTIFS_HIP_CHECK(hipSetDevice(m->ctx->device));
     motifs_ctx* c = m->ctx;
     const int64_t S = (int64_t)n_groups * m->B;
+    const size_t elt = kind == MOTIFS_DATA_ONEHOT_F32 ? 16 : kind == MOTIFS_DATA_ONEHOT_F16 ? 8 : 1;
+    const size_t raw = ((size_t)S * m->L * elt + 63) & ~(size_t)63;
     MOTIFS_HIP_CHECK(c->codes.reserve(motifs_codes_bytes(S, m->L)));
-    MOTIFS_HIP_CHECK(c->data_tmp.reserve((size_t)S * m->L + m->nP * 4 + (size_t)n_groups * 4 + 64));
-    MOTIFS_HIP_CHECK(hipMemcpyAsync(c->data_tmp.p, codes, (size_t)S * m->L, hipMemcpyHostToDevice, c->stream));
-    r = motifs_encode_dev(c, c->data_tmp.p, MOTIFS_DATA_CODES_U8, S, m->L, (uint8_t*)c->codes.p, nullptr);
-    if (r) return r;
-    float* gflat = (float*)((char*)c->data_tmp.p + (((size_t)S * m->L + 63) & ~(size_t)63));
+    MOTIFS_HIP_CHECK(c->data_tmp.reserve(raw + m->nP * 4 + (size_t)n_groups * 4 + 128));
+    MOTIFS_HIP_CHECK(hipMemcpyAsync(c->data_tmp.p, data, (size_t)S * m->L * elt, hipMemcpyHostToDevice, c->stream));
+    float* gflat = (float*)((char*)c->data_tmp.p + raw);
     float* lossd = gflat + m->nP;
+    int32_t* bad_dev = (int32_t*)(lossd + n_groups);
+    MOTIFS_HIP_CHECK(hipMemsetAsync(bad_dev, 0, 4, c->stream));
+    int r = motifs_encode_dev(c, c->data_tmp.p, kind, S, m->L, (uint8_t*)c->codes.p, bad_dev);
+    if (r) return r;
+    if (kind != MOTIFS_DATA_CODES_U8) {       // a batch that is not one-hot must not reach the optimiser
+        int32_t* h_bad = (int32_t*)((char*)c->pinned + 64);
+        MOTIFS_HIP_CHECK(hipMemcpyAsync(h_bad, bad_dev, 4, hipMemcpyDeviceToHost, c->stream));
+        MOTIFS_HIP_CHECK(hipStreamSynchronize(c->stream));
+        if (*h_bad) {
+            set_error("training batch has a column that is neither one-hot nor all-zero");
+            return MOTIFS_ERR_NOT_ONEHOT;
+        }
+    }
     r = motifs_model_loss_grad_dev(m, (const uint8_t*)c->codes.p, n_groups, lossd, gflat, 0);
     if (r) return r;
     r = motifs_model_adabelief_dev(m, gflat, 1.0f / (float)n_groups);
@@ -572,6 +621,22 @@ int motifs_model_train_step(motifs_model* m, const uint8_t* codes, int n_groups,
     MOTIFS_HIP_CHECK(hipStreamSynchronize(c->stream));
     if (l1F_out) return motifs_model_l1_syntax(m, l1F_out);
     return MOTIFS_OK;
+}
+
+// codes: n_groups*batch_size rows of L bytes (0..3).
+int motifs_model_train_step(motifs_model* m, const uint8_t* codes, int n_groups, float* loss_out, float* l1F_out) {
+    int r = check_model(m, "motifs_model_train_step");
+    if (r) return r;
+    if (!codes || n_groups < 1) return MOTIFS_ERR_INVALID;
+    return train_step_host(m, codes, MOTIFS_DATA_CODES_U8, n_groups, loss_out, l1F_out);
+}
+
+// S: the reference's own batch, `S = data.data_matrix[:, :, batch]` (train.jl:33,41): (4L, 1, n_groups*batch_size) Float32.
+int motifs_model_train_step_onehot(motifs_model* m, const float* S, int n_groups, float* loss_out, float* l1F_out) {
+    int r = check_model(m, "motifs_model_train_step_onehot");
+    if (r) return r;
+    if (!S || n_groups < 1) return MOTIFS_ERR_INVALID;
+    return train_step_host(m, S, MOTIFS_DATA_ONEHOT_F32, n_groups, loss_out, l1F_out);
 }
 
 // code_retrieval (_1_code_retrieval.jl:33-56): ADMM_XYZ only, batches of batch_size in file order,
@@ -595,7 +660,6 @@ int motifs_model_retrieve_codes(motifs_model* m, const void* data, int kind, int
     int64_t gmax = (int64_t)(m->arena_bytes / 2 / std::max<size_t>(per_group, 1));
     gmax = std::max<int64_t>(1, std::min<int64_t>(gmax, 65535 / m->B));
     const size_t elt = kind == MOTIFS_DATA_ONEHOT_F32 ? 16 : kind == MOTIFS_DATA_ONEHOT_F16 ? 8 : 1;
-    const int pitch = motifs_codes_pitch(m->L);
     int64_t total = 0;
     bool too_small = false;
     std::vector<int32_t> h_cnt;

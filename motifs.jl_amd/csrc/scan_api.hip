@@ -42,10 +42,6 @@ static int pack_bank(const uint16_t* pwms, const int64_t* lens, int K, int maxle
         set_error("pwm bank: null pointer or K/maxlen <= 0 (K=%d maxlen=%d)", K, maxlen);
         return MOTIFS_ERR_INVALID;
     }
-    if (maxlen > MOTIFS_SCAN_MAX_LEN) {
-        set_error("pwm bank: maxlen %d > MOTIFS_SCAN_MAX_LEN %d", maxlen, MOTIFS_SCAN_MAX_LEN);
-        return MOTIFS_ERR_UNSUPPORTED;
-    }
     int minlen = maxlen, maxtrue = 0;
     for (int k = 0; k < K; k++) {
         if (lens[k] < 1 || lens[k] > maxlen) {
@@ -54,6 +50,10 @@ static int pack_bank(const uint16_t* pwms, const int64_t* lens, int K, int maxle
         }
         minlen = std::min<int>(minlen, (int)lens[k]);
         maxtrue = std::max<int>(maxtrue, (int)lens[k]);
+    }
+    if (maxtrue > MOTIFS_SCAN_MAX_LEN) {      // the padded third dimension (maxlen) may be anything
+        set_error("pwm bank: longest PWM has %d positions > MOTIFS_SCAN_MAX_LEN %d", maxtrue, MOTIFS_SCAN_MAX_LEN);
+        return MOTIFS_ERR_UNSUPPORTED;
     }
     out.lenp = scan_len_padded(maxtrue);
     out.minlen = minlen;
@@ -183,6 +183,14 @@ static void pack_mfma(const PackedBank& bank, const int64_t* lens, int K, MfmaBa
     }
 }
 
+// padded PWM length of a bank (-1: longer than the kernels support); banks past 32 positions exist on the
+// matrix-core path only
+static int bank_lenp(const int64_t* lens, int K) {
+    int64_t mx = 0;
+    for (int k = 0; lens && k < K; k++) mx = std::max<int64_t>(mx, lens[k]);
+    return mx > MOTIFS_SCAN_MAX_LEN ? -1 : scan_len_padded((int)std::max<int64_t>(mx, 1));
+}
+
 static int pick_cpb(int nch) {
     int cpb = 1;
     while (cpb * 2 <= nch && cpb * 2 <= SCAN_WAVES) cpb *= 2;
@@ -205,6 +213,15 @@ static int upload_bank(motifs_ctx* c, const PackedBank& bank) {
     // the vectors die with the caller's frame: make sure the copies are done
     MOTIFS_HIP_CHECK(hipStreamSynchronize(c->stream));
     return MOTIFS_OK;
+}
+
+// hit records -> their places in the (K, N, ld_l) tensor (the fallback form of a17: zeros + hits)
+__global__ __launch_bounds__(256) void scatter_hits_dense(const HitRec* __restrict__ hits, const uint16_t* __restrict__ sc, int64_t n,
+                                                          int K, int64_t N, int64_t n0, uint16_t* __restrict__ dense) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const HitRec h = hits[i];
+    dense[(size_t)(h.m - 1) + (size_t)K * ((size_t)(h.n - 1 - n0) + (size_t)N * (h.l - 1))] = sc[i];
 }
 
 }  // namespace motifs
@@ -331,7 +348,7 @@ static int scan_hits_mfma(motifs_ctx* c, const BankSlot& bank, int K, const uint
     const int row_slots = 2 * rpr * bank.nch;                        // staged hits per row before the slow path
     const size_t per_batch = (size_t)Lout * batch * bank.nch * 16;
     const size_t stage_per_batch = emit ? (size_t)Lout * parts * row_slots * 4 : 0;
-    int64_t nb_max = (int64_t)((8ull << 30) / (per_batch + stage_per_batch));
+    int64_t nb_max = (int64_t)(c->ws_limit / (per_batch + stage_per_batch));
     nb_max = std::max<int64_t>(1, std::min<int64_t>(nb_max, (N + batch - 1) / batch));
     const int64_t sb = nb_max * batch;
     const int64_t rows_max = nb_max * Lout * parts;
@@ -458,13 +475,23 @@ int motifs_ctx_set_stream(motifs_ctx* c, void* hip_stream) {
     MOTIFS_HIP_CHECK(hipSetDevice(c->device));
     MOTIFS_HIP_CHECK(hipStreamSynchronize(c->stream));
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
-    if (hip_stream) {
-        c->stream = (hipStream_t)hip_stream;
-        c->own_stream = false;
-    } else {
-        MOTIFS_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-        c->own_stream = true;
-    }
+    // NULL is a stream too: HIP's null stream, which is what torch hands out as its default "current stream".
+    // (ABI 1 read NULL as "make a private stream": work queued by the host framework on its default stream was
+    // then silently unordered against the library's kernels.)
+    c->stream = (hipStream_t)hip_stream;
+    c->own_stream = false;
+    return MOTIFS_OK;
+}
+
+int motifs_ctx_get_stream(motifs_ctx* c, void** hip_stream_out) {
+    if (!c || !hip_stream_out) return MOTIFS_ERR_INVALID;
+    *hip_stream_out = (void*)c->stream;
+    return MOTIFS_OK;
+}
+
+int motifs_ctx_set_workspace_limit(motifs_ctx* c, size_t bytes) {
+    if (!c) return MOTIFS_ERR_INVALID;
+    c->ws_limit = bytes ? bytes : (size_t)8 << 30;
     return MOTIFS_OK;
 }
 
@@ -523,7 +550,8 @@ int motifs_pwm_scan_dense_dev(motifs_ctx* c, const uint16_t* pwms_fp16, const in
         set_error("motifs_pwm_scan_dense_dev: bad argument");
         return MOTIFS_ERR_INVALID;
     }
-    if (!c->scan_valu && K % 8 == 0) {
+    const int lenp0 = bank_lenp(lens, K);
+    if ((!c->scan_valu || lenp0 > 32) && K % 8 == 0) {
         // Matrix-core path: candidates (scan_cand_kernel) -> exact scores of the hits streamed into the tensor
         // together with the zeros around them (stage_hits, mode 2): every byte written once, in linear order.
         BankSlot* bs = nullptr;
@@ -552,6 +580,36 @@ int motifs_pwm_scan_dense_dev(motifs_ctx* c, const uint16_t* pwms_fp16, const in
             MOTIFS_HIP_CHECK(launch_stage_hits(f, 2, c->stream));
             return MOTIFS_OK;
         }
+    }
+    if (lenp0 > 32) {
+        // A long bank whose K is not a multiple of 8 (the streamed form needs 16-byte runs): zeros, then the hit
+        // records dropped into place.  Correct for any shape; not the fast path.
+        BankSlot* bs = nullptr;
+        int rcode = cached_bank(c, pwms_fp16, lens, K, maxlen, 0, L, &bs);
+        if (rcode) return rcode;
+        const int Lout = L - bs->minlen + 1;
+        if (ld_l < std::max(Lout, 0)) {
+            set_error("motifs_pwm_scan_dense_dev: ld_l=%lld < L-minlen+1=%d", (long long)ld_l, Lout);
+            return MOTIFS_ERR_INVALID;
+        }
+        if (N == 0) return MOTIFS_OK;
+        MOTIFS_HIP_CHECK(hipSetDevice(c->device));
+        KernelTimer t(c, KS_SCAN_DENSE);
+        MOTIFS_HIP_CHECK(hipMemsetAsync(scores_dev, 0, (size_t)K * N * ld_l * 2, c->stream));
+        if (Lout <= 0) return MOTIFS_OK;
+        int64_t need = 0;
+        rcode = scan_hits_mfma(c, *bs, K, codes_dev, N, L, Lout, 0, (int)std::min<int64_t>(N, MOTIFS_SCAN_BATCH), nullptr, nullptr, 0, &need, nullptr);
+        if (rcode) return rcode;
+        if (need == 0) return MOTIFS_OK;
+        MOTIFS_HIP_CHECK(c->hits_tmp.reserve((size_t)need * sizeof(motifs_hit)));
+        MOTIFS_HIP_CHECK(c->scores_tmp.reserve((size_t)need * 2));
+        rcode = scan_hits_mfma(c, *bs, K, codes_dev, N, L, Lout, 0, (int)std::min<int64_t>(N, MOTIFS_SCAN_BATCH), (motifs_hit*)c->hits_tmp.p,
+                               (uint16_t*)c->scores_tmp.p, need, &need, nullptr);
+        if (rcode) return rcode;
+        hipLaunchKernelGGL(scatter_hits_dense, dim3((unsigned)((need + 255) / 256)), dim3(256), 0, c->stream, (const HitRec*)c->hits_tmp.p,
+                           (const uint16_t*)c->scores_tmp.p, need, K, N, (int64_t)0, scores_dev);
+        MOTIFS_HIP_CHECK(hipGetLastError());
+        return MOTIFS_OK;
     }
     PackedBank bank;
     int rcode = pack_bank(pwms_fp16, lens, K, maxlen, 0, L, bank);
@@ -603,7 +661,7 @@ int motifs_pwm_scan_hits_dev(motifs_ctx* c, const uint16_t* pwms_fp16, const int
         return MOTIFS_ERR_INVALID;
     }
     *n_out = 0;
-    if (!c->scan_valu) {
+    if (!c->scan_valu || bank_lenp(lens, K) > 32) {
         BankSlot* bs = nullptr;
         const int rcode = cached_bank(c, pwms_fp16, lens, K, maxlen, rc, L, &bs);
         if (rcode) return rcode;
@@ -626,7 +684,7 @@ int motifs_pwm_scan_hits_dev(motifs_ctx* c, const uint16_t* pwms_fp16, const int
     const int LoutP = scan_lout_padded(Lout, bank.lenp);
     // super-batch: as many ordering batches as fit an ~8 GiB mask workspace
     const size_t per_batch = (size_t)LoutP * batch * bank.nch * 16;
-    int64_t nb_max = (int64_t)((8ull << 30) / per_batch);
+    int64_t nb_max = (int64_t)(c->ws_limit / per_batch);
     nb_max = std::max<int64_t>(1, std::min<int64_t>(nb_max, (N + batch - 1) / batch));
     const int64_t sb = nb_max * batch;
     const int64_t cells_max = (int64_t)nb_max * LoutP * batch * bank.nch;
@@ -740,7 +798,7 @@ int motifs_pwm_scan_hits_both_dev(motifs_ctx* c, const uint16_t* pwms_fp16, cons
     motifs_hit* hits[2] = {hits_fwd_dev, hits_rc_dev};
     uint16_t* scores[2] = {scores_fwd_dev, scores_rc_dev};
     n_out2[0] = n_out2[1] = 0;
-    const bool fast = !c->scan_valu && N > 0 && L > 0 && batch > 0 && cap >= 0 && codes_dev && n0 >= 0 && n0 + N <= 0xffffffffll &&
+    const bool fast = (!c->scan_valu || bank_lenp(lens, K) > 32) && N > 0 && L > 0 && batch > 0 && cap >= 0 && codes_dev && n0 >= 0 && n0 + N <= 0xffffffffll &&
                       (cap == 0 || (hits[0] && hits[1] && scores[0] && scores[1]));
     BankSlot* bs[2] = {nullptr, nullptr};
     if (fast) {

@@ -480,7 +480,7 @@ static hipError_t launch_len(int mode, const ScanArgs& a, dim3 grid, hipStream_t
 }
 
 int scan_len_padded(int maxlen) {
-    static const int sizes[] = {8, 12, 16, 20, 24, 32};
+    static const int sizes[] = {8, 12, 16, 20, 24, 32, 40, 48, 64};   // > 32: matrix-core path only
     for (int s : sizes)
         if (maxlen <= s) return s;
     return -1;

@@ -187,7 +187,7 @@ __global__ __launch_bounds__(512) void scan_cand_kernel(const uint4* __restrict_
 }
 // uniform slack: the wave fits 168 VGPRs, so three 4-wave blocks (2 reads x 2 tile groups, or 4 reads x 1) share a CU
 template <int T, int PG, int TGB>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(T * PG <= 16 ? 3 : 2, 4))) void scan_cand_kernel_u(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((T * PG <= 16 && PG > 1) ? 3 : 2, 4))) void scan_cand_kernel_u(
     const uint4* __restrict__ afrag, const uint8_t* __restrict__ codes, uint32_t* __restrict__ cells, const CandDims d) {
     scan_cand_body<T, PG, true, 4 / TGB, TGB>(afrag, nullptr, codes, cells, d);
 }
@@ -371,7 +371,7 @@ static __device__ __forceinline__ bool score_candidate(const FillArgs& a, const 
 // should be.  Needs K % 8 == 0 (16-byte stores).
 constexpr int DWIN = 512;         // halves per window (1 KB: one 16-byte store per lane)
 template <int LEN, bool LDS_TAB, int MODE>
-__global__ __launch_bounds__(VF_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void stage_hits(FillArgs a) {
+__global__ __launch_bounds__(VF_THREADS) __attribute__((amdgpu_waves_per_eu(LEN <= 32 ? 8 : 4, 8))) void stage_hits(FillArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: the row geometry stays on the scalar unit
     uint16_t* queue = (uint16_t*)smem + wv * QN;                      // [VF_WAVES][QN]
@@ -559,7 +559,8 @@ static hipError_t launch_cand_tp(const CandArgs& a, hipStream_t st) {
     return hipGetLastError();
 }
 
-int cand_tile_group(int lenp) { return lenp <= 20 ? 4 : 2; }
+// tiles of 32 PWMs a wave carries: its A fragments are PG * lenp / 4 registers x 4
+int cand_tile_group(int lenp) { return lenp <= 20 ? 4 : lenp <= 32 ? 2 : 1; }
 
 hipError_t launch_cand(const CandArgs& a, hipStream_t st) {
     switch (a.lenp) {
@@ -569,6 +570,9 @@ hipError_t launch_cand(const CandArgs& a, hipStream_t st) {
         case 20: return launch_cand_tp<5, 4>(a, st);
         case 24: return launch_cand_tp<6, 2>(a, st);
         case 32: return launch_cand_tp<8, 2>(a, st);
+        case 40: return launch_cand_tp<10, 1>(a, st);
+        case 48: return launch_cand_tp<12, 1>(a, st);
+        case 64: return launch_cand_tp<16, 1>(a, st);
         default: return hipErrorInvalidValue;
     }
 }
@@ -614,6 +618,9 @@ static hipError_t launch_emit_len(const FillArgs& a, hipStream_t st) {
         case 20: return CALL(20);           \
         case 24: return CALL(24);           \
         case 32: return CALL(32);           \
+        case 40: return CALL(40);           \
+        case 48: return CALL(48);           \
+        case 64: return CALL(64);           \
         default: return hipErrorInvalidValue; \
     }
 

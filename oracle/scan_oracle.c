@@ -218,6 +218,142 @@ void oracle_scan_gather(const uint16_t* pwms, const int64_t* lens, int K, const 
     }
 }
 
+/*
+ * The optimised CPU form of oracle_get_pos_scores_arr: what a careful CPU implementation of the SAME arithmetic
+ * looks like (bench.py's cpu_baseline, kind "port"; the literal loop above stays as "port-literal").
+ *   - gather form (one add per PWM position: the three w*0 = +-0 terms of :28-29 are exact no-ops);
+ *   - 8 PWMs per AVX register, binary16 adds as binary32 add + VCVTPS2PH (round to nearest even) + VCVTPH2PS:
+ *     the binary32 sum of two binary16 values rounded again to binary16 is the correctly rounded binary16 sum
+ *     (24 >= 2*11 + 2), i.e. the same bits as h_add, in the same order (ind ascending);
+ *   - no dense (K, nb, 4L) tensor: threads own ranges of start positions l of a batch and append their hits, the
+ *     ranges are concatenated in l order, which is findall's column-major order (k fastest, then n, then l).
+ * codes: N rows of L bytes 0..3 (4 = all-zero column).  Returns the number of hits (records past cap are dropped),
+ * or -1 when the CPU lacks AVX2/F16C (the caller falls back to the literal form).
+ */
+#include <immintrin.h>
+
+typedef struct {
+    oracle_hit* h;
+    uint16_t* s;
+    int64_t n, cap;
+} hitbuf;
+
+static void hb_push(hitbuf* b, uint32_t m, uint32_t n, uint32_t l, uint16_t sc) {
+    if (b->n == b->cap) {
+        b->cap = b->cap ? b->cap * 2 : 4096;
+        b->h = (oracle_hit*)realloc(b->h, (size_t)b->cap * sizeof(oracle_hit));
+        b->s = (uint16_t*)realloc(b->s, (size_t)b->cap * 2);
+    }
+    b->h[b->n].m = m;
+    b->h[b->n].n = n;
+    b->h[b->n].l = l;
+    b->s[b->n] = sc;
+    b->n++;
+}
+
+__attribute__((target("avx2,f16c"))) static void scan_rows_f16c(const float* wt, const float* lenmask, const int64_t* lens,
+                                                                 int K, int Kp, int maxlen, const uint8_t* codes, int L, int64_t nb,
+                                                                 int64_t n0, int l_lo, int l_hi, int uniform, hitbuf* out) {
+    const int ng = Kp / 8;
+    for (int l = l_lo; l < l_hi; l++) {
+        for (int64_t n = 0; n < nb; n++) {
+            const uint8_t* s = codes + (n0 + n) * L;
+            for (int g0 = 0; g0 < ng; g0 += 4) {       /* four independent chains of 8 PWMs hide the add+convert latency */
+                __m256 acc[4];
+                const int gn = ng - g0 < 4 ? ng - g0 : 4;
+                for (int j = 0; j < 4; j++) acc[j] = _mm256_setzero_ps();
+                const int span = L - l < maxlen ? L - l : maxlen;   /* positions past the read are never added: l <= L - len is checked below */
+                for (int ind = 0; ind < span; ind++) {
+                    const int b = s[l + ind];
+                    if (b >= 4) continue;
+                    const float* w = wt + ((size_t)ind * 4 + b) * Kp + (size_t)g0 * 8;
+                    for (int j = 0; j < gn; j++) {
+                        const __m256 sum = _mm256_add_ps(acc[j], _mm256_loadu_ps(w + 8 * j));
+                        const __m256 r = _mm256_cvtph_ps(_mm256_cvtps_ph(sum, _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC));
+                        if (uniform) acc[j] = r;
+                        else acc[j] = _mm256_blendv_ps(acc[j], r, _mm256_loadu_ps(lenmask + (size_t)ind * Kp + (size_t)(g0 + j) * 8));
+                    }
+                }
+                for (int j = 0; j < gn; j++) {
+                    const int pos = _mm256_movemask_ps(_mm256_cmp_ps(acc[j], _mm256_setzero_ps(), _CMP_GT_OQ));
+                    if (!pos) continue;
+                    uint16_t hs[8];
+                    _mm_storeu_si128((__m128i*)hs, _mm256_cvtps_ph(acc[j], _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC));
+                    for (int u = 0; u < 8; u++) {
+                        const int k = (g0 + j) * 8 + u;
+                        if (((pos >> u) & 1) && k < K && l <= L - (int)lens[k])
+                            hb_push(out, (uint32_t)(k + 1), (uint32_t)(n0 + n + 1), (uint32_t)(l + 1), hs[u]);
+                    }
+                }
+            }
+        }
+    }
+}
+
+int64_t oracle_get_pos_scores_arr_fast(const uint16_t* pwms_in, const int64_t* lens, int K, int maxlen, const uint8_t* codes,
+                                       int64_t N, int L, int rc, int batch_size, oracle_hit* found, uint16_t* score_record,
+                                       int64_t cap) {
+    if (!__builtin_cpu_supports("avx2") || !__builtin_cpu_supports("f16c")) return -1;
+    const int Kp = (K + 7) / 8 * 8;
+    int minlen = maxlen, maxtrue = 0;
+    for (int k = 0; k < K; k++) {
+        if (lens[k] < minlen) minlen = (int)lens[k];
+        if (lens[k] > maxtrue) maxtrue = (int)lens[k];
+    }
+    const int uniform = minlen == maxtrue;
+    const int Lout = L - minlen + 1;
+    float* wt = (float*)calloc((size_t)maxtrue * 4 * Kp, 4);
+    float* lenmask = (float*)calloc((size_t)maxtrue * Kp, 4);
+    for (int k = 0; k < K; k++) {
+        const int len = (int)lens[k];
+        for (int ind = 0; ind < len; ind++) {
+            uint32_t ones = 0xffffffffu;
+            memcpy(&lenmask[(size_t)ind * Kp + k], &ones, 4);
+            for (int a = 0; a < 4; a++) {
+                const int sa = rc ? 3 - a : a, si = rc ? len - 1 - ind : ind;   /* reverse(pwm), :68 */
+                wt[((size_t)ind * 4 + a) * Kp + k] = f16_to_f32(pwms_in[k + K * (sa + 4 * si)]);
+            }
+        }
+    }
+    int64_t nfound = 0;
+    int nthr = 1;
+#ifdef _OPENMP
+    nthr = omp_get_max_threads();
+#endif
+    hitbuf* bufs = (hitbuf*)calloc((size_t)nthr, sizeof(hitbuf));
+    for (int64_t n0 = 0; n0 < N && Lout > 0; n0 += batch_size) {   /* :71 */
+        const int64_t nb = N - n0 < batch_size ? N - n0 : batch_size;
+#pragma omp parallel num_threads(nthr)
+        {
+            int t = 0, T = 1;
+#ifdef _OPENMP
+            t = omp_get_thread_num();
+            T = omp_get_num_threads();
+#endif
+            bufs[t].n = 0;
+            const int lo = (int)((int64_t)Lout * t / T), hi = (int)((int64_t)Lout * (t + 1) / T);
+            scan_rows_f16c(wt, lenmask, lens, K, Kp, maxtrue, codes, L, nb, n0, lo, hi, uniform, &bufs[t]);
+        }
+        for (int t = 0; t < nthr; t++) {                            /* l ranges in order = findall's order */
+            for (int64_t i = 0; i < bufs[t].n; i++) {
+                if (nfound < cap) {
+                    found[nfound] = bufs[t].h[i];
+                    score_record[nfound] = bufs[t].s[i];
+                }
+                nfound++;
+            }
+        }
+    }
+    for (int t = 0; t < nthr; t++) {
+        free(bufs[t].h);
+        free(bufs[t].s);
+    }
+    free(bufs);
+    free(wt);
+    free(lenmask);
+    return nfound;
+}
+
 void oracle_set_threads(int n) {
 #ifdef _OPENMP
     if (n > 0) omp_set_num_threads(n);

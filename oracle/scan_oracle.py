@@ -32,6 +32,8 @@ def lib():
         h.oracle_greedy_search.argtypes = [p, p, p, i, i, i64, i, p]
         h.oracle_get_pos_scores_arr.restype = i64
         h.oracle_get_pos_scores_arr.argtypes = [p, p, i, i, p, i64, i, i, i, p, p, i64]
+        h.oracle_get_pos_scores_arr_fast.restype = i64
+        h.oracle_get_pos_scores_arr_fast.argtypes = [p, p, i, i, p, i64, i, i, i, p, p, i64]
         h.oracle_scan_gather.restype = None
         h.oracle_scan_gather.argtypes = [p, p, i, p, i64, i, i, p]
         h.oracle_num_threads.restype = i
@@ -79,6 +81,27 @@ def get_pos_scores_arr(pwms, lens, data_f32, rc=False, batch_size=5000):
         score = np.zeros(cap, dtype=np.float16)
         n = lib().oracle_get_pos_scores_arr(_ptr(pwms), _ptr(lens), K, maxlen, _ptr(data_f32), N, L4, int(bool(rc)),
                                             int(batch_size), _ptr(found), _ptr(score), cap)
+        if n <= cap:
+            return found[:n], score[:n]
+        cap = int(n)
+
+
+def get_pos_scores_arr_fast(pwms, lens, codes, rc=False, batch_size=5000, cap_hint=None):
+    """The optimised CPU form (AVX2/F16C, 8 PWMs per register, OpenMP over start positions): same records, same order,
+    same binary16 rounding sequence as get_pos_scores_arr.  codes: (N, L) uint8.  None if the CPU lacks F16C."""
+    pwms = np.ascontiguousarray(pwms, dtype=np.float16)
+    lens = np.ascontiguousarray(lens, dtype=np.int64)
+    codes = np.ascontiguousarray(codes, dtype=np.uint8)
+    maxlen, _, K = pwms.shape
+    N, L = codes.shape
+    cap = int(cap_hint) if cap_hint else 1 << 16
+    while True:
+        found = np.zeros(cap, dtype=HIT_DTYPE)
+        score = np.zeros(cap, dtype=np.float16)
+        n = lib().oracle_get_pos_scores_arr_fast(_ptr(pwms), _ptr(lens), K, maxlen, _ptr(codes), N, L, int(bool(rc)),
+                                                 int(batch_size), _ptr(found), _ptr(score), cap)
+        if n < 0:
+            return None
         if n <= cap:
             return found[:n], score[:n]
         cap = int(n)

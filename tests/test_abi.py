@@ -41,7 +41,15 @@ def test_binding_covers_every_declared_symbol(built):
 
 
 def test_abi_version(built):
-    assert built._lib.lib().motifs_abi_version() == 1
+    assert built._lib.lib().motifs_abi_version() == built._lib.ABI_VERSION == 2
+
+
+def test_comm_entry_points_fail_cleanly_without_a_device(built):
+    """The collectives are part of the ABI; without a context there is nothing to run them on."""
+    lib = built._lib.lib()
+    assert lib.motifs_comm_allreduce_sum_f32_dev(None, None, 4) == built._lib.ERR_INVALID
+    assert lib.motifs_hist_allreduce(None, None, 4, 3) == built._lib.ERR_INVALID
+    assert lib.motifs_comm_rank(None, None, None) == built._lib.ERR_INVALID
 
 
 def test_no_cpu_fallback(built):

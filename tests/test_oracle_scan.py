@@ -126,3 +126,27 @@ def test_golden_fixture(pkg):
         found, score = so.get_pos_scores_arr(g["bank"], g["lens"], g["onehot"], rc=bool(rc), batch_size=int(g["batch"]))
         assert np.array_equal(found, g[f"found_rc{rc}"].view(so.HIT_DTYPE).reshape(-1))
         assert np.array_equal(score.view(np.uint16), g[f"score_rc{rc}"])
+
+
+@pytest.mark.parametrize("N,L,K,lo,hi,batch", [(120, 100, 37, 6, 14, 50), (60, 200, 200, 12, 12, 5000), (50, 64, 9, 3, 20, 7),
+                                               (30, 150, 20, 33, 64, 11), (40, 500, 64, 20, 20, 5000)])
+def test_vectorised_port_equals_the_literal_restatement(N, L, K, lo, hi, batch):
+    """oracle_get_pos_scores_arr_fast (AVX2/F16C, 8 PWMs per register, no dense tensor) is what bench.py times as the CPU
+    baseline and what the larger GPU parity cases are checked against: it must give the literal loop's records, order
+    and binary16 score bits, both strands, all-zero columns and ragged PWM lengths included."""
+    from _pkg import load_pkg
+
+    sy = load_pkg().synth
+    codes = sy.gen_codes(N, L, 5 + N, n_plant=3, k=10)
+    codes[::7, ::5] = 4
+    pwms, lens = sy.gen_pwm_bank(K, 3 + K, len_lo=lo, len_hi=hi, alpha=0.5)
+    bank = sy.pad_bank(pwms, lens)
+    onehot = sy.codes_to_onehot(codes)
+    for rc in (False, True):
+        fast = so.get_pos_scores_arr_fast(bank, lens, codes, rc=rc, batch_size=batch)
+        if fast is None:
+            pytest.skip("host CPU lacks AVX2/F16C")
+        lit = so.get_pos_scores_arr(bank, lens, onehot, rc=rc, batch_size=batch)
+        assert len(lit[0]) > 0
+        assert np.array_equal(fast[0], lit[0])
+        assert np.array_equal(fast[1].view(np.uint16), lit[1].view(np.uint16))

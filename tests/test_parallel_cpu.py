@@ -1,6 +1,8 @@
-"""world_size-2 gloo tests of the data-parallel plumbing (motifs.jl_amd/parallel.py): shard layout and
-the two all-reduces.  The local compute is a deterministic stand-in (the HIP path needs a GPU; its
-single-process equivalence to per-group sums is covered by tests/test_model_gpu.py)."""
+"""CPU tests of the data-parallel host side (motifs.jl_amd/parallel.py): shard layout, the reducer classes over a
+world_size-2 and world_size-3 gloo group, and the control flow of a data-parallel step in which one rank has no
+mini-batch.  The local compute here is a deterministic stand-in for the HIP kernels (they need a GPU); the
+real-compute equivalents — sharded hit records == single-device records bit for bit, reduced gradient == sum of the
+shard gradients — are tests/test_parallel_gpu.py."""
 import os
 import socket
 
@@ -12,7 +14,8 @@ import torch.multiprocessing as mp
 
 def test_shard_range_partitions(pkg):
     sr = pkg.parallel.shard_range
-    for n, ws, al in [(100000, 8, 6), (100000, 8, 5000), (31, 2, 6), (5, 4, 6), (0, 3, 1), (12, 2, 6)]:
+    for n, ws, al in [(100000, 8, 6), (100000, 8, 5000), (31, 2, 6), (5, 4, 6), (0, 3, 1), (12, 2, 6), (100000, 3, 5000),
+                      (9999, 8, 5000), (12, 8, 6)]:
         edges = [sr(n, r, ws, al) for r in range(ws)]
         assert edges[0][0] == 0 and edges[-1][1] == n
         for (a, b), (c, d) in zip(edges, edges[1:]):
@@ -23,6 +26,16 @@ def test_shard_range_partitions(pkg):
         assert max(sizes) - min(sizes) <= 2 * al
 
 
+def test_shard_range_can_leave_a_rank_empty(pkg):
+    """More ranks than units: some blocks are empty — the callers must still join every collective (dp_train_step
+    with n_groups_local = 0, sharded_gpu_scan with no reads)."""
+    sr = pkg.parallel.shard_range
+    edges = [sr(12, r, 8, 6) for r in range(8)]            # 2 mini-batches over 8 ranks
+    assert sum(1 for a, b in edges if b > a) == 2 and sum(b - a for a, b in edges) == 12
+    edges = [sr(9999, r, 8, 5000) for r in range(8)]       # 2 ordering batches over 8 ranks
+    assert [b - a for a, b in edges] == [5000, 4999, 0, 0, 0, 0, 0, 0]
+
+
 def fake_grad(lo, hi, n):
     """Deterministic stand-in for the summed gradient of groups [lo, hi)."""
     g = np.zeros(n, dtype=np.float32)
@@ -31,7 +44,29 @@ def fake_grad(lo, hi, n):
     return g
 
 
-def _worker(rank, ws, port, ret):
+class FakeModel:
+    """The calls dp_train_step makes on a Model, on host tensors: gradient of the local groups, then a plain SGD step
+    standing in for AdaBelief (the point is the control flow around the exchange, not the optimiser)."""
+
+    def __init__(self, n, lo):
+        self.n, self.lo = n, lo
+        self.params = np.zeros(n, dtype=np.float32)
+        self.ctx = self
+        self.calls = []
+
+    def synchronize(self):
+        pass
+
+    def loss_grad_dev(self, codes_ptr, n_groups, loss_ptr, grad_ptr):
+        self.calls.append(("grad", n_groups))
+        self._grad[:] = torch.from_numpy(fake_grad(self.lo, self.lo + n_groups, self.n))
+
+    def adabelief_dev(self, grad_ptr, gscale):
+        self.calls.append(("step", gscale))
+        self.params -= 0.1 * gscale * self._grad.numpy()
+
+
+def _worker(rank, ws, port, n_groups, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=ws)
@@ -41,29 +76,59 @@ def _worker(rank, ws, port, ret):
     from _pkg import load_pkg
 
     par = load_pkg().parallel
-    n_groups, n = 10, 257
+    n = 257
+    reducer, note = par.make_reducer(None, prefer_rccl=False)
+    assert isinstance(reducer, par.HostReducer)
     lo, hi = par.shard_range(n_groups, rank, ws)
+    # the two sums of the path through the reducer
     grad = torch.from_numpy(fake_grad(lo, hi, n))
-    par.allreduce_sum_(grad)
+    reducer.sum_f32_(grad)
     counts = torch.tensor([lo, hi, 7 * rank], dtype=torch.int64)
-    par.allreduce_sum_(counts)
+    reducer.sum_i64_(counts)
+    t = par.host_all_reduce(torch.tensor([float(rank)], dtype=torch.float64), dist.ReduceOp.MAX)
+    # one data-parallel step, the group total unknown to the caller (summed over the ranks); a rank may have no group
+    model = FakeModel(n, lo)
+    model._grad = torch.zeros(n, dtype=torch.float32)
+    loss = torch.zeros(max(hi - lo, 1), dtype=torch.float32)
+    par.dp_train_step(model, 0, hi - lo, loss, model._grad, None, reducer=reducer)
     hits = np.arange(lo, hi, dtype=np.uint32)
     allh, alls = par.gather_hits(hits, hits.astype(np.float16))
-    if rank == 0:
-        ret["grad"] = grad.numpy().copy()
-        ret["counts"] = counts.numpy().copy()
-        ret["hits"] = allh
+    ret[rank] = {"grad": grad.numpy().copy(), "counts": counts.numpy().copy(), "hits": allh, "max": float(t.item()),
+                 "params": model.params.copy(), "calls": model.calls, "local": hi - lo}
     dist.destroy_process_group()
 
 
-def test_allreduce_matches_single_process():
+def _run(ws, n_groups):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
+    mp.spawn(_worker, args=(ws, port, n_groups, ret), nprocs=ws, join=True)
+    return dict(ret)
+
+
+def test_reducers_match_single_process():
+    ret = _run(2, 10)
     want = fake_grad(0, 10, 257)
-    assert np.allclose(ret["grad"], want, rtol=1e-6, atol=1e-5)
-    assert ret["counts"].tolist() == [5, 15, 7]
-    assert ret["hits"].tolist() == list(range(10))            # rank order == sequence-block order
+    for r in (0, 1):
+        assert np.allclose(ret[r]["grad"], want, rtol=1e-6, atol=1e-5)
+        assert ret[r]["counts"].tolist() == [5, 15, 7]
+        assert ret[r]["hits"].tolist() == list(range(10))            # rank order == sequence-block order
+        assert ret[r]["max"] == 1.0
+        # the step used the mean over ALL groups, on every rank alike
+        assert np.allclose(ret[r]["params"], -0.1 * want / 10, rtol=1e-6, atol=1e-6)
+    assert np.array_equal(ret[0]["params"], ret[1]["params"])        # replicas stay bit-identical
+
+
+def test_rank_without_a_mini_batch_still_joins_the_exchange():
+    """2 mini-batches over 3 ranks (such a rank used to raise before the all-reduce and hang the others)."""
+    ret = _run(3, 2)
+    want = fake_grad(0, 2, 257)
+    assert sorted(ret[r]["local"] for r in range(3)) == [0, 1, 1]
+    for r in range(3):
+        assert np.allclose(ret[r]["params"], -0.1 * want / 2, rtol=1e-6, atol=1e-6)
+        kinds = [c[0] for c in ret[r]["calls"]]
+        assert kinds == (["grad", "step"] if ret[r]["local"] else ["step"])
+        assert ret[r]["calls"][-1][1] == 0.5
+    assert np.array_equal(ret[0]["params"], ret[1]["params"]) and np.array_equal(ret[0]["params"], ret[2]["params"])
