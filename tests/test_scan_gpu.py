@@ -210,9 +210,9 @@ def test_f16_input_and_errors(torch_cuda, ctx, pkg):
     with pytest.raises(lib.MotifsError) as e:
         ctx.pwm_scan(bank, lens, onehot, lib.DATA_ONEHOT_F32, 20, 30, False, cap=max(len(b[0]) - 1, 1))
     assert e.value.code == lib.ERR_BUFFER_TOO_SMALL
-    big = np.zeros((33, 4, 2), dtype=np.float16)
+    big = np.zeros((lib.SCAN_MAX_LEN + 1, 4, 2), dtype=np.float16)
     with pytest.raises(lib.MotifsError) as e:
-        ctx.pwm_scan(big, np.array([33, 33]), onehot, lib.DATA_ONEHOT_F32, 20, 30, False)
+        ctx.pwm_scan(big, np.array([lib.SCAN_MAX_LEN + 1] * 2), onehot, lib.DATA_ONEHOT_F32, 20, 30, False)
     assert e.value.code == lib.ERR_UNSUPPORTED
 
 
