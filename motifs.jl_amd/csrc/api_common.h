@@ -75,8 +75,6 @@ struct motifs_ctx {
     // scan workspaces
     motifs::DevBuf tab, lim, cnt, off, tilesum, small, codes, hits_tmp, scores_tmp, pwmcnt, data_tmp, afrag, cinit;
     motifs::DevBuf staging, rowx;   // matrix-core scan: staged hit words, per-row offsets
-    motifs::DevBuf lists, offs;     // fused scan: per-(tile group, read) hit lists, per-(tile group, l, read) list offsets
-    bool scan_cells = false;        // MOTIFS_SCAN_CELLS=1: hit records through the cell path (cross-check of the fused path)
     motifs::BankSlot bank_slot[2];  // [rc]
     void* pinned = nullptr;  // small pinned host block for totals / flags
 };

@@ -413,125 +413,6 @@ static int scan_hits_mfma(motifs_ctx* c, const BankSlot& bank, int K, const uint
     return MOTIFS_OK;
 }
 
-
-// Hit records through the fused path (scan_mfma.hip, "the fused path"): filter + verification in one kernel (hit lists,
-// offset rows) -> unit sums -> row scan -> gather into records.  Returns -1 when the shape is outside what the path is
-// built for (the caller takes the cell path); *overflowed is set (after the host wait, finish = true) or left for the
-// caller to read from the pinned block (finish = false) when a read had more hits than its list holds.
-static int scan_hits_fused(motifs_ctx* c, const BankSlot& bank, int K, const uint8_t* codes_dev, int64_t N, int L, int Lout, int64_t n0,
-                           int batch, motifs_hit* hits_dev, uint16_t* hit_scores_dev, int64_t cap, int64_t* n_out,
-                           int64_t* per_pwm_counts_dev, int slot, bool finish, bool* overflowed) {
-    const int PG = cand_tile_group(bank.lenp), used_tiles = (K + 31) / 32, ntg = (used_tiles + PG - 1) / PG;
-    if (c->scan_cells || !fused_supported(bank.lenp, used_tiles, Lout, 8) || batch > (1 << 20)) return -1;
-    const bool emit = hits_dev != nullptr && cap > 0;
-    // list capacity per (tile group, read): an eighth of its (PWM, start) pairs; typical banks hit 1-3 % of them
-    int capr = (int)std::min<int64_t>(65535, std::max<int64_t>(256, ((int64_t)PG * 32 * Lout / 8 + 63) / 64 * 64));
-    const size_t per_batch = (size_t)batch * ntg * ((size_t)capr * 4 + (size_t)(Lout + 1) * 2);
-    int64_t nb_max = (int64_t)(c->ws_limit / per_batch);
-    nb_max = std::max<int64_t>(1, std::min<int64_t>(nb_max, (N + batch - 1) / batch));
-    const int64_t sb = nb_max * batch;
-    const int cpb = (batch + 63) / 64;
-    const int64_t units_max = nb_max * Lout * cpb;
-    if (units_max >= ((int64_t)1 << 31)) return -1;
-
-    FusedArgs a{};
-    a.afrag = (const uint4*)bank.afrag.p;
-    a.cinit = (const float*)bank.cinit.p;
-    a.d.L = L;
-    a.d.pitch = motifs_codes_pitch(L);
-    a.d.Lout = Lout;
-    a.d.nch = bank.nch;
-    a.d.batch = batch;
-    a.d.ohlen = (Lout + 31) / 32 * 32 + bank.lenp;
-    a.d.used_tiles = used_tiles;
-    a.tabk = (const uint16_t*)bank.tabk.p;
-    a.tabk_stride = bank.tabk_stride;
-    a.lim = (const int32_t*)bank.lim.p;
-    a.lim_min = L - bank.maxlen_true;
-    a.K = K;
-    a.capr = capr;
-    a.ntg = ntg;
-    a.pwm_counts = per_pwm_counts_dev;
-    a.hist_bins = (per_pwm_counts_dev && K <= FILL_HIST_MAX) ? K : 0;
-    a.lenp = bank.lenp;
-    a.uniform_eps = bank.uniform_eps;
-    a.d.spw = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(sb, N) * ntg / 16384, 8));
-    a.d.N = std::min<int64_t>(sb, N);
-    if (!fused_plan(a)) return -1;
-    const int spw = a.d.spw;
-
-    MOTIFS_HIP_CHECK(c->lists.reserve((size_t)nb_max * batch * ntg * capr * 4));
-    MOTIFS_HIP_CHECK(c->offs.reserve((size_t)nb_max * batch * ntg * (Lout + 1) * 2 + 64));
-    MOTIFS_HIP_CHECK(c->tilesum.reserve((size_t)units_max * 4));
-    MOTIFS_HIP_CHECK(c->off.reserve((size_t)((units_max + 1023) / 1024) * 8));
-    MOTIFS_HIP_CHECK(c->rowx.reserve((size_t)units_max * 4));
-    MOTIFS_HIP_CHECK(c->small.reserve(128));
-    int64_t* totals = (int64_t*)c->small.p + 2 * slot;
-    uint32_t* ovf_dev = (uint32_t*)((char*)c->small.p + 64) + slot;
-    MOTIFS_HIP_CHECK(hipMemsetAsync(totals, 0, 16, c->stream));
-    MOTIFS_HIP_CHECK(hipMemsetAsync(ovf_dev, 0, 4, c->stream));
-    int64_t* h_total = (int64_t*)c->pinned + slot;
-    uint32_t* h_ovf = (uint32_t*)((char*)c->pinned + 128) + slot;
-
-    int launch_no = 0;
-    for (int64_t s0 = 0; s0 < N; s0 += sb, launch_no++) {
-        const int64_t ns = std::min<int64_t>(sb, N - s0);
-        const int64_t nb = (ns + batch - 1) / batch;
-        a.codes = codes_dev + (size_t)s0 * a.d.pitch;
-        a.d.N = ns;
-        a.d.spw = spw;
-        a.nbatch = (int)nb;
-        a.lists = (uint32_t*)c->lists.p;
-        a.off = (uint16_t*)c->offs.p;
-        a.overflow = ovf_dev;
-        const int64_t nunits = nb * Lout * cpb;
-        FillArgs f{};
-        f.nrows = nunits;
-        f.row_sum = (uint32_t*)c->tilesum.p;
-        f.row_excl = (uint32_t*)c->rowx.p;
-        f.blk_base = (unsigned long long*)c->off.p;
-        f.base_in = totals + (launch_no & 1);
-        f.total = totals + ((launch_no + 1) & 1);
-        {
-            KernelTimer t(c, KS_SCAN_COUNT);
-            MOTIFS_HIP_CHECK(launch_fused(a, c->stream));
-        }
-        {
-            KernelTimer t(c, KS_SCAN_OFFSETS);
-            MOTIFS_HIP_CHECK(launch_unit_sums(a, cpb, nunits, f.row_sum, c->stream));
-            MOTIFS_HIP_CHECK(launch_row_scan(f, c->stream));
-        }
-        if (emit) {
-            KernelTimer t(c, KS_SCAN_FILL);
-            MOTIFS_HIP_CHECK(launch_emit_units(a, cpb, f.row_excl, f.blk_base, (HitRec*)hits_dev, hit_scores_dev, cap, n0 + s0, c->stream));
-        }
-    }
-    MOTIFS_HIP_CHECK(hipMemcpyAsync(h_total, totals + (launch_no & 1), 8, hipMemcpyDeviceToHost, c->stream));
-    MOTIFS_HIP_CHECK(hipMemcpyAsync(h_ovf, ovf_dev, 4, hipMemcpyDeviceToHost, c->stream));
-    if (!finish) return MOTIFS_OK;
-    MOTIFS_HIP_CHECK(hipStreamSynchronize(c->stream));
-    *overflowed = *h_ovf != 0;
-    if (*overflowed) return MOTIFS_OK;
-    const int64_t emitted = *h_total;
-    *n_out = emitted;
-    if (emitted > cap && !(cap == 0 && hits_dev == nullptr)) {
-        set_error("hit buffer too small: need %lld records, cap %lld", (long long)emitted, (long long)cap);
-        return MOTIFS_ERR_BUFFER_TOO_SMALL;
-    }
-    return MOTIFS_OK;
-}
-
-// one strand, host wait included: the fused path, or the cell path where the fused one does not apply / a list overflowed
-static int scan_hits_auto(motifs_ctx* c, const BankSlot& bank, int K, const uint8_t* codes_dev, int64_t N, int L, int Lout, int64_t n0, int batch,
-                          motifs_hit* hits_dev, uint16_t* hit_scores_dev, int64_t cap, int64_t* n_out, int64_t* per_pwm_counts_dev) {
-    bool overflowed = false;
-    const int r = scan_hits_fused(c, bank, K, codes_dev, N, L, Lout, n0, batch, hits_dev, hit_scores_dev, cap, n_out, per_pwm_counts_dev, 0, true,
-                                  &overflowed);
-    if (r >= 0 && !overflowed) return r;
-    if (overflowed && per_pwm_counts_dev) MOTIFS_HIP_CHECK(hipMemsetAsync(per_pwm_counts_dev, 0, (size_t)K * 8, c->stream));
-    return scan_hits_mfma(c, bank, K, codes_dev, N, L, Lout, n0, batch, hits_dev, hit_scores_dev, cap, n_out, per_pwm_counts_dev);
-}
-
 extern "C" {
 
 int motifs_abi_version(void) { return MOTIFS_ABI_VERSION; }
@@ -568,8 +449,6 @@ int motifs_ctx_create(int device, motifs_ctx** out) {
     MOTIFS_HIP_CHECK(hipHostMalloc(&c->pinned, 256, hipHostMallocDefault));
     const char* ev = getenv("MOTIFS_SCAN_VALU");
     c->scan_valu = ev && ev[0] == '1';
-    ev = getenv("MOTIFS_SCAN_CELLS");
-    c->scan_cells = ev && ev[0] == '1';
     *out = c;
     return MOTIFS_OK;
 }
@@ -579,7 +458,7 @@ void motifs_ctx_destroy(motifs_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : {&c->tab, &c->lim, &c->cnt, &c->off, &c->tilesum, &c->small, &c->codes, &c->hits_tmp,
-                      &c->scores_tmp, &c->pwmcnt, &c->data_tmp, &c->afrag, &c->cinit, &c->staging, &c->rowx, &c->lists, &c->offs})
+                      &c->scores_tmp, &c->pwmcnt, &c->data_tmp, &c->afrag, &c->cinit, &c->staging, &c->rowx})
         b->release();
     for (BankSlot& bs : c->bank_slot)
         for (DevBuf* b : {&bs.tab, &bs.lim, &bs.afrag, &bs.cinit, &bs.tabk}) b->release();
@@ -790,7 +669,7 @@ int motifs_pwm_scan_hits_dev(motifs_ctx* c, const uint16_t* pwms_fp16, const int
         if (per_pwm_counts_dev) MOTIFS_HIP_CHECK(hipMemsetAsync(per_pwm_counts_dev, 0, (size_t)K * 8, c->stream));
         const int Lout = L - bs->minlen + 1;
         if (N == 0 || Lout <= 0) return MOTIFS_OK;
-        return scan_hits_auto(c, *bs, K, codes_dev, N, L, Lout, n0, batch, hits_dev, hit_scores_dev, cap, n_out, per_pwm_counts_dev);
+        return scan_hits_mfma(c, *bs, K, codes_dev, N, L, Lout, n0, batch, hits_dev, hit_scores_dev, cap, n_out, per_pwm_counts_dev);
     }
     PackedBank bank;
     int rcode = pack_bank(pwms_fp16, lens, K, maxlen, rc, L, bank);
@@ -938,30 +817,15 @@ int motifs_pwm_scan_hits_both_dev(motifs_ctx* c, const uint16_t* pwms_fp16, cons
     }
     MOTIFS_HIP_CHECK(hipSetDevice(c->device));
     if (per_pwm_counts2_dev) MOTIFS_HIP_CHECK(hipMemsetAsync(per_pwm_counts2_dev, 0, (size_t)2 * K * 8, c->stream));
-    bool fused[2] = {false, false};
     for (int rc = 0; rc < 2; rc++) {
         const int Lout = L - bs[rc]->minlen + 1;
         int64_t dummy = 0;
-        bool ovf = false;
-        int64_t* cnt = per_pwm_counts2_dev ? per_pwm_counts2_dev + (size_t)rc * K : nullptr;
-        int rcode = scan_hits_fused(c, *bs[rc], K, codes_dev, N, L, Lout, n0, batch, hits[rc], scores[rc], cap, &dummy, cnt, rc, false, &ovf);
-        fused[rc] = rcode >= 0;
-        if (rcode < 0) rcode = scan_hits_mfma(c, *bs[rc], K, codes_dev, N, L, Lout, n0, batch, hits[rc], scores[rc], cap, &dummy, cnt, rc, false);
+        const int rcode = scan_hits_mfma(c, *bs[rc], K, codes_dev, N, L, Lout, n0, batch, hits[rc], scores[rc], cap, &dummy,
+                                         per_pwm_counts2_dev ? per_pwm_counts2_dev + (size_t)rc * K : nullptr, rc, false);
         if (rcode) return rcode;
     }
     MOTIFS_HIP_CHECK(hipStreamSynchronize(c->stream));
-    int64_t h_total[2] = {((const int64_t*)c->pinned)[0], ((const int64_t*)c->pinned)[1]};
-    const uint32_t* h_ovf = (const uint32_t*)((const char*)c->pinned + 128);
-    for (int rc = 0; rc < 2; rc++) {
-        if (fused[rc] && h_ovf[rc]) {               // a hit list overflowed: this strand again through the cell path
-            int64_t* cnt = per_pwm_counts2_dev ? per_pwm_counts2_dev + (size_t)rc * K : nullptr;
-            if (cnt) MOTIFS_HIP_CHECK(hipMemsetAsync(cnt, 0, (size_t)K * 8, c->stream));
-            int64_t got = 0;
-            const int rcode = scan_hits_mfma(c, *bs[rc], K, codes_dev, N, L, L - bs[rc]->minlen + 1, n0, batch, hits[rc], scores[rc], cap, &got, cnt);
-            if (rcode && rcode != MOTIFS_ERR_BUFFER_TOO_SMALL) return rcode;
-            h_total[rc] = got;
-        }
-    }
+    const int64_t* h_total = (const int64_t*)c->pinned;
     for (int rc = 0; rc < 2; rc++) {
         n_out2[rc] = h_total[rc];
         if (h_total[rc] > cap && !(cap == 0 && hits[rc] == nullptr)) {

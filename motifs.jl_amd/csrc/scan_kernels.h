@@ -112,30 +112,6 @@ hipError_t launch_row_scan(const FillArgs& a, hipStream_t st);             // ro
 hipError_t launch_emit_records(const FillArgs& a, hipStream_t st);         // staged hits -> records
 hipError_t launch_fill_scan(const FillArgs& a, hipStream_t st);            // exclusive scan of row_sum
 
-struct FusedArgs {
-    const uint4* afrag;
-    const float* cinit;
-    const uint8_t* codes;
-    CandDims d;
-    const uint16_t* tabk;         // [K][tabk_stride] re-scoring table
-    int tabk_stride;
-    const int32_t* lim;           // last valid start per PWM
-    int lim_min, K;
-    uint32_t* lists;              // [tg][read of the super-batch][capr] hit words
-    uint16_t* off;                // [tg][batch][l = 0..Lout][read in batch]
-    int capr, ntg, nbatch;
-    int64_t* pwm_counts;
-    int hist_bins;
-    uint32_t* overflow;           // max over (tg, read) of the list length
-    int lenp, uniform_eps, lds_tab;
-};
-bool fused_supported(int lenp, int used_tiles, int Lout, int spw_max);
-bool fused_plan(FusedArgs& a);                                                  // picks reads per wave / table placement; false: does not fit
-hipError_t launch_fused(const FusedArgs& a, hipStream_t st);                    // filter + verification: hit lists and offset rows
-hipError_t launch_unit_sums(const FusedArgs& a, int cpb, int64_t nunits, uint32_t* row_sum, hipStream_t st);
-hipError_t launch_emit_units(const FusedArgs& a, int cpb, const uint32_t* row_excl, const unsigned long long* blk_base, HitRec* hits,
-                             uint16_t* hit_scores, int64_t cap, int64_t n0, hipStream_t st);
-
 int scan_len_padded(int maxlen);
 // positions per mask row for windows 0..Lout-1 of padded length lenp
 int scan_lout_padded(int Lout, int lenp);

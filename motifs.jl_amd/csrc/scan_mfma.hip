@@ -545,319 +545,6 @@ __global__ __launch_bounds__(VF_THREADS) void emit_records(FillArgs a) {
     }
 }
 
-// ---- the fused path: candidates are verified by the wave that found them ------------------------------------
-//
-// The cells above cost 16 bytes per (start, read, chunk) written by one kernel and read by the next (605 MB per strand
-// at BASELINE configs[1], 1.4x the bytes of the records themselves).  Here the wave that runs the filter for
-// (read n, tile group tg) also turns its sign words into candidates (LDS ring, in (l, k) order), scores them in the
-// reference's arithmetic and appends the hits, 4 bytes each (k within the group | binary16 score), to the list of
-// (tg, n).  What the record order needs besides is, per (tg, l, n), where in that list the hits of start l begin:
-// off[tg][batch][l][n in batch] (2 bytes), collected per block in LDS and written as rows.  The hits of one (l, n)
-// are then a list slice, and the reference's order (5000-read batch, l, n, k) is a walk over (l, n) with the tile groups
-// in turn: unit_sums counts the records of every unit = 64 reads at one l, the row scan of the cell path turns the
-// counts into offsets, emit_units gathers the slices into records.
-constexpr int FQ = 128;           // ring slots per wave (entries: l << 8 | k within the tile group)
-
-template <int T, int PG, bool UEPS, int RPB, int TGB, bool LDS_TAB>
-static __device__ __forceinline__ void scan_fused_body(const FusedArgs& a) {
-    constexpr int LEN = 4 * T;
-    constexpr int NW = RPB * TGB;
-    extern __shared__ __attribute__((aligned(16))) uint32_t fsm[];
-    const CandDims& d = a.d;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int w = lane & 31, h = lane >> 5;
-    const int ohl = (d.ohlen + 3) & ~3, R = RPB * d.spw, rows = d.Lout + 1;
-    // LDS: one-hot images | code rows | rings | first positions | transposed offsets | histogram | table
-    uint2* oh = (uint2*)fsm + (size_t)wave * ohl;
-    const int cw = d.pitch / 4 + T + 2;                               // code row + zero codes for the padded tail of a window
-    uint32_t* codes_l = fsm + (size_t)NW * ohl * 2 + (size_t)wave * cw;
-    uint32_t* ring = fsm + (size_t)NW * ohl * 2 + (size_t)NW * cw + (size_t)wave * FQ;
-    uint32_t* firstpos = fsm + (size_t)NW * ohl * 2 + (size_t)NW * cw + (size_t)NW * FQ + (size_t)wave * (rows + 1);
-    uint32_t* after_fp = fsm + (size_t)NW * ohl * 2 + (size_t)NW * cw + (size_t)NW * FQ + (size_t)NW * (rows + 1);
-    uint16_t* offT = (uint16_t*)after_fp;                             // [TGB][rows][R]
-    uint32_t* hist = after_fp + ((size_t)TGB * rows * R + 1) / 2;
-    uint32_t* ltab = hist + a.hist_bins;
-    for (int i = tid; i < a.hist_bins; i += NW * 64) hist[i] = 0;
-    const _Float16* tb = (const _Float16*)a.tabk;
-    if (LDS_TAB) {
-        const int ndw = (a.K * a.tabk_stride + 1) / 2;
-        const uint32_t* src = (const uint32_t*)a.tabk;
-        for (int i = tid; i < ndw; i += NW * 64) ltab[i] = src[i];
-        tb = (const _Float16*)ltab;
-    }
-    for (int i = tid; i < (TGB * rows * R + 1) / 2; i += NW * 64) after_fp[i] = 0u;   // reads the block does not have count nothing
-    for (int i = lane; i <= rows; i += 64) firstpos[i] = 0xffffffffu;
-    __syncthreads();
-
-    const int slot = wave % RPB, tgi = wave / RPB;
-    const int tg = blockIdx.y * TGB + tgi;
-    const bool active = tg * PG < d.used_tiles;
-    const int tile0 = tg * PG;
-    const int ng = active ? (d.used_tiles - tile0 < PG ? d.used_tiles - tile0 : PG) : 0;   // wave-uniform
-    constexpr int NC = UEPS ? 1 : PG;
-    f16x8 A[PG][T];
-    f32x16 C0[NC];
-    if (active) {
-#pragma unroll
-        for (int g = 0; g < PG; g++) {
-#pragma unroll
-            for (int t = 0; t < T; t++) {
-                const uint4 v = a.afrag[((size_t)(tile0 + g) * T + t) * 64 + lane];
-                A[g][t] = __builtin_bit_cast(f16x8, v);
-            }
-            if (!UEPS) {
-#pragma unroll
-                for (int r = 0; r < 16; r++) C0[g][r] = a.cinit[((size_t)(tile0 + g) * 2 + h) * 16 + r];
-            }
-        }
-    }
-    if (UEPS) {
-#pragma unroll
-        for (int r = 0; r < 16; r++) C0[0][r] = 4.0f;
-    }
-    const unsigned lb = xcd_swz(blockIdx.x, gridDim.x);
-    const int ntile = (d.Lout + 31) / 32;
-    const uint32_t kbase = (uint32_t)tile0 * 32u;
-    for (int s = 0; s < d.spw && active; s++) {
-        const int64_t n = ((int64_t)lb * d.spw + s) * RPB + slot;        // wave-uniform
-        if (n >= d.N) break;
-        const uint32_t* srow = (const uint32_t*)(a.codes + n * d.pitch);
-        for (int p4 = lane; p4 * 4 < d.ohlen || p4 < cw; p4 += 64) {
-            const uint32_t wv = p4 * 4 < d.pitch ? srow[p4] : 0u;        // padding, flag bytes and the tail read as codes 0/1: the table holds +0 there
-            if (p4 < cw) codes_l[p4] = wv;
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int p = p4 * 4 + u;
-                const uint32_t c = p < d.L ? (wv >> (8 * u)) & 0xffu : 4u;
-                const uint64_t one = c < 4 ? (uint64_t)0x3c00u << (16 * c) : 0ull;
-                if (p < d.ohlen) oh[p] = make_uint2((uint32_t)one, (uint32_t)(one >> 32));
-            }
-        }
-        wave_lds_sync();
-        uint32_t* list = a.lists + ((size_t)tg * d.N + (size_t)n) * a.capr;
-        uint32_t nlist = 0, qlen = 0, head = 0;                          // wave-uniform
-        auto drain = [&](const uint32_t e, const bool live) {            // 64 candidates -> hits appended to the list
-            const uint32_t l = e >> 8, kl = e & 255u, k = kbase + kl;
-            bool hit = live && (int)k < a.K && ((int)l <= a.lim_min || (int)l <= a.lim[k]);
-            uint16_t sc = 0;
-            if (hit) {
-                uint32_t W[LEN / 4 + 1];
-#pragma unroll
-                for (int j = 0; j <= LEN / 4; j++) W[j] = codes_l[(l >> 2) + j];
-                sc = exact_score<LEN>(tb + __umul24(k, (uint32_t)a.tabk_stride), W, (int)l);
-                hit = half_pos(sc);
-            }
-            const unsigned long long hb = __ballot(hit);
-            if (hit) {
-                const uint32_t pos = nlist + (uint32_t)__builtin_popcountll(hb & ((1ull << lane) - 1ull));
-                if (pos < (uint32_t)a.capr) list[pos] = kl | ((uint32_t)sc << 16);
-                atomicMin(&firstpos[l], pos);
-                if (a.hist_bins) atomicAdd(&hist[k], 1u);
-                else if (a.pwm_counts) atomicAdd((unsigned long long*)&a.pwm_counts[k], 1ull);
-            }
-            nlist += (uint32_t)__builtin_popcountll(hb);
-        };
-        auto take_words = [&](int l0, uint32_t wa, uint32_t wb) {       // the sign words of window l0 + w -> ring, in (l, k) order
-            const int l = l0 + w;
-            if (l >= d.Lout || (PG == 1 && h == 1)) wa = wb = 0u;
-            if (PG != 4) wb = 0u;
-            const uint32_t c = (uint32_t)(__builtin_popcount(wa) + __builtin_popcount(wb));
-            const auto sw = __builtin_amdgcn_permlane32_swap(c, c, false, false);
-            const uint32_t cp = h ? sw[0] : sw[1];                       // the other half's count for the same window
-            const uint32_t pair = c + cp;
-            const uint32_t inc = wave_incl_scan(pair);                   // lanes 0..31 then 32..63: both halves carry the same pairs
-            const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)inc, 31);
-            if (!tot) return;
-            const uint32_t ex = inc - pair - (h ? tot : 0u) + (h ? cp : 0u);   // windows before w, then half 0 of w before half 1
-            const uint32_t kl0 = PG == 4 ? 64u * h : PG == 2 ? 32u * h : 0u;
-            uint32_t done = 0;
-            while (true) {                                               // wave-uniform
-                const uint32_t room = FQ - qlen;
-                const uint32_t take = tot - done < room ? tot - done : room;
-                uint32_t g = ex;
-#pragma unroll
-                for (int q = 0; q < 2; q++) {
-                    uint32_t bits = q ? wb : wa;
-                    while (bits) {
-                        const int i = __builtin_ctz(bits);
-                        bits &= bits - 1;
-                        if (g >= done && g < done + take)
-                            ring[(head + qlen + g - done) & (FQ - 1)] = ((uint32_t)l << 8) | (kl0 + 32u * q + (uint32_t)i);
-                        g++;
-                    }
-                }
-                qlen += take;
-                done += take;
-                wave_lds_sync();
-                while (qlen >= 64) {
-                    drain(ring[(head + lane) & (FQ - 1)], true);
-                    head += 64;
-                    qlen -= 64;
-                }
-                wave_lds_sync();
-                if (done >= tot) break;
-            }
-        };
-        switch (ng) {
-            case 1: cand_read<T, PG, 1, NC>(A, C0, oh, ntile, w, h, take_words); break;
-            case 2: cand_read<T, PG, (PG >= 2 ? 2 : PG), NC>(A, C0, oh, ntile, w, h, take_words); break;
-            case 3: cand_read<T, PG, (PG >= 3 ? 3 : PG), NC>(A, C0, oh, ntile, w, h, take_words); break;
-            default: cand_read<T, PG, PG, NC>(A, C0, oh, ntile, w, h, take_words); break;
-        }
-        if (qlen) drain(ring[(head + lane) & (FQ - 1)], (uint32_t)lane < qlen);
-        wave_lds_sync();
-        // off[l] = hits of starts < l = the first position of the next start that has a hit (suffix minimum), off[Lout] = all
-        const int r = s * RPB + slot;
-        uint32_t carry = nlist;
-        for (int base = (d.Lout / 64) * 64; base >= 0; base -= 64) {
-            const int idx = base + lane;
-            uint32_t v = idx < d.Lout ? firstpos[idx] : 0xffffffffu;
-            if (idx <= d.Lout) firstpos[idx] = 0xffffffffu;
-#pragma unroll
-            for (int sh = 1; sh < 64; sh <<= 1) {
-                const uint32_t o = (uint32_t)__shfl_down((int)v, sh, 64);
-                if (lane + sh < 64 && o < v) v = o;
-            }
-            if (carry < v) v = carry;
-            if (idx <= d.Lout) offT[((size_t)tgi * rows + idx) * R + r] = (uint16_t)(v > 0xffffu ? 0xffffu : v);
-            carry = (uint32_t)__builtin_amdgcn_readlane((int)v, 0);
-        }
-        if (nlist > (uint32_t)a.capr && lane == 0) atomicMax(a.overflow, nlist);
-        wave_lds_sync();
-    }
-    __syncthreads();
-    // rows of offsets out: the block's reads are consecutive, 2 bytes each
-    const int64_t nfirst = (int64_t)lb * d.spw * RPB;
-    for (int i = tid; i < TGB * rows * R; i += NW * 64) {
-        const int r = i % R, l = (i / R) % rows, tq = i / (R * rows);
-        const int64_t n = nfirst + r;
-        const int tgq = blockIdx.y * TGB + tq;
-        if (n < d.N && tgq * PG < d.used_tiles) {
-            const int64_t bq = n / d.batch;
-            a.off[(((size_t)tgq * a.nbatch + bq) * rows + l) * d.batch + (size_t)(n - bq * d.batch)] = offT[((size_t)tq * rows + l) * R + r];
-        }
-    }
-    if (a.hist_bins) {
-        for (int i = tid; i < a.hist_bins; i += NW * 64)
-            if (hist[i]) atomicAdd((unsigned long long*)&a.pwm_counts[i], (unsigned long long)hist[i]);
-    }
-}
-
-template <int T, int PG, bool LDS_TAB>
-__global__ __launch_bounds__(512) void scan_fused_kernel(const FusedArgs a) {
-    scan_fused_body<T, PG, false, 4, 2, LDS_TAB>(a);
-}
-template <int T, int PG, int TGB, bool LDS_TAB>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) void scan_fused_kernel_u(const FusedArgs a) {
-    scan_fused_body<T, PG, true, 4 / TGB, TGB, LDS_TAB>(a);
-}
-
-// records of every unit = the 64 reads [64c, 64c + 64) of batch b at start l (u = (b * Lout + l) * cpb + c)
-__global__ __launch_bounds__(256) void unit_sums(const uint16_t* __restrict__ off, int ntg, int nbatch, int Lout, int batch, int cpb,
-                                                 int64_t N, int64_t nunits, uint32_t* __restrict__ row_sum) {
-    const int lane = threadIdx.x & 63;
-    const int64_t u = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (u >= nunits) return;
-    const int c = (int)(u % cpb), l = (int)((u / cpb) % Lout);
-    const int64_t b = u / ((int64_t)cpb * Lout);
-    const int nb = c * 64 + lane;
-    uint32_t cnt = 0;
-    if (nb < batch && b * batch + nb < N)
-        for (int tg = 0; tg < ntg; tg++) {
-            const uint16_t* row = off + (((size_t)tg * nbatch + b) * (Lout + 1) + l) * batch + nb;
-            cnt += (uint32_t)row[batch] - (uint32_t)row[0];
-        }
-    const uint32_t inc = wave_incl_scan(cnt);
-    if (lane == 63) row_sum[u] = inc;
-}
-
-// list slices -> records.  A wave owns the 64 reads of a chunk c of batch b and walks a range of starts l, so that the
-// list lines it gathers from stay in its CU's L1 from one start to the next.
-__global__ __launch_bounds__(256) void emit_units(const uint16_t* __restrict__ off, const uint32_t* __restrict__ lists, int ntg, int nbatch,
-                                                  int Lout, int batch, int cpb, int64_t N, int capr, int pg32, int lsplit,
-                                                  const uint32_t* __restrict__ row_excl, const unsigned long long* __restrict__ blk_base,
-                                                  HitRec* __restrict__ hits, uint16_t* __restrict__ hit_scores, int64_t cap, int64_t n0) {
-    const int lane = threadIdx.x & 63;
-    const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int64_t nw = (int64_t)nbatch * cpb * lsplit;
-    if (wid >= nw) return;
-    const int ls = (int)(wid % lsplit), c = (int)((wid / lsplit) % cpb);
-    const int64_t b = wid / ((int64_t)lsplit * cpb);
-    const int l_lo = (int)((int64_t)Lout * ls / lsplit), l_hi = (int)((int64_t)Lout * (ls + 1) / lsplit);
-    const int nb = c * 64 + lane;
-    const int64_t n = b * batch + nb;
-    const bool have = nb < batch && n < N;
-    for (int l = l_lo; l < l_hi; l++) {
-        const int64_t u = (b * Lout + l) * cpb + c;
-        uint32_t o0[4], cn[4], tot = 0;                                // up to 4 tile groups at a time
-        const int64_t row_at = (int64_t)blk_base[u >> 10] + row_excl[u];
-        for (int t0 = 0; t0 < ntg; t0 += 4) {
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                o0[q] = cn[q] = 0;
-                if (have && t0 + q < ntg) {
-                    const uint16_t* row = off + (((size_t)(t0 + q) * nbatch + b) * (Lout + 1) + l) * batch + nb;
-                    o0[q] = row[0];
-                    cn[q] = (uint32_t)row[batch] - o0[q];
-                }
-            }
-            const uint32_t mine = cn[0] + cn[1] + cn[2] + cn[3];
-            const uint32_t inc = wave_incl_scan(mine);
-            int64_t at = row_at + tot + (inc - mine);
-            tot += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
-            // the reads of a unit precede each other whole (n, then k): a tile group's hits follow those of the groups before it
-            // only when all groups of a read are in this pass; for ntg > 4 the reference order needs every group of read n
-            // before read n + 1, which the passes break -> the launcher keeps ntg <= 4
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                if (t0 + q >= ntg) break;
-                const uint32_t* src = lists + ((size_t)(t0 + q) * N + (size_t)n) * capr + o0[q];
-                for (uint32_t j = 0; j < cn[q]; j++) {
-                    const uint32_t e = src[j];
-                    if (at < cap) {
-                        hits[at] = HitRec{(uint32_t)(t0 + q) * (uint32_t)pg32 + (e & 0xffffu) + 1u, (uint32_t)(n + n0 + 1), (uint32_t)(l + 1)};
-                        hit_scores[at] = (uint16_t)(e >> 16);
-                    }
-                    at++;
-                }
-            }
-        }
-    }
-}
-
-template <int T, int PG>
-static hipError_t launch_fused_tp(const FusedArgs& a, hipStream_t st) {
-    const int ntg = (a.d.used_tiles + PG - 1) / PG;
-    const int tgb = (a.uniform_eps && ntg == 1) ? 1 : 2;
-    const int rpb = a.uniform_eps ? 4 / tgb : 4;
-    const int nw = rpb * tgb;
-    const int64_t per_block = (int64_t)rpb * a.d.spw;
-    const int rows = a.d.Lout + 1, R = rpb * a.d.spw;
-    dim3 grid((unsigned)((a.d.N + per_block - 1) / per_block), (unsigned)((ntg + tgb - 1) / tgb), 1);
-    const size_t tab_bytes = a.lds_tab ? (((size_t)a.K * a.tabk_stride * 2 + 3) & ~(size_t)3) : 0;
-    const size_t lds = ((size_t)nw * ((a.d.ohlen + 3) & ~3) * 2 + (size_t)nw * (a.d.pitch / 4 + a.lenp / 4 + 2) + (size_t)nw * FQ + (size_t)nw * (rows + 1) +
-                        ((size_t)tgb * rows * R + 1) / 2 + 1 + (size_t)a.hist_bins) * 4 + tab_bytes;
-    if (lds > 150 * 1024) return hipErrorInvalidValue;
-#define MOTIFS_FUSED_LAUNCH(KERN, THREADS)                                                                       \
-    do {                                                                                                          \
-        hipError_t e_ = hipFuncSetAttribute((const void*)KERN, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        if (e_ != hipSuccess) return e_;                                                                          \
-        hipLaunchKernelGGL(KERN, grid, dim3(THREADS), lds, st, a);                                                \
-    } while (0)
-    if (a.uniform_eps && tgb == 1) {
-        if (a.lds_tab) MOTIFS_FUSED_LAUNCH((scan_fused_kernel_u<T, PG, 1, true>), 256);
-        else MOTIFS_FUSED_LAUNCH((scan_fused_kernel_u<T, PG, 1, false>), 256);
-    } else if (a.uniform_eps) {
-        if (a.lds_tab) MOTIFS_FUSED_LAUNCH((scan_fused_kernel_u<T, PG, 2, true>), 256);
-        else MOTIFS_FUSED_LAUNCH((scan_fused_kernel_u<T, PG, 2, false>), 256);
-    } else {
-        if (a.lds_tab) MOTIFS_FUSED_LAUNCH((scan_fused_kernel<T, PG, true>), 512);
-        else MOTIFS_FUSED_LAUNCH((scan_fused_kernel<T, PG, false>), 512);
-    }
-#undef MOTIFS_FUSED_LAUNCH
-    return hipGetLastError();
-}
-
 template <int T, int PG>
 static hipError_t launch_cand_tp(const CandArgs& a, hipStream_t st) {
     const int ntg = (a.d.used_tiles + PG - 1) / PG;           // tile groups that hold PWMs
@@ -952,67 +639,6 @@ hipError_t launch_emit_records(const FillArgs& a, hipStream_t st) {
 #define CALL(LEN) launch_emit_len<LEN>(a, st)
     MOTIFS_LEN_SWITCH(a.lenp, CALL)
 #undef CALL
-}
-
-// The fused path is built for banks of at most four tile groups (the records of a read take its groups in turn) and
-// reads whose offset rows fit LDS; anything else takes the cell path.
-bool fused_supported(int lenp, int used_tiles, int Lout, int spw_max) {
-    const int PG = cand_tile_group(lenp);
-    const int ntg = (used_tiles + PG - 1) / PG;
-    (void)spw_max;
-    return ntg <= 4 && Lout >= 1 && Lout <= 2047;
-}
-size_t fused_lds_bytes(const FusedArgs& a, int rpb, int tgb) {
-    const int nw = rpb * tgb, rows = a.d.Lout + 1, R = rpb * a.d.spw;
-    const size_t tab_bytes = a.lds_tab ? (((size_t)a.K * a.tabk_stride * 2 + 3) & ~(size_t)3) : 0;
-    return ((size_t)nw * ((a.d.ohlen + 3) & ~3) * 2 + (size_t)nw * (a.d.pitch / 4 + a.lenp / 4 + 2) + (size_t)nw * FQ + (size_t)nw * (rows + 1) +
-            ((size_t)tgb * rows * R + 1) / 2 + 1 + (size_t)a.hist_bins) * 4 + tab_bytes;
-}
-// chooses reads per wave and whether the re-scoring table lives in LDS so that the block fits; false: use the cell path
-bool fused_plan(FusedArgs& a) {
-    const int PG = cand_tile_group(a.lenp);
-    const int ntg = (a.d.used_tiles + PG - 1) / PG;
-    const int tgb = (a.uniform_eps && ntg == 1) ? 1 : 2;
-    const int rpb = a.uniform_eps ? 4 / tgb : 4;
-    const size_t budget = a.uniform_eps ? 52 * 1024 : 100 * 1024;      // three 256-thread blocks (one 512-thread block) per CU
-    for (int lds_tab = 1; lds_tab >= 0; lds_tab--)
-        for (int spw = std::min(a.d.spw, 8); spw >= 1; spw >>= 1) {
-            a.lds_tab = lds_tab;
-            a.d.spw = spw;
-            if (fused_lds_bytes(a, rpb, tgb) <= budget) return true;
-        }
-    a.lds_tab = 0;
-    a.d.spw = 1;
-    return fused_lds_bytes(a, rpb, tgb) <= 150 * 1024;
-}
-hipError_t launch_fused(const FusedArgs& a, hipStream_t st) {
-    switch (a.lenp) {
-        case 8: return launch_fused_tp<2, 4>(a, st);
-        case 12: return launch_fused_tp<3, 4>(a, st);
-        case 16: return launch_fused_tp<4, 4>(a, st);
-        case 20: return launch_fused_tp<5, 4>(a, st);
-        case 24: return launch_fused_tp<6, 2>(a, st);
-        case 32: return launch_fused_tp<8, 2>(a, st);
-        case 40: return launch_fused_tp<10, 1>(a, st);
-        case 48: return launch_fused_tp<12, 1>(a, st);
-        case 64: return launch_fused_tp<16, 1>(a, st);
-        default: return hipErrorInvalidValue;
-    }
-}
-hipError_t launch_unit_sums(const FusedArgs& a, int cpb, int64_t nunits, uint32_t* row_sum, hipStream_t st) {
-    hipLaunchKernelGGL(unit_sums, dim3((unsigned)((nunits + 3) / 4)), dim3(256), 0, st, a.off, a.ntg, a.nbatch, a.d.Lout, a.d.batch, cpb, a.d.N,
-                       nunits, row_sum);
-    return hipGetLastError();
-}
-hipError_t launch_emit_units(const FusedArgs& a, int cpb, const uint32_t* row_excl, const unsigned long long* blk_base, HitRec* hits,
-                             uint16_t* hit_scores, int64_t cap, int64_t n0, hipStream_t st) {
-    const int PG = cand_tile_group(a.lenp);
-    int lsplit = 1;
-    while ((int64_t)a.nbatch * cpb * lsplit < 8192 && lsplit * 8 <= a.d.Lout) lsplit *= 2;   // enough waves to fill the chip
-    const int64_t nw = (int64_t)a.nbatch * cpb * lsplit;
-    hipLaunchKernelGGL(emit_units, dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, st, a.off, a.lists, a.ntg, a.nbatch, a.d.Lout, a.d.batch, cpb,
-                       a.d.N, a.capr, PG * 32, lsplit, row_excl, blk_base, hits, hit_scores, cap, n0);
-    return hipGetLastError();
 }
 
 }  // namespace motifs
