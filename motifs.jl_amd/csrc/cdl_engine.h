@@ -20,6 +20,7 @@
 
 #include <functional>
 #include <map>
+#include <tuple>
 #include <string>
 #include <utility>
 #include <vector>
@@ -92,8 +93,16 @@ struct Engine {
     bool failed = false;           // arena exhausted
     // re-laid-out copies of filter banks (fragment order, flipped, transposed), keyed by source and kind: a bank serves
     // many calls of a pass and its contents are final when the first of them runs
-    std::map<std::pair<const void*, int>, float*> derived;
-    float* relayout(const float* src, int kind, size_t n, bool& fresh);   // fresh: the caller fills it
+    struct RelayoutKey {
+        const void* src;
+        int kind, d0, d1, d2;      // which re-layout and the dimensions it was made for
+        size_t n;                  // its size in floats (the group count is in here)
+        bool operator<(const RelayoutKey& o) const {
+            return std::tie(src, kind, d0, d1, d2, n) < std::tie(o.src, o.kind, o.d0, o.d1, o.d2, o.n);
+        }
+    };
+    std::map<RelayoutKey, float*> derived;
+    float* relayout(const float* src, int kind, int d0, int d1, int d2, size_t n, bool& fresh);   // fresh: the caller fills it
     float* zpool = nullptr;        // current pre-zeroed chunk (dies with the arena at reset())
     size_t zleft = 0;
     std::map<std::string, Tensor> named;
@@ -158,6 +167,6 @@ void median_threshold(hipStream_t st, const float* ZY, float* thr, int G, int n_
 uint32_t* median_hist_ptr(void* workspace, int G);   // the [G][2*2048] counters inside a (zeroed) workspace
 void onehot_from_codes(hipStream_t st, const uint8_t* codes, int pitch, float* S, int nseq, int L);
 void adabelief_step(hipStream_t st, float* x, float* m, float* s, const float* grad, size_t n, float gscale, float eta,
-                    float b1, float b2, float eps, float b1p, float b2p);
+                    float b1, float b2, float eps, double b1p, double b2p);   // b1p, b2p: running powers of beta, kept in double
 
 }  // namespace motifs

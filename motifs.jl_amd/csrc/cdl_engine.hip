@@ -84,9 +84,9 @@ float* Engine::grad(Tensor t) {
     return t->g;
 }
 
-// kind: low 4 bits = which re-layout, the rest = its dimensions (a bank pointer seen with other dimensions is another entry)
-float* Engine::relayout(const float* src, int kind, size_t n, bool& fresh) {
-    auto key = std::make_pair((const void*)src, kind);
+// a bank pointer seen with another re-layout kind or other dimensions is another entry
+float* Engine::relayout(const float* src, int kind, int d0, int d1, int d2, size_t n, bool& fresh) {
+    const RelayoutKey key{(const void*)src, kind, d0, d1, d2, n};
     auto it = derived.find(key);
     fresh = it == derived.end();
     if (!fresh) return it->second;
@@ -1394,7 +1394,7 @@ static bool launch_ana_lds(Engine& e, const float* A, const float* Bm, float* C,
     const int gB = gm.ldb == 0 ? 1 : gm.S / gm.B;
     const size_t perf = (size_t)(gm.Q / 8) * 256;
     bool fresh;
-    float* Bf = e.relayout(Bm, 1 | ((gm.Q << 4) ^ (gm.N << 20)), perf * gB, fresh);
+    float* Bf = e.relayout(Bm, 1, gm.Q, gm.N, 0, perf * gB, fresh);
     if (!Bf) return true;
     if (fresh) hipLaunchKernelGGL(k_frag_b, dim3(nblocks(perf * gB)), dim3(256), 0, e.st, Bm, gB, gm.Q, gm.N, Bf);
     // blocks per CU: the count whose rounds x resident waves is smallest (all blocks take the same time)
@@ -1712,7 +1712,7 @@ static bool launch_rowgemm_lds(Engine& e, const float* A, const float* Bm, float
     const int tpg = (int)((rpg + 31) / 32);
     const size_t perf = (size_t)(rg.Q / 4) * 256;
     bool fresh;
-    float* Bf = e.relayout(Bm, 2 | ((rg.Q << 4) ^ (rg.N << 20)), perf * groups, fresh);
+    float* Bf = e.relayout(Bm, 2, rg.Q, rg.N, 0, perf * groups, fresh);
     if (!Bf) return true;
     if (fresh) hipLaunchKernelGGL(k_frag_b16, dim3(nblocks(perf * groups)), dim3(256), 0, e.st, Bm, groups, rg.Q, rg.N, Bf);
     const int NT = (rg.N + 15) / 16;
@@ -1840,7 +1840,7 @@ static bool launch_toep_wide(Engine& e, const float* A, const float* Bm, float* 
     const int gB = gm.ldb == 0 ? 1 : gm.S / gm.B;
     const size_t perf = (size_t)NCT * KG * 256;
     bool fresh;
-    float* Bf = e.relayout(Bm, 3 | ((gm.Q << 4) ^ (gm.N << 20)), perf * gB, fresh);
+    float* Bf = e.relayout(Bm, 3, gm.Q, gm.N, 0, perf * gB, fresh);
     if (!Bf) return true;
     if (fresh) hipLaunchKernelGGL(k_frag_bw, dim3(nblocks(perf * gB)), dim3(256), 0, e.st, Bm, gB, gm.Q, gm.N, Bf);
     const int tps = (gm.P + 31) / 32;
@@ -1888,7 +1888,7 @@ static void launch_toep(Engine& e, const float* A, const float* Bm, float* C, co
         const int gB = gm.ldb == 0 ? 1 : gm.S / gm.B;
         const size_t per = (size_t)gm.Q * gm.N;
         bool fresh;
-        float* Bt = e.relayout(Bm, 4 | ((gm.sa << 4) ^ (gm.N << 20) ^ (H << 26)), per * gB, fresh);
+        float* Bt = e.relayout(Bm, 4, gm.sa, gm.N, H, per * gB, fresh);
         float* Wt = e.arena.alloc((size_t)gm.S * R * H * gm.N);
         if (!Bt || !Wt) {
             e.failed = true;
@@ -2325,7 +2325,7 @@ static bool toep_adjoint_a(Engine& e, const float* dC, const float* Bm, float* d
     const int gB = gm.ldb == 0 ? 1 : gm.S / gm.B;
     const size_t per = (size_t)gm.Q * gm.N;
     bool fresh;
-    float* tmp = e.relayout(Bm, 5 | ((W << 4) ^ (gm.N << 20) ^ (H << 26)), per * gB, fresh);
+    float* tmp = e.relayout(Bm, 5, W, gm.N, H, per * gB, fresh);
     if (!tmp) return false;
     if (fresh) launch_flipT(e.st, Bm, gB, H, W, gm.N, tmp, 0);
     ToepGeom g2;
@@ -3203,19 +3203,22 @@ void onehot_from_codes(hipStream_t st, const uint8_t* codes, int pitch, float* S
 
 // Flux 0.14 AdaBelief: m, s running moments; the gradient is gscale * grad
 __global__ void k_adabelief(float* x, float* m, float* s, const float* grad, size_t n, float gscale, float eta, float b1,
-                            float b2, float eps, float b1p, float b2p) {
+                            float b2, float eps, float c1, float c2) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const float d = gscale * grad[i];
         const float mt = b1 * m[i] + (1.0f - b1) * d;
         const float st_ = b2 * s[i] + (1.0f - b2) * (d - mt) * (d - mt) + eps;
         m[i] = mt;
         s[i] = st_;
-        x[i] -= eta * mt / (1.0f - b1p) / (sqrtf(st_ / (1.0f - b2p)) + eps);
+        x[i] -= eta * mt / c1 / (sqrtf(st_ / c2) + eps);
     }
 }
 void adabelief_step(hipStream_t st, float* x, float* m, float* s, const float* grad, size_t n, float gscale, float eta,
-                    float b1, float b2, float eps, float b1p, float b2p) {
-    hipLaunchKernelGGL(k_adabelief, dim3(nblocks(n)), dim3(256), 0, st, x, m, s, grad, n, gscale, eta, b1, b2, eps, b1p, b2p);
+                    float b1, float b2, float eps, double b1p, double b2p) {
+    // Flux keeps the running powers of beta in Float64 and forms 1 - beta^t there (Flux 0.14 src/optimise/optimisers.jl, AdaBelief:
+    // `Float64[beta[1], beta[2]]`); in float, 1 - 0.999 is 0.00099998713 instead of 0.001
+    const float c1 = (float)(1.0 - b1p), c2 = (float)(1.0 - b2p);
+    hipLaunchKernelGGL(k_adabelief, dim3(nblocks(n)), dim3(256), 0, st, x, m, s, grad, n, gscale, eta, b1, b2, eps, c1, c2);
 }
 
 }  // namespace motifs

@@ -521,7 +521,7 @@ int motifs_model_adabelief_dev(motifs_model* m, const float* grad_flat_dev, floa
     if (!grad_flat_dev) return MOTIFS_ERR_INVALID;
     MOTIFS_HIP_CHECK(hipSetDevice(m->ctx->device));
     adabelief_step(m->ctx->stream, m->params, m->ada_m, m->ada_s, grad_flat_dev, m->nP, gscale, 1e-3f, 0.9f, 0.999f, 1e-8f,
-                   (float)m->b1p, (float)m->b2p);
+                   m->b1p, m->b2p);
     m->b1p *= 0.9;
     m->b2p *= 0.999;
     MOTIFS_HIP_CHECK(hipGetLastError());
