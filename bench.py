@@ -359,6 +359,10 @@ def main():
         if world > 1:
             tdt = float(par.host_all_reduce(torch.tensor([tdt], dtype=torch.float64), dist.ReduceOp.MAX).item())
         gms, gn = ctx.kernel_ms(lib.KS_TRAIN_STEP)
+        # a4 on its own (SURVEY 8d "conv forward scan"): in L bytes of codes per read, out 2*c*M*4 bytes of dense codes
+        a4_ms = cdl.model.time_filter_scan(tdev.data_ptr(), Gt, reps=10)
+        c_rows = L - args.filter_len + 1
+        a4_bytes = St * (L + 2 * c_rows * args.filters * 4)
         # the reference's own schedule: one optimiser step per 6-read mini-batch (train.jl:40-46)
         for _ in range(3):
             tstep(1)
@@ -374,6 +378,12 @@ def main():
             "ms_per_step_g1": g1dt / g1_steps * 1e3,
             "seqs_per_s_g1": hp.batch_size * world * g1_steps / g1dt,
             "g1_note": "reference schedule (train.jl:40-46): one AdaBelief step per mini-batch of 6 reads per GPU; launch-bound",
+            "filter_scan_a4": {
+                "kernel": "k_toep_wide (warmup_ZY's conv(S,D) pair as one Toeplitz GEMM on v_mfma_f32_32x32x2_f32; model.jl:171-173)",
+                "bound": "hbm", "achieved": a4_bytes / (a4_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": a4_bytes / (a4_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_launch_ms": a4_ms, "algorithmic_bytes": a4_bytes,
+                "reads_per_launch": St, "bases_per_s": St * L / (a4_ms * 1e-3),
+            },
             "loss_first_group": float(tloss[0].item()),
             "grad_allreduce_floats": int(cdl.model.nP) if world > 1 else 0,
             "reference_schedule_equivalent": f"{Gt * world} reference steps (batch 6) worth of reads per step",

@@ -230,6 +230,10 @@ int motifs_model_train_step_onehot(motifs_model* m, const float* S, int n_groups
 /* Replaces code_retrieval (_1_code_retrieval.jl:33-56).  data: host matrix of `kind`, N sequences. */
 int motifs_model_retrieve_codes(motifs_model* m, const void* data, int kind, int64_t N, motifs_code_rec* out,
                                 int64_t cap, int64_t* n_out);
+/* Measurement hook (bench.py, SURVEY.md 8d "conv forward scan"): a4 alone -- warmup_ZY's two convolutions of the reads
+ * with the filter bank (model.jl:171-173), one Toeplitz GEMM over the expanded bank -- launched `reps` times for
+ * n_groups mini-batches; *ms_out = average device time per launch (HIP events on the context's stream). */
+int motifs_model_time_filter_scan(motifs_model* m, const uint8_t* codes_dev, int n_groups, int reps, float* ms_out);
 /* Test hook: a named intermediate of the last loss_grad call made with keep_intermediates != 0. */
 int motifs_model_dump(motifs_model* m, const char* name, float* out, int64_t cap, int64_t* n);
 

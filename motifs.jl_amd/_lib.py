@@ -95,6 +95,7 @@ SIGNATURES = {
     "motifs_hist_allreduce": (_int, [_p, _p, _int, _int]),
     "motifs_model_dp_train_step_dev": (_int, [_p, _p, _p, _int, _i64, _p, _p]),
     "motifs_model_retrieve_codes": (_int, [_p, _p, _int, _i64, _p, _i64, C.POINTER(_i64)]),
+    "motifs_model_time_filter_scan": (_int, [_p, _p, _int, _int, C.POINTER(C.c_float)]),
     "motifs_model_dump": (_int, [_p, C.c_char_p, _p, _i64, C.POINTER(_i64)]),
     "motifs_fasta_read": (_int, [C.c_char_p, _i64, _p, _i64, C.POINTER(_i64), C.POINTER(C.c_int32)]),
     "motifs_hits_minmax_dev": (_int, [_p, _p, _p, _i64, _int, _p, _p]),
@@ -432,6 +433,12 @@ class Model:
         out = np.zeros(max(cap, 1), dtype=CODE_DTYPE)
         check(lib().motifs_model_retrieve_codes(self._h, _np_ptr(data), int(kind), int(N), _np_ptr(out), int(cap), C.byref(n_out)))
         return out[: n_out.value]
+
+    def time_filter_scan(self, codes_ptr, n_groups, reps=5):
+        """Average device ms of a4 (warmup_ZY's filter-bank scan) alone, a measurement hook for bench.py."""
+        ms = C.c_float(0)
+        check(lib().motifs_model_time_filter_scan(self._h, _p(codes_ptr), int(n_groups), int(reps), C.byref(ms)))
+        return ms.value
 
     def dump(self, name):
         n = _i64(0)
