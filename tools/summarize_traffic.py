@@ -8,13 +8,15 @@ import json
 import sys
 
 tag, out = sys.argv[1], sys.argv[2]
+commit = sys.argv[3] if len(sys.argv) > 3 else None
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
     with open(f"gpurun_out/{tag}_pmc_{ctr}/out_counter_collection.csv") as fh:
         for r in csv.DictReader(fh):
             if r["Counter_Name"] == ctr:
                 acc[r["Kernel_Name"].split("(")[0]][ctr].append(float(r["Counter_Value"]))
-res = {"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/profile_round.sh) over tools/prof_scan.py "
+res = {"commit": commit, "command": "bash tools/profile_round.sh " + tag + "  (on the GPU box: rocprofv3 --pmc FETCH_SIZE --kernel-trace ... -- python3 tools/prof_scan.py; the same with WRITE_SIZE), then python tools/summarize_traffic.py " + tag + " <out> <commit>",
+       "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/profile_round.sh) over tools/prof_scan.py "
                "at BASELINE configs[1] (100k reads x 200 bp, 200 PWMs len 12; dense launches: 20k reads). Per-launch averages. "
                "hbm_bytes_per_launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 read-side correction).", "kernels": {}}
 for k, v in acc.items():
