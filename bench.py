@@ -325,13 +325,40 @@ def main():
                 n_h += len(f)
             hdt = time.perf_counter() - t0
             assert n_h == sum(need), (n_h, need)
+            ctx.pwm_scan_both(bank, lens, onehot, lib.DATA_ONEHOT_F32, N, L, cap=cap_h)
+            t0 = time.perf_counter()
+            both = ctx.pwm_scan_both(bank, lens, onehot, lib.DATA_ONEHOT_F32, N, L, cap=cap_h)
+            bdt = time.perf_counter() - t0
+            assert len(both[0][0]) + len(both[1][0]) == sum(need)
             extras["host_entry"] = {
-                "entry": "motifs_pwm_scan (host Float32 one-hot matrix in, host records out), one call per strand as gpu_scan makes them",
-                "bases_per_s": N * L / hdt, "ms_both_strands": hdt * 1e3,
-                "h2d_bytes_per_strand": int(onehot.nbytes), "d2h_bytes_both_strands": int(n_h * 14),
-                "note": "PCIe-inclusive and pageable host memory: upload of 16 B/base per strand, download of 14 B/hit; never `value`",
+                "entry": "motifs_pwm_scan_both (gpu_scan, _h3_1_alignment.jl:89-99: host Float32 one-hot matrix in, the two strands' host records out, one upload)",
+                "bases_per_s": N * L / bdt, "ms_both_strands": bdt * 1e3,
+                "per_strand_entry": {"entry": "motifs_pwm_scan, one call per strand (get_pos_scores_arr, :57-87)", "bases_per_s": N * L / hdt,
+                                     "ms_both_strands": hdt * 1e3},
+                "h2d_bytes": int(onehot.nbytes), "d2h_bytes_both_strands": int(n_h * 14),
+                "note": "PCIe-inclusive and pageable host memory: upload of 16 B/base, download of 14 B/hit; never `value`",
             }
             del onehot
+            # ---- FASTA text -> base codes (loadfasta/helpers.jl:83-139), host threads only ----
+            import tempfile
+
+            rows = np.frombuffer(b"ACGT", dtype=np.uint8)[codes]
+            with tempfile.NamedTemporaryFile("wb", suffix=".fa", delete=False) as fh:
+                fa_path = fh.name
+                for i in range(N):
+                    fh.write(b">s%d\n" % i)
+                    fh.write(rows[i].tobytes())
+                    fh.write(b"\n")
+            fa_bytes = os.path.getsize(fa_path)
+            lib.fasta_read(fa_path)
+            t0 = time.perf_counter()
+            fa = lib.fasta_read(fa_path)
+            fdt = time.perf_counter() - t0
+            os.remove(fa_path)
+            assert np.array_equal(fa, codes)
+            extras["fasta_reader"] = {"bases_per_s": N * L / fdt, "file_MB_per_s": fa_bytes / fdt / 1e6, "ms": fdt * 1e3, "file_bytes": fa_bytes,
+                                      "host_threads": min(32, os.cpu_count() or 1),
+                                      "note": "motifs_fasta_read, query + fill call (the file is parsed twice), page-cache resident file"}
 
     # ---- conv-train step (BASELINE metric, second half): unrolled-ADMM forward/backward + AdaBelief ----
     train = None

@@ -175,6 +175,12 @@ int motifs_pwm_scan(motifs_ctx* ctx, const uint16_t* pwms_fp16, const int64_t* l
                     motifs_hit* hits, uint16_t* hit_scores, int64_t cap, int64_t* n_out,
                     int64_t* per_pwm_counts);
 
+/* gpu_scan (_h3_1_alignment.jl:89-99) on host buffers: one upload of `data`, both strands, two record lists of `cap`
+ * entries each; n_out2 = {forward, reverse} totals; per_pwm_counts2 = optional 2*K host int64. */
+int motifs_pwm_scan_both(motifs_ctx* ctx, const uint16_t* pwms_fp16, const int64_t* lens, int K, int maxlen, const void* data,
+                         int kind, int64_t N, int L, motifs_hit* hits_fwd, uint16_t* scores_fwd, motifs_hit* hits_rc,
+                         uint16_t* scores_rc, int64_t cap, int64_t* n_out2, int64_t* per_pwm_counts2);
+
 /* ---- convolutional sparse coding: src/model.jl, src/train.jl, _1_code_retrieval.jl ------------ */
 
 /* Hyperparam (model.jl:1-14); f_len = 4*filter_len and twoM = 2*M are derived. */

@@ -229,12 +229,35 @@ function modify_w_found!(found_record, score_record, positions, scores, use_comp
     end
 end
 
-function gpu_scan(ms, data; bg=false, test=false, ctx::Context=context())      # :89-99
-    found_record, score_record = get_pos_scores_arr(ms, data; rc=false, bg=bg, test=test, ctx=ctx)
-    found_record_rc, score_record_rc = get_pos_scores_arr(ms, data; rc=true, bg=bg, test=test, ctx=ctx)
+# :89-99 through motifs_pwm_scan_both: the Float32 matrix crosses PCIe once for the two strands
+function gpu_scan(ms, data; bg=false, test=false, ctx::Context=context())
+    data_matrix = bg ? data_bg(data; test=test) : data_(data; test=test)
+    length(size(data_matrix)) == 2 && (data_matrix = reshape(data_matrix, (size(data_matrix, 1), 1, size(data_matrix, 2))))
+    data_matrix = Array{Float32}(data_matrix)
+    L4, _, N = size(data_matrix)
+    K = ms.num_motifs; maxlen = maximum(ms.lens)
+    pwms = zeros(float_type_retrieval, K, 4, maxlen)
+    for i in 1:K; pwms[i, :, 1:ms.lens[i]] = ms.pwms[i]; end
+    lens = Int64.(ms.lens); n2 = zeros(Int64, 2)
+    cap = max(1024, (N * (L4 ÷ 4) * K) ÷ 64)
+    found = [Vector{record_t}(undef, cap) for _ in 1:2]; score = [Vector{float_type_retrieval}(undef, cap) for _ in 1:2]
+    f1 = found[1]; f2 = found[2]; s1 = score[1]; s2 = score[2]
+    status = GC.@preserve pwms lens data_matrix f1 f2 s1 s2 n2 ccall((:motifs_pwm_scan_both, lib), Cint,
+        (Ptr{Cvoid}, Ptr{UInt16}, Ptr{Int64}, Cint, Cint, Ptr{Cvoid}, Cint, Int64, Cint, Ptr{Cvoid}, Ptr{UInt16}, Ptr{Cvoid}, Ptr{UInt16},
+         Int64, Ptr{Int64}, Ptr{Int64}),
+        ctx.h, pwms, lens, K, maxlen, data_matrix, 1, N, L4 ÷ 4, f1, s1, f2, s2, cap, n2, C_NULL)
+    if status == 4                                              # MOTIFS_ERR_BUFFER_TOO_SMALL: n2 holds the required counts
+        cap = maximum(n2); resize!(f1, cap); resize!(f2, cap); resize!(s1, cap); resize!(s2, cap)
+        status = GC.@preserve pwms lens data_matrix f1 f2 s1 s2 n2 ccall((:motifs_pwm_scan_both, lib), Cint,
+            (Ptr{Cvoid}, Ptr{UInt16}, Ptr{Int64}, Cint, Cint, Ptr{Cvoid}, Cint, Int64, Cint, Ptr{Cvoid}, Ptr{UInt16}, Ptr{Cvoid}, Ptr{UInt16},
+             Int64, Ptr{Int64}, Ptr{Int64}),
+            ctx.h, pwms, lens, K, maxlen, data_matrix, 1, N, L4 ÷ 4, f1, s1, f2, s2, cap, n2, C_NULL)
+    end
+    check(status)
+    resize!(f1, n2[1]); resize!(s1, n2[1]); resize!(f2, n2[2]); resize!(s2, n2[2])
     positions, scores, use_comp = motifs_prep(ms)
-    modify_w_found!(found_record, score_record, positions, scores, use_comp; rc=false)
-    modify_w_found!(found_record_rc, score_record_rc, positions, scores, use_comp; rc=true)
+    modify_w_found!(f1, s1, positions, scores, use_comp; rc=false)
+    modify_w_found!(f2, s2, positions, scores, use_comp; rc=true)
     return positions, scores, use_comp
 end
 

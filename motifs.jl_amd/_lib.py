@@ -111,6 +111,10 @@ SIGNATURES = {
         _int,
         [_p, _p, _p, _int, _int, _p, _int, _i64, _int, _int, _p, _p, _i64, C.POINTER(_i64), _p],
     ),
+    "motifs_pwm_scan_both": (
+        _int,
+        [_p, _p, _p, _int, _int, _p, _int, _i64, _int, _p, _p, _p, _p, _i64, C.POINTER(_i64), _p],
+    ),
 }
 
 
@@ -322,6 +326,26 @@ class Context:
         n = n_out.value
         out = (hits[:n], scores[:n].view(np.float16))
         return out + (counts,) if want_counts else out
+
+
+def _pwm_scan_both(self, pwms, lens, data, kind, N, L, cap=None):
+    """gpu_scan on host buffers (one upload, both strands).  Returns ((found_fwd, score_fwd), (found_rc, score_rc))."""
+    pwms, lens, K, maxlen = _bank(pwms, lens)
+    data = np.ascontiguousarray(data)
+    n_out = (_i64 * 2)(0, 0)
+    if cap is None:
+        check(lib().motifs_pwm_scan_both(self._h, _np_ptr(pwms), _np_ptr(lens), K, maxlen, _np_ptr(data), int(kind), int(N), int(L),
+                                         None, None, None, None, 0, n_out, None))
+        cap = max(n_out[0], n_out[1])
+    hits = [np.zeros(max(cap, 1), dtype=HIT_DTYPE) for _ in range(2)]
+    scores = [np.zeros(max(cap, 1), dtype=np.uint16) for _ in range(2)]
+    check(lib().motifs_pwm_scan_both(self._h, _np_ptr(pwms), _np_ptr(lens), K, maxlen, _np_ptr(data), int(kind), int(N), int(L),
+                                     _np_ptr(hits[0]) if cap else None, _np_ptr(scores[0]) if cap else None,
+                                     _np_ptr(hits[1]) if cap else None, _np_ptr(scores[1]) if cap else None, int(cap), n_out, None))
+    return tuple((hits[s][: n_out[s]], scores[s][: n_out[s]].view(np.float16)) for s in range(2))
+
+
+Context.pwm_scan_both = _pwm_scan_both
 
 
 def fasta_read(path, max_entries=100000):

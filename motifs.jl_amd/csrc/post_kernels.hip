@@ -12,6 +12,9 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <climits>
+#include <functional>
+#include <thread>
 
 #include "api_common.h"
 #include "scan_kernels.h"
@@ -274,36 +277,94 @@ int motifs_fasta_read(const char* path, int64_t max_entries, uint8_t* codes_out,
         set_error("motifs_fasta_read: cannot open %s", path);
         return MOTIFS_ERR_INVALID;
     }
-    std::string text;
-    char buf[1 << 16];
-    size_t got;
-    while ((got = fread(buf, 1, sizeof(buf), f)) > 0) text.append(buf, got);
-    fclose(f);
-    std::vector<std::string> reads;
-    size_t pos = 0;
-    while (pos <= text.size()) {                   // records between '>' characters
-        size_t nxt = text.find('>', pos);
-        if (nxt == std::string::npos) nxt = text.size();
-        if (nxt > pos) {                           // !isempty(i)
-            const std::string rec = text.substr(pos, nxt - pos);
-            size_t nl = rec.find('\n');
-            std::string seq;
-            if (nl != std::string::npos)
-                for (size_t i = nl + 1; i < rec.size(); i++)
-                    if (rec[i] != '\n') seq.push_back(rec[i]);           // join(splits[2:end])
-            if (seq.find('N') == std::string::npos && seq.find('n') == std::string::npos) reads.push_back(seq);
-        }
-        pos = nxt + 1;
+    std::vector<char> text;
+    if (fseek(f, 0, SEEK_END) == 0) {
+        const long sz = ftell(f);
+        rewind(f);
+        if (sz > 0) text.resize((size_t)sz);
+        const size_t got = text.empty() ? 0 : fread(text.data(), 1, text.size(), f);
+        text.resize(got);
     }
-    if ((int64_t)reads.size() > max_entries) reads.resize((size_t)max_entries);
-    if (reads.empty()) {
+    fclose(f);
+    const char* t = text.data();
+    const size_t tn = text.size();
+    const unsigned hw = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+    // fn(begin, end) over [0, n) in contiguous pieces, one host thread each (the file is tens of MB: worth the threads)
+    auto parallel = [&](size_t n, size_t grain, const std::function<void(size_t, size_t, unsigned)>& fn) -> unsigned {
+        const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(hw, n / std::max<size_t>(grain, 1)));
+        std::vector<std::thread> th;
+        for (unsigned i = 1; i < T; i++) th.emplace_back(fn, n * i / T, n * (i + 1) / T, i);
+        fn(0, n / T, 0u);
+        for (auto& x : th) x.join();
+        return T;
+    };
+    // 1. records lie between '>' characters (`split(reads, '>')`, helpers.jl:85)
+    std::vector<std::vector<size_t>> marks(hw);
+    parallel(tn, 1 << 20, [&](size_t lo, size_t hi, unsigned ti) {
+        for (const char* p = t + lo; p < t + hi;) {
+            const char* q = (const char*)memchr(p, '>', (size_t)(t + hi - p));
+            if (!q) break;
+            marks[ti].push_back((size_t)(q - t));
+            p = q + 1;
+        }
+    });
+    struct Rec {
+        size_t b, e;        // the sequence text: after the header line, up to the next '>'
+        size_t len;         // its characters without the line breaks (`join(splits[2:end])`, :88)
+        bool has_n;
+    };
+    std::vector<Rec> recs;
+    {
+        size_t pos = 0;
+        auto add = [&](size_t lo, size_t hi) {
+            if (hi > lo) recs.push_back(Rec{lo, hi, 0, false});      // !isempty(i)
+        };
+        for (const auto& v : marks)
+            for (size_t m : v) {
+                add(pos, m);
+                pos = m + 1;
+            }
+        add(pos, tn);
+    }
+    // 2. per record: drop the header line, measure the sequence, look for N / n (:92)
+    parallel(recs.size(), 4096, [&](size_t lo, size_t hi, unsigned) {
+        for (size_t i = lo; i < hi; i++) {
+            Rec& r = recs[i];
+            const char* nl = (const char*)memchr(t + r.b, '\n', r.e - r.b);
+            if (!nl) {                                               // a header without a sequence: an empty read
+                r.b = r.e;
+                continue;
+            }
+            r.b = (size_t)(nl + 1 - t);
+            size_t breaks = 0;                                       // memchr hops: the lines are long, libc's scan is vectorised
+            for (const char* p = t + r.b; p < t + r.e;) {
+                const char* q = (const char*)memchr(p, '\n', (size_t)(t + r.e - p));
+                if (!q) break;
+                breaks++;
+                p = q + 1;
+            }
+            r.len = r.e - r.b - breaks;
+            r.has_n = memchr(t + r.b, 'N', r.e - r.b) != nullptr || memchr(t + r.b, 'n', r.e - r.b) != nullptr;
+        }
+    });
+    // 3. reads with N dropped, the first max_entries kept (:95), then only reads as long as the first (:98)
+    std::vector<const Rec*> keep;
+    for (const Rec& r : recs) {
+        if (r.has_n) continue;
+        if ((int64_t)keep.size() >= max_entries) break;
+        keep.push_back(&r);
+    }
+    if (keep.empty()) {
         set_error("There aren't DNA strings found in the input");          // helpers.jl:131
         return MOTIFS_ERR_INVALID;
     }
-    const size_t len0 = reads[0].size();
-    std::vector<const std::string*> keep;
-    for (const auto& s : reads)
-        if (s.size() == len0) keep.push_back(&s);
+    const size_t len0 = keep[0]->len;
+    {
+        size_t w = 0;
+        for (const Rec* r : keep)
+            if (r->len == len0) keep[w++] = r;
+        keep.resize(w);
+    }
     *n_reads = (int64_t)keep.size();
     *L = (int32_t)len0;
     if (!codes_out) return MOTIFS_OK;
@@ -311,20 +372,46 @@ int motifs_fasta_read(const char* path, int64_t max_entries, uint8_t* codes_out,
         set_error("motifs_fasta_read: buffer too small (%zu bytes needed)", keep.size() * len0);
         return MOTIFS_ERR_BUFFER_TOO_SMALL;
     }
-    for (size_t i = 0; i < keep.size(); i++)
-        for (size_t p = 0; p < len0; p++) {
-            uint8_t code;
-            switch ((*keep[i])[p]) {
-                case 'A': case 'a': code = 0; break;
-                case 'C': case 'c': code = 1; break;
-                case 'G': case 'g': code = 2; break;
-                case 'T': case 't': code = 3; break;
-                default:
-                    set_error("motifs_fasta_read: read %zu has '%c' at %zu (the reference's dna2dummy raises a KeyError)", i + 1,
-                              (*keep[i])[p], p + 1);
-                    return MOTIFS_ERR_INVALID;
+    // 4. base codes (dna2dummy's Dict, :110-117): A C G T in either case; anything else is the reference's KeyError.
+    // Line by line, branch-free so that the compiler vectorises it: with x = (ch >> 1) & 3, A C G T give 0 1 3 2,
+    // and x ^ (x >> 1) is 0 1 2 3.
+    std::vector<size_t> bad_read(hw, SIZE_MAX), bad_pos(hw, 0);
+    std::vector<char> bad_ch(hw, 0);
+    parallel(keep.size(), 2048, [&](size_t lo, size_t hi, unsigned ti) {
+        for (size_t i = lo; i < hi; i++) {
+            uint8_t* __restrict out = codes_out + i * len0;
+            size_t k = 0;
+            for (const char* p = t + keep[i]->b; p < t + keep[i]->e;) {
+                const char* q = (const char*)memchr(p, '\n', (size_t)(t + keep[i]->e - p));
+                const size_t n = (size_t)((q ? q : t + keep[i]->e) - p);
+                const unsigned char* __restrict in = (const unsigned char*)p;
+                unsigned bad = 0;
+                for (size_t j = 0; j < n; j++) {
+                    const unsigned ch = in[j], up = ch & 0xdfu, x = (ch >> 1) & 3u;
+                    bad |= (unsigned)((up != 'A') & (up != 'C') & (up != 'G') & (up != 'T'));
+                    out[k + j] = (uint8_t)(x ^ (x >> 1));
+                }
+                if (bad) {
+                    for (size_t j = 0; j < n; j++) {
+                        const unsigned up = in[j] & 0xdfu;
+                        if (up != 'A' && up != 'C' && up != 'G' && up != 'T') {
+                            bad_read[ti] = i;
+                            bad_pos[ti] = k + j;
+                            bad_ch[ti] = (char)in[j];
+                            return;
+                        }
+                    }
+                }
+                k += n;
+                p += n + 1;
             }
-            codes_out[i * len0 + p] = code;
+        }
+    });
+    for (unsigned ti = 0; ti < hw; ti++)                               // pieces are in read order: the first failing piece holds the first failing read
+        if (bad_read[ti] != SIZE_MAX) {
+            set_error("motifs_fasta_read: read %zu has '%c' at %zu (the reference's dna2dummy raises a KeyError)", bad_read[ti] + 1, bad_ch[ti],
+                      bad_pos[ti] + 1);
+            return MOTIFS_ERR_INVALID;
         }
     return MOTIFS_OK;
 }

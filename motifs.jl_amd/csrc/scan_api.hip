@@ -836,23 +836,15 @@ int motifs_pwm_scan_hits_both_dev(motifs_ctx* c, const uint16_t* pwms_fp16, cons
     return MOTIFS_OK;
 }
 
-int motifs_pwm_scan(motifs_ctx* c, const uint16_t* pwms_fp16, const int64_t* lens, int K, int maxlen, const void* data,
-                    int kind, int64_t N, int L, int rc, motifs_hit* hits, uint16_t* hit_scores, int64_t cap,
-                    int64_t* n_out, int64_t* per_pwm_counts) {
-    if (!c || !n_out || N < 0 || L <= 0 || kind < 0 || kind > 2 || (N > 0 && !data) || cap < 0 ||
-        (cap > 0 && (!hits || !hit_scores))) {
-        set_error("motifs_pwm_scan: bad argument");
-        return MOTIFS_ERR_INVALID;
-    }
-    MOTIFS_HIP_CHECK(hipSetDevice(c->device));
+// host matrix of `kind` -> c->codes (the internal code matrix), checked for one-hot columns
+static int upload_and_encode(motifs_ctx* c, const void* data, int kind, int64_t N, int L) {
     const size_t elt = kind == MOTIFS_DATA_ONEHOT_F32 ? 16 : kind == MOTIFS_DATA_ONEHOT_F16 ? 8 : 1;
     MOTIFS_HIP_CHECK(c->codes.reserve(motifs_codes_bytes(N, L)));
-    int32_t* bad_dev = nullptr;
     MOTIFS_HIP_CHECK(c->small.reserve(4096));
     // encode in slabs so the staging buffer stays bounded (<= 1 GiB)
     const int64_t slab = std::max<int64_t>(1, (int64_t)((1ull << 30) / ((size_t)L * elt)));
     MOTIFS_HIP_CHECK(c->data_tmp.reserve((size_t)std::min<int64_t>(slab, std::max<int64_t>(N, 1)) * L * elt + 64));
-    bad_dev = (int32_t*)((char*)c->small.p + 2048);
+    int32_t* bad_dev = (int32_t*)((char*)c->small.p + 2048);
     MOTIFS_HIP_CHECK(hipMemsetAsync(bad_dev, 0, 4, c->stream));
     const int pitch = motifs_codes_pitch(L);
     for (int64_t s0 = 0; s0 < N; s0 += slab) {
@@ -870,24 +862,83 @@ int motifs_pwm_scan(motifs_ctx* c, const uint16_t* pwms_fp16, const int64_t* len
         set_error("data matrix has a column that is neither one-hot nor all-zero");
         return MOTIFS_ERR_NOT_ONEHOT;
     }
+    return MOTIFS_OK;
+}
+
+int motifs_pwm_scan(motifs_ctx* c, const uint16_t* pwms_fp16, const int64_t* lens, int K, int maxlen, const void* data,
+                    int kind, int64_t N, int L, int rc, motifs_hit* hits, uint16_t* hit_scores, int64_t cap,
+                    int64_t* n_out, int64_t* per_pwm_counts) {
+    if (!c || !n_out || N < 0 || L <= 0 || kind < 0 || kind > 2 || (N > 0 && !data) || cap < 0 ||
+        (cap > 0 && (!hits || !hit_scores))) {
+        set_error("motifs_pwm_scan: bad argument");
+        return MOTIFS_ERR_INVALID;
+    }
+    MOTIFS_HIP_CHECK(hipSetDevice(c->device));
+    int r = upload_and_encode(c, data, kind, N, L);
+    if (r) return r;
     if (cap > 0) {
         MOTIFS_HIP_CHECK(c->hits_tmp.reserve((size_t)cap * sizeof(motifs_hit)));
         MOTIFS_HIP_CHECK(c->scores_tmp.reserve((size_t)cap * 2));
     }
     int64_t* counts_dev = nullptr;
     if (per_pwm_counts) {
-        // second half of `small` is free above the batch table only for small nbatch; use a dedicated block
         MOTIFS_HIP_CHECK(c->data_tmp.reserve((size_t)K * 8));
         counts_dev = (int64_t*)c->data_tmp.p;
     }
-    int r = motifs_pwm_scan_hits_dev(c, pwms_fp16, lens, K, maxlen, (const uint8_t*)c->codes.p, N, L, rc, 0,
-                                     MOTIFS_SCAN_BATCH, cap > 0 ? (motifs_hit*)c->hits_tmp.p : nullptr,
-                                     cap > 0 ? (uint16_t*)c->scores_tmp.p : nullptr, cap, n_out, counts_dev);
+    r = motifs_pwm_scan_hits_dev(c, pwms_fp16, lens, K, maxlen, (const uint8_t*)c->codes.p, N, L, rc, 0,
+                                 MOTIFS_SCAN_BATCH, cap > 0 ? (motifs_hit*)c->hits_tmp.p : nullptr,
+                                 cap > 0 ? (uint16_t*)c->scores_tmp.p : nullptr, cap, n_out, counts_dev);
     if (per_pwm_counts && (r == MOTIFS_OK || r == MOTIFS_ERR_BUFFER_TOO_SMALL))
         MOTIFS_HIP_CHECK(hipMemcpyAsync(per_pwm_counts, counts_dev, (size_t)K * 8, hipMemcpyDeviceToHost, c->stream));
     if (r == MOTIFS_OK && cap > 0 && *n_out > 0) {
         MOTIFS_HIP_CHECK(hipMemcpyAsync(hits, c->hits_tmp.p, (size_t)*n_out * sizeof(motifs_hit), hipMemcpyDeviceToHost, c->stream));
         MOTIFS_HIP_CHECK(hipMemcpyAsync(hit_scores, c->scores_tmp.p, (size_t)*n_out * 2, hipMemcpyDeviceToHost, c->stream));
+    }
+    MOTIFS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return r;
+}
+
+// gpu_scan (_h3_1_alignment.jl:89-99) on host buffers: the matrix is uploaded and encoded once, both strands are scanned
+// by one device call, the two record lists come back.
+int motifs_pwm_scan_both(motifs_ctx* c, const uint16_t* pwms_fp16, const int64_t* lens, int K, int maxlen, const void* data, int kind,
+                         int64_t N, int L, motifs_hit* hits_fwd, uint16_t* scores_fwd, motifs_hit* hits_rc, uint16_t* scores_rc, int64_t cap,
+                         int64_t* n_out2, int64_t* per_pwm_counts2) {
+    if (!c || !n_out2 || N < 0 || L <= 0 || kind < 0 || kind > 2 || (N > 0 && !data) || cap < 0 ||
+        (cap > 0 && (!hits_fwd || !scores_fwd || !hits_rc || !scores_rc))) {
+        set_error("motifs_pwm_scan_both: bad argument");
+        return MOTIFS_ERR_INVALID;
+    }
+    MOTIFS_HIP_CHECK(hipSetDevice(c->device));
+    int r = upload_and_encode(c, data, kind, N, L);
+    if (r) return r;
+    motifs_hit* hd[2] = {nullptr, nullptr};
+    uint16_t* sd[2] = {nullptr, nullptr};
+    if (cap > 0) {
+        const int64_t cap8 = (cap + 7) & ~(int64_t)7;      // the reverse strand's scores start 16-byte aligned
+        MOTIFS_HIP_CHECK(c->hits_tmp.reserve((size_t)2 * cap * sizeof(motifs_hit)));
+        MOTIFS_HIP_CHECK(c->scores_tmp.reserve((size_t)(cap8 + cap) * 2));
+        hd[0] = (motifs_hit*)c->hits_tmp.p;
+        hd[1] = hd[0] + cap;
+        sd[0] = (uint16_t*)c->scores_tmp.p;
+        sd[1] = sd[0] + cap8;
+    }
+    int64_t* counts_dev = nullptr;
+    if (per_pwm_counts2) {
+        MOTIFS_HIP_CHECK(c->data_tmp.reserve((size_t)2 * K * 8));
+        counts_dev = (int64_t*)c->data_tmp.p;
+    }
+    r = motifs_pwm_scan_hits_both_dev(c, pwms_fp16, lens, K, maxlen, (const uint8_t*)c->codes.p, N, L, 0, MOTIFS_SCAN_BATCH, hd[0], sd[0], hd[1],
+                                      sd[1], cap, n_out2, counts_dev);
+    if (per_pwm_counts2 && (r == MOTIFS_OK || r == MOTIFS_ERR_BUFFER_TOO_SMALL))
+        MOTIFS_HIP_CHECK(hipMemcpyAsync(per_pwm_counts2, counts_dev, (size_t)2 * K * 8, hipMemcpyDeviceToHost, c->stream));
+    if (r == MOTIFS_OK && cap > 0) {
+        motifs_hit* hh[2] = {hits_fwd, hits_rc};
+        uint16_t* sh[2] = {scores_fwd, scores_rc};
+        for (int s = 0; s < 2; s++)
+            if (n_out2[s] > 0) {
+                MOTIFS_HIP_CHECK(hipMemcpyAsync(hh[s], hd[s], (size_t)n_out2[s] * sizeof(motifs_hit), hipMemcpyDeviceToHost, c->stream));
+                MOTIFS_HIP_CHECK(hipMemcpyAsync(sh[s], sd[s], (size_t)n_out2[s] * 2, hipMemcpyDeviceToHost, c->stream));
+            }
     }
     MOTIFS_HIP_CHECK(hipStreamSynchronize(c->stream));
     return r;

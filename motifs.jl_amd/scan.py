@@ -110,9 +110,14 @@ def modify_w_found(found_record, score_record, positions, scores, use_comp, rc=F
 
 
 def gpu_scan(ms, data, bg=False, test=False, ctx=None):
-    """:89-99."""
-    found, score = get_pos_scores_arr(ms, data, rc=False, bg=bg, test=test, ctx=ctx)
-    found_rc, score_rc = get_pos_scores_arr(ms, data, rc=True, bg=bg, test=test, ctx=ctx)
+    """:89-99.  Both strands through one library call (`motifs_pwm_scan_both`): the data matrix crosses PCIe once."""
+    ctx = ctx or default_context()
+    data_matrix = data_bg(data, test=test) if bg else data_(data, test=test)
+    data_matrix = np.ascontiguousarray(data_matrix, dtype=np.float32)
+    N = data_matrix.shape[0]
+    data_matrix = data_matrix.reshape(N, -1)
+    (found, score), (found_rc, score_rc) = ctx.pwm_scan_both(pad_bank(ms.pwms, ms.lens), ms.lens, data_matrix, _lib.DATA_ONEHOT_F32, N,
+                                                             data_matrix.shape[1] // 4)
     positions, scores, use_comp = motifs_prep(ms)
     modify_w_found(found, score, positions, scores, use_comp, rc=False)
     modify_w_found(found_rc, score_rc, positions, scores, use_comp, rc=True)

@@ -31,6 +31,42 @@ def test_fasta_read_matches_reading(pkg, tmp_path):
     assert len(po.read_fasta(str(p), 3)) == 2                     # s1, s3, (s4 dropped by length)
 
 
+def test_fasta_reader_on_a_messy_file(pkg, tmp_path):
+    """The threaded reader against the restatement of `reading` on 3000 records: wrapped lines, mixed case, reads with N,
+    other lengths, a header without a sequence at the end, the cap before the length filter."""
+    import random
+
+    rnd = random.Random(7)
+    parts = []
+    for i in range(3000):
+        s_ = "".join(rnd.choice("ACGTacgt") for _ in range(90))
+        if i % 17 == 0:
+            s_ = s_[:10] + rnd.choice("Nn") + s_[11:]
+        if i % 23 == 0:
+            s_ = s_[:30]
+        w = rnd.choice([25, 60, 90])
+        parts.append(">r%d some text\n" % i + "\n".join(s_[j:j + w] for j in range(0, len(s_), w)) + "\n")
+    parts.append(">last_without_sequence")
+    p = tmp_path / "messy.fa"
+    p.write_text("".join(parts))
+    for cap in (100000, 1500, 1):
+        want = po.read_fasta(str(p), cap)
+        got = pkg._lib.fasta_read(str(p), max_entries=cap)
+        if want and len(want[0]) > 0:
+            assert np.array_equal(got, po.reads_to_codes(want)), cap
+        else:
+            assert got.shape[0] == len(want)
+    # text before the first '>' is a record too (its first line plays the header): here an empty read, so only empty reads survive
+    p.write_text("ACGTACGTAC\n" + "".join(parts))
+    assert pkg._lib.fasta_read(str(p)).shape == (len(po.read_fasta(str(p))), 0)
+    # an invalid base deep in the file: the first offending read is named
+    bad = "".join(parts[:2000]) + ">bad\n" + "ACGT" * 10 + "R" + "ACGT" * 12 + "A\n" + "".join(parts[2000:])
+    p.write_text(bad)
+    with pytest.raises(pkg._lib.MotifsError) as e:
+        pkg._lib.fasta_read(str(p))
+    assert "'R' at 41" in str(e.value)
+
+
 def test_fasta_errors(pkg, tmp_path):
     p = tmp_path / "b.fa"
     p.write_text(">x\nACGR\n")

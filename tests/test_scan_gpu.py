@@ -175,6 +175,14 @@ def test_host_entry_and_mirror(torch_cuda, ctx, pkg):
         of, os_ = so.get_pos_scores_arr(bank, lens, onehot, rc=rc)
         assert np.array_equal(found, of) and np.array_equal(score.view(np.uint16), os_.view(np.uint16))
         assert found["n"].max() > 5000
+    # gpu_scan's host entry (one upload, both strands) against the two single-strand calls
+    both = ctx.pwm_scan_both(bank, lens, onehot, pkg._lib.DATA_ONEHOT_F32, N, L)
+    for rc in (0, 1):
+        f1, s1 = ctx.pwm_scan(bank, lens, onehot, pkg._lib.DATA_ONEHOT_F32, N, L, bool(rc))
+        assert np.array_equal(both[rc][0], f1) and np.array_equal(both[rc][1].view(np.uint16), s1.view(np.uint16))
+    with pytest.raises(pkg._lib.MotifsError) as e:
+        ctx.pwm_scan_both(bank, lens, onehot, pkg._lib.DATA_ONEHOT_F32, N, L, cap=10)
+    assert e.value.code == pkg._lib.ERR_BUFFER_TOO_SMALL
     sc.scan_w_gpu(ms, data, ctx=ctx)
     # per (m, n): forward hits in ascending l, then reverse-strand hits in ascending l
     m0 = next(i for i, d in enumerate(ms.positions) if d)
