@@ -229,8 +229,17 @@ def warmup_X(F, Z, Y, omega_stepsize_warmup, hp, ln):                          #
     return project_X(X_updated, hp)
 
 
+# torch's conv2d cannot run the literal padded grouped form of syn_FX at BASELINE configs[3] shape (it asks for a 290 GB
+# work buffer) and is slow on F_gradient's 144-group form.  FAST_SYNTAX = True uses the same sums written directly:
+# FX = conv_transpose2d(X, F) (sum_k sum_p X[b,k,p] F[k,j,i-p]) and F_grad = einsum over the h windows of the residual.
+# Equality with the literal forms: tests/test_oracle_model.py::test_needed_lag_update_D_equals_the_literal_one.
+FAST_SYNTAX = False
+
+
 def syn_FX(X, F, hp):
     """sum(convolution(X, F, pad=(h-1, twoM-1), groups=K), dims=3)  (:229, :263, :294, :316, :370)."""
+    if FAST_SYNTAX:
+        return Fn.conv_transpose2d(X, F)
     return conv2(X, F, pad=(hp.h - 1, hp.twoM - 1), groups=hp.K).sum(dim=1, keepdim=True)
 
 
@@ -301,9 +310,27 @@ def conv_code_diff(code, diff, hp, ln):                                        #
     return out.reshape(hp.batch_size, hp.M, ln.CS_vlen)
 
 
+# The six conv_code_diff calls of update_D compute C + L - 1 lags each and mapdrange keeps f_len of them (3 % at
+# configs[1]); torch's grouped conv1d with groups = M*B makes them ~95 % of the oracle's time.  NEEDED_LAGS = True forms
+# only the kept lags (D_grad[m, j] = sum_b sum_p code[b, m, 4p] * sig[b, 4p + j], reversed in j for the reverse strand) -
+# the identity tests/test_oracle_model.py::test_adjointness_and_needed_lags proves against the literal form.  It exists so
+# that a golden mini-batch at BASELINE configs[3] shape can be generated in minutes; everything else stays literal.
+NEEDED_LAGS = False
+
+
+def _needed_lag_corr(code, sig, hp, ln, reverse):
+    win = sig[:, 0, :].unfold(1, hp.f_len, 4)                                  # (B, c, f_len): sig[b, 4p + j]
+    out = torch.einsum("bmp,bpj->mj", code[..., 0::4], win)
+    return out.flip(-1) if reverse else out
+
+
 def update_D(S, Z, Y, D, mu, hp, ln, projs, num_pass):                         # :275-290
     sumZD = syn_ZD(Z, D, hp).sum(dim=1, keepdim=True)
     sumYRD = syn_ZD(Y, D, hp, flipped=True).sum(dim=1, keepdim=True)
+    if NEEDED_LAGS:
+        D_grad = sum(_needed_lag_corr(Z, sg, hp, ln, False) + _needed_lag_corr(Y, sg, hp, ln, True) for sg in (sumZD, sumYRD, S))
+        Breg_num = (D * torch.exp(-mu[num_pass] * D_grad.reshape(hp.M, 1, hp.f_len))).reshape(hp.M, 1, hp.filter_len, 4)
+        return (Breg_num / Breg_num.sum(dim=-1, keepdim=True)).reshape(hp.M, 1, hp.f_len)
     ZtsumZD = conv_code_diff(Z, sumZD, hp, ln)
     YtsumZD = conv_code_diff(Y, sumZD, hp, ln)
     ZtsumYRD = conv_code_diff(Z, sumYRD, hp, ln)
@@ -317,6 +344,9 @@ def update_D(S, Z, Y, D, mu, hp, ln, projs, num_pass):                         #
 
 
 def F_gradient(ZY, X, F, hp, ln, theta):                                       # :292-302
+    if FAST_SYNTAX:
+        R = (syn_FX(X, F, hp) - (ZY + theta))[:, 0]                             # (B, twoM, c)
+        return torch.einsum("bjip,bkp->kji", R.unfold(2, ln.l, 1), X[:, :, 0, :]).reshape(hp.K, 1, hp.twoM, hp.h)
     diff_X_upsampled = (syn_FX(X, F, hp) - (ZY + theta)).repeat_interleave(hp.K, dim=1)
     diff_r = diff_X_upsampled.reshape(1, hp.K * hp.batch_size, hp.twoM, ln.c)
     X_r = X.reshape(hp.K * hp.batch_size, 1, 1, ln.l)

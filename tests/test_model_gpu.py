@@ -170,6 +170,35 @@ def test_cfg2_golden(ctx, pkg):
     cdl.model.close()
 
 
+def test_cfg3_golden(ctx, pkg):
+    """One mini-batch at BASELINE configs[3] shape (500 bp, 512 filters of length 20) against the float64 oracle
+    (tests/golden/make_model_cfg3_golden.py; the oracle's needed-lag / direct syntax forms, proven equal to the literal
+    ones on small shapes): loss and every gradient.  The gradient of F (294 912 entries) is stored as every 7th entry +
+    sums."""
+    g = np.load(os.path.join(HERE, "golden", "model_cfg3.npz"))
+    hp = mo.Hyperparam(filter_len=20, M=512)
+    cdl_o = mo.UCDL(hp, np.random.default_rng(0)).to(torch.float64)
+    for n in mo.PARAM_VECS + ["D", "F"]:
+        setattr(cdl_o, n, torch.tensor(g["init_" + n].astype(np.float64)))
+    cdl_o.lambda_sparsity_warmup, cdl_o.lambda_stepsize_warmup, cdl_o.omega_stepsize_warmup = [float(x) for x in g["warm"]]
+    cdl = to_model(pkg, ctx, hp, 500, cdl_o, arena=16 << 30)
+    try:
+        loss, flat = gpu_loss_grad(pkg, ctx, cdl, g["codes"], 1)
+        got = split_grad(cdl, flat)
+        assert abs(loss[0] - g["loss0"]) <= RTOL * g["loss0"], (loss[0], g["loss0"])
+        for n in NAMES:
+            if n == "F":
+                continue
+            assert rel_inf(got[n], g[f"grad0_{n}"].astype(np.float64)) <= 5 * RTOL, (n, rel_inf(got[n], g[f"grad0_{n}"]))
+        gf = got["F"].astype(np.float64)
+        stride = int(g["grad0_F_sample_stride"])
+        assert np.abs(gf[::stride] - g["grad0_F_sample"].astype(np.float64)).max() <= 5 * RTOL * g["grad0_F_absmax"]
+        assert abs(np.abs(gf).max() - g["grad0_F_absmax"]) <= 5 * RTOL * g["grad0_F_absmax"]
+        assert abs((gf * gf).sum() - g["grad0_F_sumsq"]) <= 1e-3 * g["grad0_F_sumsq"]
+    finally:
+        cdl.model.close()
+
+
 def test_cfg2_groups_are_independent(ctx, pkg):
     """Two mini-batches at configs[1] shape in one launch == one at a time: the per-group filter banks of the ADMM_DF
     passes and the group indexing of the LDS-resident GEMM kernels at their real sizes."""
@@ -282,8 +311,8 @@ def test_train_ucdl_runs_and_code_retrieval_format(ctx, pkg):
 
 
 def test_cfg4_shape_runs(ctx, pkg):
-    """BASELINE configs[3] shape (500 bp, 512 filters of length 20): the oracle needs hours on the CPU here, so
-    check what does not need it: finite losses, gradient of two mini-batches == sum of the two single ones."""
+    """BASELINE configs[3] shape (500 bp, 512 filters of length 20) with the reference's own init scale (test_cfg3_golden
+    holds one mini-batch to the oracle): finite losses, gradient of two mini-batches == sum of the two single ones."""
     md = pkg.model
     hp = md.Hyperparam(filter_len=20, M=512)
     L = 500

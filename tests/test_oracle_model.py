@@ -220,3 +220,19 @@ def test_adabelief_three_steps_by_hand():
         b1p *= 0.9
         b2p *= 0.999
     assert np.allclose(xs.numpy(), xh, rtol=1e-12)
+
+
+def test_needed_lag_update_D_equals_the_literal_one():
+    """mo.NEEDED_LAGS and mo.FAST_SYNTAX (used only to generate the configs[3]-shape golden mini-batch, which the literal
+    torch forms cannot do) change nothing: the loss and every gradient agree with the literal forms."""
+    hp, codes, cdl, ln, projs = tiny(3)
+    try:
+        mo.NEEDED_LAGS = mo.FAST_SYNTAX = False
+        v0, g0 = mo.loss_and_grads(codes, cdl, hp, DT)
+        mo.NEEDED_LAGS = mo.FAST_SYNTAX = True
+        v1, g1 = mo.loss_and_grads(codes, cdl, hp, DT)
+    finally:
+        mo.NEEDED_LAGS = mo.FAST_SYNTAX = False
+    assert abs(v0.item() - v1.item()) <= 1e-12 * abs(v0.item())
+    for a, b in zip(g0, g1):
+        assert torch.allclose(a, b, rtol=1e-9, atol=1e-12 * float(a.abs().max() + 1))
