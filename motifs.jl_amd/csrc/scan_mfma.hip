@@ -4,14 +4,14 @@
 // [PWMs x 4*len] x [4*len x windows].  v_mfma_f32_32x32x16_f16 forms it exactly in f32 (products of
 // binary16 weights with 0/1 are exact), which is NOT the reference's arithmetic — greedy_search!
 // (src/inference/_h3_1_alignment.jl:26-31) adds in binary16, rounding after every add.  So the matrix
-// cores only FILTER: with S the exact sum and s the sequentially rounded one,
-//     |s - S| <= eps_k := 1.02 * 2^-11 * sum_{i=2..len_k} P_i,   P_i = sum_{j<=i} max_a |pwm[k, a, j]|
-// (the i-th add rounds by at most half an ulp of a running sum bounded by P_i; the first add is exact; 1.02
-// covers the compounding, and small absolute terms cover binary16 subnormals and the f32 GEMM's own rounding;
-// pack_mfma in scan_api.hip),
-// hence s > 0 implies S > -eps_k.  Every (PWM, window)
-// with S > -eps_k becomes a candidate bit; candidates (about 1 % of the pairs) are then re-scored in the
-// reference's arithmetic and only true hits survive (fill_verify_row_sums), so records and scores stay
+// cores only FILTER: with S the exact sum and s the sequentially rounded one, a window with s > 0 has S > -eps_k, where
+// eps_k = c * sum_{i=2..len_k} B_i / (1 - c * len_k), c = (1 + 2^-11)^len_k * 2^-11, and B_i bounds the i-th exact prefix
+// sum of a window whose total lies in [-eps_k, 0]: it is pinned by what the first i positions can reach AND by what the
+// remaining ones can still undo (pack_mfma in scan_api.hip derives it; for log-odds banks it is ~5x below the plain
+// sum_{j<=i} max_a |pwm[k, a, j]|); small absolute terms cover binary16 subnormals and the f32 GEMM's own rounding,
+// and eps = inf (keep everything) where a partial sum could overflow binary16.  Every (PWM, window)
+// with S > -eps_k becomes a candidate bit; candidates (under 1 % of the pairs) are then re-scored in the
+// reference's arithmetic and only true hits survive (stage_hits), so records and scores stay
 // bit-identical to the reference while 99 % of the pairs never touch the slow fp16 chain.
 //
 // Cells: uint4 per (batch, l, n-in-batch, chunk of 128 PWMs), bit i = PWM 128*chunk + i.  This order is
