@@ -2016,12 +2016,15 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ A, cons
 // for the whole sequence).  Row strides of both LDS tiles are 16 mod 32 floats: conflict-free operand reads.
 template <int QW, int NW>
 __global__ __launch_bounds__(NW * 64) void k_rowwgrad_lds(const float* __restrict__ A, const float* __restrict__ C, float* __restrict__ part,
-                                                      int R, int Q, int N, int ST, int SN) {
+                                                      int R, int Q, int N, int ST, int SN, int TS) {
     constexpr int NT = 3, TH = NW * 64, NVA = (32 * 120 + TH - 1) / TH, NVC = (32 * 16 + TH - 1) / TH;   // 16-byte loads per thread: 32 x Q (Q <= 480) of A, 32 x N (N <= 64) of C
     extern __shared__ float lds[];                 // A tile [32][ST], C tile [32][SN]
     float* Cs = lds + 32 * ST;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int s = blockIdx.x, Q4 = Q >> 2, N4 = N >> 2, QB = Q >> 4;
+    // TS blocks share a sequence (block ts walks the row tiles ts, ts + TS, ..): with the reference's 6 reads per step one
+    // block per read leaves the chip idle behind a serial walk of R / 32 tiles; the TS partial banks are summed with the
+    // per-read ones
+    const int s = blockIdx.x / TS, ts = blockIdx.x - s * TS, Q4 = Q >> 2, N4 = N >> 2, QB = Q >> 4;
     const float4* Ag = (const float4*)(A + (size_t)s * R * Q);
     const float4* Cg = (const float4*)(C + (size_t)s * R * N);
     float4 va[NVA], vc[NVC];
@@ -2067,12 +2070,12 @@ __global__ __launch_bounds__(NW * 64) void k_rowwgrad_lds(const float* __restric
     for (int i = tid; i < 32 * SN; i += TH) Cs[i] = 0.0f;
     const float* ap = lds + (lane >> 4) * ST + (lane & 15) + wave * 16;     // A'[q][r] = tile[r][q]
     const float* cp = Cs + (lane >> 4) * SN + (lane & 15);
-    gload(0);
-    for (int r0 = 0; r0 < R; r0 += 32) {
+    if (ts * 32 < R) gload(ts * 32);
+    for (int r0 = ts * 32; r0 < R; r0 += 32 * TS) {
         __syncthreads();                           // the previous tile has been read
         lstore();
         __syncthreads();
-        if (r0 + 32 < R) gload(r0 + 32);
+        if (r0 + 32 * TS < R) gload(r0 + 32 * TS);
 #pragma unroll
         for (int ks = 0; ks < 8; ks++) {
             float bv[NT];
@@ -2088,7 +2091,7 @@ __global__ __launch_bounds__(NW * 64) void k_rowwgrad_lds(const float* __restric
             }
         }
     }
-    float* out = part + (size_t)s * Q * N;
+    float* out = part + ((size_t)s * TS + ts) * Q * N;
 #pragma unroll
     for (int i = 0; i < QW; i++) {
         if (wave + NW * i < QB) {
@@ -2103,7 +2106,10 @@ __global__ __launch_bounds__(NW * 64) void k_rowwgrad_lds(const float* __restric
         }
     }
 }
-// per-sequence partial banks part[S][Q][N] of the row GEMM's filter gradient; false when the shape is not covered
+// blocks per sequence of k_rowwgrad_lds: 1 when the sequences alone fill the chip
+static int rowwgrad_split(const ToepGeom& rg) { return rg.S >= 48 ? 1 : std::max(1, std::min(8, (rg.P + 31) / 32)); }
+// per-sequence partial banks part[S * TS][Q][N] (TS = rowwgrad_split) of the row GEMM's filter gradient; false when the
+// shape is not covered
 static bool launch_rowwgrad_lds(Engine& e, const float* A, const float* C, float* part, const ToepGeom& rg) {
     if (rg.a0 != 0 || rg.sa != rg.Q || rg.lda != (int64_t)rg.P * rg.Q || rg.ldc != (int64_t)rg.P * rg.N) return false;
     if ((rg.Q & 15) || rg.Q > 480 || rg.Q < 64 || rg.N < 33 || rg.N > 48 || (rg.N & 3)) return false;
@@ -2116,7 +2122,8 @@ static bool launch_rowwgrad_lds(Engine& e, const float* A, const float* C, float
     // 8 waves per block (each owns every 8th block of 16 rows of q): a read is walked twice as fast as by 4, and reads are
     // few (54 -> 48 us; 16 waves: 53 us)
     const int QW = (QB + 7) / 8;
-#define ROWWGRAD(QWV) hipLaunchKernelGGL((k_rowwgrad_lds<QWV, 8>), dim3(rg.S), dim3(512), lds, e.st, A, C, part, rg.P, rg.Q, rg.N, ST, SN)
+    const int TS = rowwgrad_split(rg);
+#define ROWWGRAD(QWV) hipLaunchKernelGGL((k_rowwgrad_lds<QWV, 8>), dim3(rg.S * TS), dim3(512), lds, e.st, A, C, part, rg.P, rg.Q, rg.N, ST, SN, TS)
     if (QW <= 2) ROWWGRAD(2);
     else if (QW == 3) ROWWGRAD(3);
     else ROWWGRAD(4);
@@ -2183,7 +2190,8 @@ static void launch_wgrad(Engine& e, const float* A, const float* C, float* dB, c
         const ToepGeom rg = tall_row_geom(gm);
         const int rtiles = ((rg.Q + 127) / 128) * ((rg.N + 31) / 32);
         if (rg.B > 1 && rtiles * G < 2048) {      // per-sequence partial banks, then their sums (see below)
-            float* part = e.arena.alloc(per * gm.S);
+            const int TS = rowwgrad_split(rg);
+            float* part = e.arena.alloc(per * gm.S * TS);
             if (!part) {
                 e.failed = true;
                 return;
@@ -2191,9 +2199,12 @@ static void launch_wgrad(Engine& e, const float* A, const float* C, float* dB, c
             ToepGeom r1 = rg;
             r1.B = 1;
             static const bool legacy_rows = getenv("MOTIFS_TOEP_LEGACY") != nullptr;
-            if (legacy_rows || !launch_rowwgrad_lds(e, A, dW, part, rg))
+            int nparts = rg.B * TS;                // partial banks per group
+            if (legacy_rows || !launch_rowwgrad_lds(e, A, dW, part, rg)) {
                 hipLaunchKernelGGL(k_wgrad_mfma, dim3((rg.Q + 127) / 128, gm.S, (rg.N + 31) / 32), dim3(256), 0, st, A, dW, part, r1, 0);
-            hipLaunchKernelGGL(k_sum_segments, dim3(nblocks(per * G)), dim3(256), 0, st, part, per, rg.B, per * G, dBt, 0);
+                nparts = rg.B;
+            }
+            hipLaunchKernelGGL(k_sum_segments, dim3(nblocks(per * G)), dim3(256), 0, st, part, per, nparts, per * G, dBt, 0);
         } else {
             hipLaunchKernelGGL(k_wgrad_mfma, dim3((rg.Q + 127) / 128, G, (rg.N + 31) / 32), dim3(256), 0, st, A, dW, dBt, rg, 0);
         }
@@ -2208,14 +2219,14 @@ static void launch_wgrad(Engine& e, const float* A, const float* C, float* dB, c
         rg.S = gm.S, rg.P = gm.P, rg.Q = gm.N, rg.N = gm.Q, rg.sa = gm.N, rg.a0 = 0, rg.amax = gm.P * gm.N;
         rg.lda = (int64_t)gm.P * gm.N, rg.ldc = (int64_t)gm.P * gm.Q, rg.B = gm.B, rg.ldb = 0;
         float* Wn = e.arena.alloc((size_t)gm.S * gm.P * gm.Q);
-        float* part = e.arena.alloc(per * gm.S);
+        float* part = e.arena.alloc(per * gm.S * rowwgrad_split(rg));
         if (!Wn || !part) {
             e.failed = true;
             return;
         }
         hipLaunchKernelGGL(k_windows, dim3(nblocks((size_t)gm.S * gm.P * gm.Q)), dim3(256), 0, st, A, gm, Wn);
         if (launch_rowwgrad_lds(e, C, Wn, part, rg)) {
-            hipLaunchKernelGGL(k_sum_segments_T, dim3((gm.N + 31) / 32, G), dim3(256), 0, st, part, gm.Q, gm.N, gm.B, dB, acc);
+            hipLaunchKernelGGL(k_sum_segments_T, dim3((gm.N + 31) / 32, G), dim3(256), 0, st, part, gm.Q, gm.N, gm.B * rowwgrad_split(rg), dB, acc);
             return;
         }
     }
@@ -2779,27 +2790,30 @@ static void launch_sp_ana_masked(hipStream_t st, const float* img, const float* 
 // reach row r are the (position-sorted) run with p in (r - h, r], found once per row by bisection.  The image is
 // written (or accumulated) once with 16-byte accesses, the contributions of a row meet in registers in entry order -
 // the same sums as the ring of k_sp_syn, without its serial walk over the entries.
+// RB rows per block: 32 when there are reads enough to fill the chip, 8 for the reference's 6-read steps (each thread then
+// walks a quarter of the dependent filter loads)
+template <int RB>
 __global__ __launch_bounds__(256) void k_sp_syn_rows(NzView nz, const float* __restrict__ FAf, float* __restrict__ out, SpDims d, int acc) {
     constexpr int EC = 256;                        // decoded entries kept in LDS (more: decoded on the fly)
-    __shared__ int lo[32], hi[32];
+    __shared__ int lo[RB], hi[RB];
     __shared__ int ep[EC], ek[EC];
     __shared__ float ev[EC];
-    const int s = blockIdx.y, r0 = blockIdx.x * 32, tid = threadIdx.x;
+    const int s = blockIdx.y, r0 = blockIdx.x * RB, tid = threadIdx.x;
     const int cnt = nz.cnt[s];
     const uint2* es = nz.ent + (size_t)s * nz.cap;
-    if (tid < 64) {                                // first entry with p >= r - h + 1 (lo) / p >= r + 1 (hi)
-        const int r = r0 + (tid & 31);
-        const long key = ((long)(tid < 32 ? r - d.h + 1 : r + 1)) * d.K;
+    if (tid < 2 * RB) {                            // first entry with p >= r - h + 1 (lo) / p >= r + 1 (hi)
+        const int r = r0 + (tid % RB);
+        const long key = ((long)(tid < RB ? r - d.h + 1 : r + 1)) * d.K;
         int a = 0, b = cnt;
         while (a < b) {
             const int m = (a + b) >> 1;
             if ((long)es[m].x < key) a = m + 1;
             else b = m;
         }
-        (tid < 32 ? lo : hi)[tid & 31] = a;
+        (tid < RB ? lo : hi)[tid % RB] = a;
     }
     __syncthreads();
-    const int nrow = min(32, d.c - r0);
+    const int nrow = min(RB, d.c - r0);
     const int zb = lo[0], ne = hi[nrow - 1] - zb;
     const bool cached = ne <= EC;
     if (cached) {
@@ -2843,7 +2857,8 @@ __global__ __launch_bounds__(256) void k_sp_syn_rows(NzView nz, const float* __r
 static void launch_sp_syn(hipStream_t st, const NzView& nz, const float* FAf, float* out, const SpDims& d, int acc) {
     static const bool legacy = getenv("MOTIFS_TOEP_LEGACY") != nullptr;
     if (!legacy && (d.W & 3) == 0 && d.W <= 1024 && (d.ldf & 3) == 0 && ((((uintptr_t)FAf) | ((uintptr_t)out)) & 15) == 0) {
-        hipLaunchKernelGGL(k_sp_syn_rows, dim3((d.c + 31) / 32, d.S), dim3(256), 0, st, nz, FAf, out, d, acc);
+        if (d.S >= 48) hipLaunchKernelGGL(k_sp_syn_rows<32>, dim3((d.c + 31) / 32, d.S), dim3(256), 0, st, nz, FAf, out, d, acc);
+        else hipLaunchKernelGGL(k_sp_syn_rows<8>, dim3((d.c + 7) / 8, d.S), dim3(256), 0, st, nz, FAf, out, d, acc);
         return;
     }
     if (d.h == 12) hipLaunchKernelGGL(k_sp_syn<12>, dim3((d.W + 127) / 128, d.S), dim3(128), 0, st, nz, FAf, out, d, acc);
