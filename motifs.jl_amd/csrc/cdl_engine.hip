@@ -2134,8 +2134,14 @@ static bool launch_rowwgrad_lds(Engine& e, const float* A, const float* C, float
 __global__ void k_sum_segments(const float* x, size_t per, int B, size_t total, float* y, int acc) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const size_t g = i / per, j = i - g * per;
-        float a = 0.0f;
-        for (int b = 0; b < B; b++) a += x[(g * B + b) * per + j];
+        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;          // four chains: the loads of a long sum overlap
+        int b = 0;
+        for (; b + 4 <= B; b += 4) {
+            a0 += x[(g * B + b) * per + j], a1 += x[(g * B + b + 1) * per + j];
+            a2 += x[(g * B + b + 2) * per + j], a3 += x[(g * B + b + 3) * per + j];
+        }
+        for (; b < B; b++) a0 += x[(g * B + b) * per + j];
+        const float a = (a0 + a1) + (a2 + a3);
         y[i] = acc ? y[i] + a : a;
     }
 }
@@ -2159,9 +2165,15 @@ __global__ __launch_bounds__(256) void k_sum_segments_T(const float* __restrict_
     const int nn_max = min(32, N - n0), cnt = nn_max * Q;
     const size_t per = (size_t)Q * N;
     for (int idx = tid; idx < cnt; idx += 256) {
-        float a = 0.0f;
-        for (int b = 0; b < B; b++) a += part[((size_t)g * B + b) * per + (size_t)n0 * Q + idx];
-        t[idx % Q][idx / Q] = a;
+        const float* src = part + (size_t)g * B * per + (size_t)n0 * Q + idx;
+        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;          // four chains: the loads of a long sum overlap
+        int b = 0;
+        for (; b + 4 <= B; b += 4) {
+            a0 += src[(size_t)b * per], a1 += src[(size_t)(b + 1) * per];
+            a2 += src[(size_t)(b + 2) * per], a3 += src[(size_t)(b + 3) * per];
+        }
+        for (; b < B; b++) a0 += src[(size_t)b * per];
+        t[idx % Q][idx / Q] = (a0 + a1) + (a2 + a3);
     }
     __syncthreads();
     for (int idx = tid; idx < Q * 32; idx += 256) {

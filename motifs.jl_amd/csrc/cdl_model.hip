@@ -36,6 +36,22 @@ struct motifs_model {
     int o_ls, o_ks, o_lst, o_ost, o_kst, o_pen, o_mu;
     Tensor last_X = nullptr;
     int last_groups = 0;
+    // The forward/backward graph of a step is a fixed sequence of ~500 short launches on fixed arena addresses: from the
+    // second call with the same (mini-batch count, buffers) on it is captured once into a hipGraph and replayed, which
+    // takes the host out of the reference's one-step-per-6-reads schedule (train.jl:40-46; 527 nodes at configs[1], worth
+    // 1.5 % while the small-grid kernels themselves bound the step).  Larger steps hide their launches and stay eager.
+    // MOTIFS_NO_GRAPH=1: always eager.
+    struct StepGraph {
+        int n_groups = 0;
+        const void* codes = nullptr;
+        void* loss = nullptr;
+        void* grad = nullptr;
+        hipGraphExec_t exec = nullptr;
+    };
+    std::vector<StepGraph> step_graphs;
+    hipStream_t cap_stream = nullptr;
+    bool use_graphs = true;
+    int graph_max_groups = 8;
 };
 
 namespace {
@@ -331,6 +347,35 @@ __global__ void k_write_codes(const float* X, int l, int K, const int64_t* off, 
         }
 }
 
+// every launch of one loss + gradient evaluation, on stream st (the context's stream, or a capturing one)
+static int enqueue_loss_grad(motifs_model* m, hipStream_t st, const uint8_t* codes_dev, int n_groups, float* loss_dev, float* grad_flat_dev,
+                             int keep_intermediates) {
+    Engine& e = m->eng;
+    e.st = st;
+    e.reset();
+    e.recording = grad_flat_dev != nullptr;
+    e.keep_named = keep_intermediates != 0;
+    MOTIFS_HIP_CHECK(hipMemsetAsync(m->grads, 0, m->nP * 4, e.st));
+    Graph gr(m, n_groups);
+    gr.Sone = make_onehot(m, codes_dev, gr.S);
+    Tensor Lv = forward_loss(m, gr, e.recording);
+    if (!e.failed && e.recording) {
+        float* g = e.grad(Lv);
+        if (g) hipLaunchKernelGGL(k_fill, dim3(1), dim3(256), 0, e.st, g, (size_t)n_groups, 1.0f);
+        e.backward();
+    }
+    if (e.failed) {
+        set_error("engine arena exhausted (%zu bytes): lower n_groups or create the model with a larger arena",
+                  m->arena_bytes);
+        return MOTIFS_ERR_UNSUPPORTED;
+    }
+    if (loss_dev) MOTIFS_HIP_CHECK(hipMemcpyAsync(loss_dev, Lv->v, (size_t)n_groups * 4, hipMemcpyDeviceToDevice, e.st));
+    if (grad_flat_dev) MOTIFS_HIP_CHECK(hipMemcpyAsync(grad_flat_dev, m->grads, m->nP * 4, hipMemcpyDeviceToDevice, e.st));
+    e.st = m->ctx->stream;
+    MOTIFS_HIP_CHECK(hipGetLastError());
+    return MOTIFS_OK;
+}
+
 extern "C" {
 
 int motifs_model_create(motifs_ctx* ctx, const motifs_hparams* hp, int L, size_t arena_bytes, motifs_model** out) {
@@ -386,6 +431,7 @@ int motifs_model_create(motifs_ctx* ctx, const motifs_hparams* hp, int L, size_t
     m->eng.arena.base = (char*)base;
     m->eng.arena.cap = m->arena_bytes;
     m->eng.st = ctx->stream;
+    m->use_graphs = getenv("MOTIFS_NO_GRAPH") == nullptr;
     *out = m;
     return MOTIFS_OK;
 }
@@ -395,6 +441,9 @@ void motifs_model_destroy(motifs_model* m) {
     (void)hipSetDevice(m->ctx->device);
     (void)hipStreamSynchronize(m->ctx->stream);
     m->eng.reset();
+    for (auto& g : m->step_graphs)
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);
     for (void* p : {(void*)m->params, (void*)m->grads, (void*)m->ada_m, (void*)m->ada_s, (void*)m->eng.arena.base})
         if (p) (void)hipFree(p);
     delete m;
@@ -487,29 +536,48 @@ int motifs_model_loss_grad_dev(motifs_model* m, const uint8_t* codes_dev, int n_
         return MOTIFS_ERR_INVALID;
     }
     MOTIFS_HIP_CHECK(hipSetDevice(m->ctx->device));
-    Engine& e = m->eng;
-    e.st = m->ctx->stream;
-    e.reset();
-    e.recording = grad_flat_dev != nullptr;
-    e.keep_named = keep_intermediates != 0;
-    MOTIFS_HIP_CHECK(hipMemsetAsync(m->grads, 0, m->nP * 4, e.st));
     KernelTimer tm(m->ctx, KS_TRAIN_STEP);
-    Graph gr(m, n_groups);
-    gr.Sone = make_onehot(m, codes_dev, gr.S);
-    Tensor Lv = forward_loss(m, gr, e.recording);
-    if (!e.failed && e.recording) {
-        float* g = e.grad(Lv);
-        if (g) hipLaunchKernelGGL(k_fill, dim3(1), dim3(256), 0, e.st, g, (size_t)n_groups, 1.0f);
-        e.backward();
+    if (!m->use_graphs || keep_intermediates || n_groups > m->graph_max_groups)
+        return enqueue_loss_grad(m, m->ctx->stream, codes_dev, n_groups, loss_dev, grad_flat_dev, keep_intermediates);
+    motifs_model::StepGraph* sg = nullptr;
+    for (auto& g : m->step_graphs)
+        if (g.n_groups == n_groups && g.codes == codes_dev && g.loss == loss_dev && g.grad == grad_flat_dev) sg = &g;
+    if (!sg) {       // first sight of this step: eager (lazy kernel loading and first-use set-up happen outside any capture)
+        if (m->step_graphs.size() >= 8) {
+            if (m->step_graphs.front().exec) (void)hipGraphExecDestroy(m->step_graphs.front().exec);
+            m->step_graphs.erase(m->step_graphs.begin());
+        }
+        motifs_model::StepGraph g;
+        g.n_groups = n_groups;
+        g.codes = codes_dev;
+        g.loss = loss_dev;
+        g.grad = grad_flat_dev;
+        m->step_graphs.push_back(g);
+        return enqueue_loss_grad(m, m->ctx->stream, codes_dev, n_groups, loss_dev, grad_flat_dev, 0);
     }
-    if (e.failed) {
-        set_error("engine arena exhausted (%zu bytes): lower n_groups or create the model with a larger arena",
-                  m->arena_bytes);
-        return MOTIFS_ERR_UNSUPPORTED;
+    if (!sg->exec) {   // second call: record the launches instead of running them
+        if (!m->cap_stream) MOTIFS_HIP_CHECK(hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking));
+        MOTIFS_HIP_CHECK(hipStreamBeginCapture(m->cap_stream, hipStreamCaptureModeRelaxed));
+        const int rc = enqueue_loss_grad(m, m->cap_stream, codes_dev, n_groups, loss_dev, grad_flat_dev, 0);
+        hipGraph_t graph = nullptr;
+        const hipError_t ce = hipStreamEndCapture(m->cap_stream, &graph);
+        if (rc != MOTIFS_OK || ce != hipSuccess || !graph) {
+            if (graph) (void)hipGraphDestroy(graph);
+            (void)hipGetLastError();
+            m->use_graphs = false;     // something in the step cannot be captured on this runtime: stay eager from here on
+            if (rc != MOTIFS_OK) return rc;
+            return enqueue_loss_grad(m, m->ctx->stream, codes_dev, n_groups, loss_dev, grad_flat_dev, 0);
+        }
+        const hipError_t ie = hipGraphInstantiate(&sg->exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (ie != hipSuccess) {
+            sg->exec = nullptr;
+            (void)hipGetLastError();
+            m->use_graphs = false;
+            return enqueue_loss_grad(m, m->ctx->stream, codes_dev, n_groups, loss_dev, grad_flat_dev, 0);
+        }
     }
-    if (loss_dev) MOTIFS_HIP_CHECK(hipMemcpyAsync(loss_dev, Lv->v, (size_t)n_groups * 4, hipMemcpyDeviceToDevice, e.st));
-    if (grad_flat_dev) MOTIFS_HIP_CHECK(hipMemcpyAsync(grad_flat_dev, m->grads, m->nP * 4, hipMemcpyDeviceToDevice, e.st));
-    MOTIFS_HIP_CHECK(hipGetLastError());
+    MOTIFS_HIP_CHECK(hipGraphLaunch(sg->exec, m->ctx->stream));
     return MOTIFS_OK;
 }
 

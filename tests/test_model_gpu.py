@@ -327,3 +327,50 @@ def test_cfg4_shape_runs(ctx, pkg):
         acc += f1
     assert rel_inf(flat, acc) <= 1e-4
     cdl.model.close()
+
+
+def test_step_graph_replay_equals_eager(ctx, pkg):
+    """Small steps (<= 8 mini-batches) are captured into a hipGraph on their second call with the same buffers and replayed
+    from the third: same losses and gradient as the eager first call (float atomics leave ulp-level noise), and the
+    replay follows new parameters and new reads, which it reads from memory."""
+    md, sy, lib = pkg.model, pkg.synth, pkg._lib
+    hp = md.Hyperparam(filter_len=8, M=16, K=8, q=8, h=6)
+    L, G = 60, 3
+    cdl = md.ucdl(hp, L, ctx=ctx, seed=77, arena_bytes=1 << 30)
+    try:
+        S = G * hp.batch_size
+        dcodes = torch.zeros(lib.Context.codes_bytes(S, L), dtype=torch.uint8, device="cuda")
+        loss = torch.zeros(G, dtype=torch.float32, device="cuda")
+        grad = torch.zeros(cdl.model.nP, dtype=torch.float32, device="cuda")
+
+        def run(codes):
+            raw = torch.from_numpy(codes).cuda()
+            torch.cuda.synchronize()
+            ctx.encode_dev(raw.data_ptr(), lib.DATA_CODES_U8, S, L, dcodes.data_ptr())
+            cdl.model.loss_grad_dev(dcodes.data_ptr(), G, loss.data_ptr(), grad.data_ptr())
+            ctx.synchronize()
+            return loss.cpu().numpy().copy(), grad.cpu().numpy().copy()
+
+        c1, c2 = sy.gen_codes(S, L, 1, n_plant=2, k=8), sy.gen_codes(S, L, 2, n_plant=2, k=8)
+        l_eager, g_eager = run(c1)          # 1: eager
+        l_cap, g_cap = run(c1)              # 2: captured, then launched
+        l_rep, g_rep = run(c1)              # 3: replayed
+        scale = np.abs(g_eager).max()
+        for l, g in ((l_cap, g_cap), (l_rep, g_rep)):
+            assert np.allclose(l, l_eager, rtol=2e-6)
+            assert np.allclose(g, g_eager, rtol=0, atol=2e-6 * scale)
+        l2_rep, _ = run(c2)                 # other reads through the same buffers
+        assert not np.allclose(l2_rep, l_eager, rtol=1e-4)
+        D, F, w, v = cdl.model.get_params()
+        cdl.model.set_params(D * 1.01, F, None, None)
+        l3_rep, _ = run(c2)                 # other parameters
+        assert not np.allclose(l3_rep, l2_rep, rtol=1e-6)
+        fresh = md.ucdl(hp, L, ctx=ctx, seed=77, arena_bytes=1 << 30)
+        try:
+            fresh.model.set_params(D * 1.01, F, w, v)
+            lo2, _ = gpu_loss_grad(pkg, ctx, fresh, c2, G)      # eager (first sight of its buffers)
+            assert np.allclose(lo2, l3_rep, rtol=2e-6)
+        finally:
+            fresh.model.close()
+    finally:
+        cdl.model.close()
