@@ -421,6 +421,9 @@ def main():
         }
         cdl.model.close()
 
+    if isinstance(reducer, par.RcclReducer):       # the library's own communicator goes before torch's
+        ctx.synchronize()
+        reducer.comm.close()
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
