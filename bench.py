@@ -227,7 +227,7 @@ def main():
     extras = {}
     Lout = L - PL + 1
     hits, hsc, need, cap, dcodes = weak["hits"], weak["hsc"], weak["need"], weak["cap"], weak["codes"]
-    if not args.no_extras:
+    if not args.no_extras and rank == 0:           # untimed side legs, all local to one device: rank 0 only
         # ---- the a17 kernel on its own: dense (K, nb, L-len+1) fp16 scores (untimed extra leg) ----
         nb = min(N, 20_000)                        # 20k x 189 x 200 x 2 B = 1.5 GB per launch
         dense = torch.empty((Lout, nb, K), dtype=torch.int16, device=dev)

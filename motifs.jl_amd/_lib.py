@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmotifs_hip.so")
+LIB_PATH = os.environ.get("MOTIFS_HIP_LIB") or os.path.join(HERE, "libmotifs_hip.so")   # MOTIFS_HIP_LIB: another build (A/B timing)
 
 OK, ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_BUFFER_TOO_SMALL, ERR_NOT_ONEHOT, ERR_NONFINITE, ERR_UNSUPPORTED, ERR_COMM = range(9)
 ABI_VERSION = 2
