@@ -166,7 +166,11 @@ int motifs_pwm_scan_hits_both_dev(motifs_ctx* ctx, const uint16_t* pwms_fp16, co
                                   motifs_hit* hits_fwd_dev, uint16_t* scores_fwd_dev, motifs_hit* hits_rc_dev,
                                   uint16_t* scores_rc_dev, int64_t cap, int64_t* n_out2, int64_t* per_pwm_counts2_dev);
 
-/* Host-buffer form of the same call: what Julia's `ccall` binds.  `data` is a
+/* There is no `score_mode` argument (SURVEY.md 8b sketched fp32 / MFMA-tolerance modes): the only mode is the
+ * reference's own arithmetic, bit for bit - the matrix cores are used as an exact pre-filter behind it, so an approximate
+ * mode would not be faster.
+ *
+ * Host-buffer form of the same call: what Julia's `ccall` binds.  `data` is a
  * host matrix of `kind`; hits / hit_scores / per_pwm_counts are host buffers.
  * hits == NULL or cap too small: returns MOTIFS_ERR_BUFFER_TOO_SMALL (or
  * MOTIFS_OK when hits == NULL && cap == 0) with *n_out = required count. */
@@ -261,7 +265,7 @@ int motifs_comm_create(motifs_ctx* ctx, const uint8_t id[MOTIFS_COMM_ID_BYTES], 
  * single Julia process driving the 8 GPUs of a node uses; bracket the per-device collective calls of one step
  * with motifs_comm_group_start / _end (ncclGroupStart / ncclGroupEnd). */
 int motifs_comm_create_all(motifs_ctx* const* ctxs, int n_dev, motifs_comm** out);
-void motifs_comm_destroy(motifs_comm* comm);
+void motifs_comm_destroy(motifs_comm* comm);   /* before the context it was made on */
 int motifs_comm_rank(motifs_comm* comm, int* rank, int* nranks);
 int motifs_comm_group_start(void);
 int motifs_comm_group_end(void);
