@@ -141,9 +141,12 @@ def main():
             dist.barrier()
 
     ctx = lib.Context(local_rank)
-    # The context enqueues on HIP's null stream = torch's default current stream: torch allocations / fills and the
-    # library's kernels are then ordered by the stream itself (ABI 1 silently made a private stream here).
-    ctx.set_stream(0)
+    # One ordinary (non-default) stream for everything: torch's allocations / fills run on it as its current stream, the
+    # library's kernels and its RCCL collectives are enqueued on it through motifs_ctx_set_stream, so the stream itself
+    # orders them (ABI 1 silently made a private stream here, and the two sides raced).
+    work_stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(work_stream)
+    ctx.set_stream(work_stream.cuda_stream)
     reducer, reducer_note = par.make_reducer(ctx, prefer_rccl=not rehearse)
 
     # ---- synthetic inputs ------------------------------------------------------
