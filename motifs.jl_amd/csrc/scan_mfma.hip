@@ -200,7 +200,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((T * PG <= 
 // traffic between waves.  After an exclusive scan of the row counts, emit_records turns the staged words
 // into (m, n, l, score) records at their final offsets; a row with more hits than staging slots is re-scored
 // from its cells there (rare: more than two hits per cell on average).
-constexpr uint32_t NOROW = 0xffffffffu;
 constexpr int VF_THREADS = 512;
 constexpr int VF_WAVES = VF_THREADS / 64;
 constexpr int QN = 128;           // candidate ring slots per wave (power of two); fewer than 64 stay behind after a push
