@@ -102,7 +102,7 @@ struct MfmaBank {
     std::vector<uint32_t> afrag;   // [tiles][T][64][4]
     std::vector<float> cinit;      // [tiles][2][16]
     int ntiles = 0, T = 0;
-    int uniform_eps = 0;           // afrag scaled by a power of two so that the slack is the constant 4.0 for every PWM
+    int uniform_eps = 0;           // afrag scaled by powers of two so that the slack is an inline constant for every PWM
 };
 static uint16_t f2h_exact_scaled(uint16_t h, int e) {   // h * 2^e for a finite binary16 h; the caller guarantees exactness
     if ((h & 0x7fffu) == 0) return h;
@@ -119,7 +119,7 @@ static void pack_mfma(const PackedBank& bank, const int64_t* lens, int K, MfmaBa
     out.T = T;
     out.ntiles = ntiles;
     out.afrag.assign((size_t)ntiles * T * 64 * 4, 0u);
-    out.cinit.assign((size_t)ntiles * 32, -1.0f);
+    out.cinit.assign((size_t)ntiles * 32, 1.0f);   // rows without a PWM: never negative
     auto wbits = [&](int k, int a, int ind) -> uint16_t {
         const uint32_t cell = bank.tab[(size_t)(ind * 4 + a) * bank.KP + (k >> 1)];
         return (uint16_t)((k & 1) ? cell >> 16 : cell);
@@ -167,15 +167,22 @@ static void pack_mfma(const PackedBank& bank, const int64_t* lens, int K, MfmaBa
         if (A * 1.04 >= 60000.0) eps[k] = INFINITY;      // a partial sum may overflow binary16: keep every window
         eps_max = std::max(eps_max, eps[k]);
     }
-    // One slack for all: scale the bank by 2^e (exact in binary16) so that eps_max * 2^e <= 4.0, the MFMA's
-    // inline-constant C.  The test S * 2^e + 4 > 0 is S > -4 / 2^e with 4 / 2^e >= eps_k for every k.
+    // The kernel wants "candidate" as a SET sign bit (its packing then needs no complement), so the operands are negated:
+    // A = -w, C = -eps, result -(S + eps) < 0 <=> S > -eps (S = -eps exactly gives +0 and is dropped: the bound is strict).
+    // One slack for all: scale the bank by 2^e (exact in binary16) so that eps_max * 2^e <= 4.0 and C can be an inline
+    // constant of the MFMA instead of 16 registers.  The compiler only encodes it inline when every accumulator chain of
+    // the wave has a constant of its own, so tile g of a wave's group (g = tile mod PG) is scaled by 2^(e-g) and tested
+    // against -4 / 2^g: -(S 2^(e-g) + 4 / 2^g) < 0 is S > -4 / 2^e for every g, with 4 / 2^e >= eps_k for every k.
+    const int PG = cand_tile_group(bank.lenp);
     int e = 0;
     bool uniform = std::isfinite(eps_max) && eps_max > 0.f && eps_max <= 4.0f;
     if (uniform) {
         e = (int)std::floor(std::log2(4.0 / eps_max));
         e = std::min(e, 8);
         // scaled weights must stay normal binary16 numbers (no overflow, no bits lost at the bottom)
-        if (wmax * std::ldexp(1.0f, e) >= 32768.0f || (std::isfinite(wmin_nz) && wmin_nz < 6.2e-5f)) uniform = false;
+        if (wmax * std::ldexp(1.0f, e) >= 32768.0f ||
+            (std::isfinite(wmin_nz) && wmin_nz * std::ldexp(1.0f, std::min(0, e - (PG - 1))) < 6.2e-5f))
+            uniform = false;
     }
     out.uniform_eps = uniform ? 1 : 0;
     for (int tile = 0; tile < ntiles; tile++) {
@@ -189,16 +196,17 @@ static void pack_mfma(const PackedBank& bank, const int64_t* lens, int K, MfmaBa
                     const int kk = 16 * t + 8 * hh + j, ind = kk >> 2, a = kk & 3;
                     hv[j] = (k < K && ind < (int)lens[k]) ? wbits(k, a, ind) : (uint16_t)0;
                     if (uniform) {
-                        if (k < K) hv[j] = f2h_exact_scaled(hv[j], e);
+                        if (k < K) hv[j] = f2h_exact_scaled(hv[j], e - tile % PG);
                         else if (ind == 0) hv[j] = 0xec00u;   // -4096: a row without a PWM never becomes a candidate
                     }
+                    hv[j] ^= 0x8000u;                         // negated operands (above)
                 }
                 uint32_t* dst = &out.afrag[(((size_t)tile * T + t) * 64 + lane) * 4];
                 for (int u = 0; u < 4; u++) dst[u] = (uint32_t)hv[2 * u] | ((uint32_t)hv[2 * u + 1] << 16);
             }
         for (int q = 0; q < 32; q++) {
             const int k = tile * 32 + q;
-            if (k < K) out.cinit[((size_t)tile * 2 + (q >> 4)) * 16 + (q & 15)] = eps[k];
+            if (k < K) out.cinit[((size_t)tile * 2 + (q >> 4)) * 16 + (q & 15)] = -eps[k];
         }
     }
 }

@@ -40,39 +40,48 @@ static __device__ __forceinline__ unsigned xcd_swz(unsigned b, unsigned nb) {
 //                     h reports);
 //   B operand (cols): 32 consecutive windows; lane (w, h) needs the one-hot of positions l0+w+4t+2h, +1,
 //                     read as two 8-byte LDS words from the read's one-hot image;
-//   C = eps_k per PWM row, so that the sign bit of the result is "not a candidate".
+//   A and C arrive negated (pack_mfma): C = -eps_k per PWM row, the result is -(S + eps_k) and its sign bit says
+//                     "candidate".
 // NG = live tiles of the group (tiles past the bank hold no PWM).  The body is branch-free so that the NG
 // accumulator chains interleave: the matrix pipe works on one tile while the VALU packs the signs of another.
 // emit(l0, wa, wb) receives the candidate words of window l0 + w: PG = 4: lane half h holds words 2h, 2h + 1 of the
 // chunk; PG = 2: wa = word h of the wave's pair (wb = 0); PG = 1: wa = the word (both halves).
-template <int T, int PG, int NG, int NC, typename E>
-static __device__ __forceinline__ void cand_read(const f16x8 (&A)[PG][T], const f32x16 (&C0)[NC], const uint2* oh, int ntile, int w,
-                                                 int h, E&& emit) {
+// ohl = the lane's column in the one-hot image at window tile 0 (position of its window + 2h); WSTEP = windows a tile
+// advances by (32: one read per wave; 8: four reads per wave, scan_cand_kernel_q).
+template <int T, int PG, int NG, int NC, int WSTEP, typename E>
+static __device__ __forceinline__ void cand_read(const f16x8 (&A)[PG][T], const f32x16 (&C0)[NC], const uint2* ohl, int ntile, E&& emit) {
     for (int wt = 0; wt < ntile; wt++) {
-        const int l0 = wt * 32;
+        const int l0 = wt * WSTEP;
         f16x8 B[T];
 #pragma unroll
         for (int t = 0; t < T; t++) {
-            const int pos = l0 + w + 4 * t + 2 * h;
-            const uint2 a0 = oh[pos], a1 = oh[pos + 1];
+            const uint2 a0 = ohl[l0 + 4 * t], a1 = ohl[l0 + 4 * t + 1];
             B[t] = __builtin_bit_cast(f16x8, make_uint4(a0.x, a0.y, a1.x, a1.y));
         }
         f32x16 acc[NG];
 #pragma unroll
-        for (int g = 0; g < NG; g++) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[g][0], B[0], C0[NC == 1 ? 0 : g], 0, 0, 0);
+        for (int g = 0; g < NG; g++) {
+            f32x16 c;
+            if (NC == 1) {                // a constant per chain: one shared splat is materialised in 16 VGPRs per tile instead
+                const float cv = g == 0 ? -4.0f : g == 1 ? -2.0f : g == 2 ? -1.0f : -0.5f;
+#pragma unroll
+                for (int r = 0; r < 16; r++) c[r] = cv;
+            } else {
+                c = C0[g];
+            }
+            acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[g][0], B[0], c, 0, 0, 0);
+        }
 #pragma unroll
         for (int t = 1; t < T; t++)
 #pragma unroll
             for (int g = 0; g < NG; g++) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[g][t], B[t], acc[g], 0, 0, 0);
-        uint32_t m[PG];           // bit r = accumulator r is a candidate (sign clear = above -eps)
+        uint32_t m[PG];           // bit r = accumulator r is a candidate (sign set: -(S + eps) < 0)
 #pragma unroll
         for (int g = 0; g < PG; g++) {
             m[g] = 0;
             if (g < NG) {
-                uint32_t v = 0;
 #pragma unroll
-                for (int r = 15; r >= 0; r--) v = __builtin_amdgcn_alignbit(v, __float_as_uint(acc[g][r]), 31);
-                m[g] = ~v & 0xffffu;
+                for (int r = 15; r >= 0; r--) m[g] = __builtin_amdgcn_alignbit(m[g], __float_as_uint(acc[g][r]), 31);
             }
         }
         // the other 16 PWMs of a tile sit in the other half of the wave: v_permlane32_swap hands lane (w, 0) both
@@ -91,8 +100,8 @@ static __device__ __forceinline__ void cand_read(const f16x8 (&A)[PG][T], const 
     }
 }
 
-// UEPS: the bank was scaled by a power of two on the host so that one slack, the inline constant 4.0, serves
-// every PWM (C is then not a register operand and the wave needs 64 VGPRs fewer); otherwise C = eps_k from cinit.
+// UEPS: the bank was scaled by powers of two on the host so that the slack of tile g of a group is the inline constant
+// -4 / 2^g (C is then not a register operand and the wave needs 64 VGPRs fewer); otherwise C = -eps_k from cinit.
 template <int T, int PG, bool UEPS, int RPB, int TGB>
 static __device__ __forceinline__ void scan_cand_body(const uint4* __restrict__ afrag, const float* __restrict__ cinit,
                                                       const uint8_t* __restrict__ codes, uint32_t* __restrict__ cells,
@@ -128,7 +137,7 @@ static __device__ __forceinline__ void scan_cand_body(const uint4* __restrict__ 
     }
     if (UEPS) {
 #pragma unroll
-        for (int r = 0; r < 16; r++) C0[0][r] = 4.0f;
+        for (int r = 0; r < 16; r++) C0[0][r] = 0.f;   // unused: cand_read takes the inline constants
     }
 
     const unsigned lb = xcd_swz(blockIdx.x, gridDim.x);
@@ -169,11 +178,12 @@ static __device__ __forceinline__ void scan_cand_body(const uint4* __restrict__ 
             }
             cp += tile_step;
         };
+        const uint2* ohl = oh + w + 2 * h;
         switch (ng) {
-            case 1: cand_read<T, PG, 1, NC>(A, C0, oh, ntile, w, h, store_cells); break;
-            case 2: cand_read<T, PG, (PG >= 2 ? 2 : PG), NC>(A, C0, oh, ntile, w, h, store_cells); break;
-            case 3: cand_read<T, PG, (PG >= 3 ? 3 : PG), NC>(A, C0, oh, ntile, w, h, store_cells); break;
-            default: cand_read<T, PG, PG, NC>(A, C0, oh, ntile, w, h, store_cells); break;
+            case 1: cand_read<T, PG, 1, NC, 32>(A, C0, ohl, ntile, store_cells); break;
+            case 2: cand_read<T, PG, (PG >= 2 ? 2 : PG), NC, 32>(A, C0, ohl, ntile, store_cells); break;
+            case 3: cand_read<T, PG, (PG >= 3 ? 3 : PG), NC, 32>(A, C0, ohl, ntile, store_cells); break;
+            default: cand_read<T, PG, PG, NC, 32>(A, C0, ohl, ntile, store_cells); break;
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -190,6 +200,110 @@ template <int T, int PG, int TGB>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((T * PG <= 16 && PG > 1) ? 3 : 2, 4))) void scan_cand_kernel_u(
     const uint4* __restrict__ afrag, const uint8_t* __restrict__ codes, uint32_t* __restrict__ cells, const CandDims d) {
     scan_cand_body<T, PG, true, 4 / TGB, TGB>(afrag, nullptr, codes, cells, d);
+}
+
+// Four reads per wave (uniform slack, short reads): the 32 columns of a tile are 8 consecutive windows of 4 consecutive
+// reads, lane (w, h) -> read w >> 3, window w & 7.  The cells of one start l and 4 reads x 2 chunks are one 128-byte line,
+// so a wave's store touches 8 lines instead of 32 (the 32-line scatter cost 10 % of the kernel: the same bytes stored
+// contiguously ran 0.343 ms against 0.381), and the per-read overhead (staging, cell address) is shared by 24 tiles
+// instead of 6.  The four images sit `opitch` apart in LDS, opitch = 8 (mod 32) positions = 64 (mod 256) bytes: the 8-byte
+// B-operand reads of a half wave then cover the 64 banks exactly once.
+static __host__ __device__ inline int quad_pitch(int ohlen) { return ((((ohlen + 3) & ~3) - 8 + 31) & ~31) + 8; }
+
+template <int T, int PG, int TGB>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((T * PG <= 12) ? 4 : (T * PG <= 16 && PG > 1) ? 3 : 2, 4))) void scan_cand_kernel_q(
+    const uint4* __restrict__ afrag, const uint8_t* __restrict__ codes, uint32_t* __restrict__ cells, const CandDims d) {
+    extern __shared__ __attribute__((aligned(16))) uint2 oh_all[];
+    constexpr int QPB = 4 / TGB;                     // quads of reads per block
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int w = lane & 31, h = lane >> 5, rq = w >> 3, wq = w & 7;
+    const int opitch = quad_pitch(d.ohlen);
+    uint2* oh = oh_all + (size_t)wave * 4 * opitch;
+    const int slot = wave % QPB;
+    const int tg = blockIdx.y * TGB + wave / QPB;
+    if (tg * PG >= d.used_tiles) return;
+    const int tile0 = tg * PG;
+    const int chunk = tile0 >> 2, word0 = tile0 & 3;
+    const int ng = d.used_tiles - tile0 < PG ? d.used_tiles - tile0 : PG;   // wave-uniform
+
+    f16x8 A[PG][T];
+    f32x16 C0[1];
+#pragma unroll
+    for (int r = 0; r < 16; r++) C0[0][r] = 0.f;     // unused: cand_read takes the inline constants
+#pragma unroll
+    for (int g = 0; g < PG; g++)
+#pragma unroll
+        for (int t = 0; t < T; t++) A[g][t] = __builtin_bit_cast(f16x8, afrag[((size_t)(tile0 + g) * T + t) * 64 + lane]);
+
+    const unsigned lb = xcd_swz(blockIdx.x, gridDim.x);
+    const int ntile = (d.Lout + 7) / 8;
+    const size_t lstride4 = (size_t)d.batch * d.nch * 4;
+    const uint2* ohl = oh + rq * opitch + wq + 2 * h;
+    // (ordering batch, read in batch) of the wave's first read; later quads advance it without dividing
+    int64_t nq = ((int64_t)lb * d.spw * QPB + slot) * 4;
+    int64_t bq0 = nq / d.batch;
+    int r0 = (int)(nq - bq0 * d.batch);
+    for (int s = 0; s < d.spw; s++, nq += 4 * QPB) {
+        if (nq >= d.N) break;
+        // stage the one-hot images: 4 halves per position (1.0 at the base; all zero for code 4, padding and reads past N);
+        // a lane turns one dword of codes into four positions
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) {
+            const uint32_t* srow = (const uint32_t*)(codes + (nq + rr) * d.pitch);
+            const bool row = nq + rr < d.N;
+            for (int p4 = lane; p4 * 4 < d.ohlen; p4 += 64) {
+                const int keep = d.L - p4 * 4;       // positions of this dword inside the read
+                uint32_t wv = 0x04040404u;
+                if (row && keep > 0) {
+                    wv = srow[p4];
+                    if (keep < 4) {
+                        const uint32_t mk = (1u << (8 * keep)) - 1u;
+                        wv = (wv & mk) | (0x04040404u & ~mk);
+                    }
+                }
+                const uint32_t sh = wv << 4;         // 16 * code per byte; code 4 -> shift 63: the 1.0 leaves the word
+                uint64_t one[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t su = (sh >> (8 * u)) & 0xffu;
+                    one[u] = (uint64_t)0x3c00u << (su < 63u ? su : 63u);
+                }
+                uint4* dst = (uint4*)(oh + rr * opitch + p4 * 4);
+                dst[0] = make_uint4((uint32_t)one[0], (uint32_t)(one[0] >> 32), (uint32_t)one[1], (uint32_t)(one[1] >> 32));
+                dst[1] = make_uint4((uint32_t)one[2], (uint32_t)(one[2] >> 32), (uint32_t)one[3], (uint32_t)(one[3] >> 32));
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // the lane's read and its cell of window tile 0; window tiles follow 8 cell lines apart
+        int64_t bql = bq0;
+        int rl = r0 + rq;
+        while (rl >= d.batch) rl -= d.batch, bql++;
+        const bool rowl = nq + rq < d.N;
+        const size_t cell0 = ((size_t)bql * d.Lout * d.batch + (size_t)rl) * d.nch + chunk;
+        uint32_t* cp = cells + cell0 * 4 + word0 + (size_t)wq * lstride4 + (PG == 4 ? 2 * h : PG == 2 ? h : 0);
+        const size_t tile_step = 8 * lstride4;
+        auto store_cells = [&](int l0, uint32_t wa, uint32_t wb) {
+            const bool live = rowl && l0 + wq < d.Lout;
+            if (PG == 4) {
+                if (live && (ng > 2 || h == 0)) *(uint2*)cp = make_uint2(wa, wb);
+            } else if (PG == 2) {
+                if (live) *cp = wa;
+            } else {
+                if (live && h == 0) *cp = wa;
+            }
+            cp += tile_step;
+        };
+        switch (ng) {
+            case 1: cand_read<T, PG, 1, 1, 8>(A, C0, ohl, ntile, store_cells); break;
+            case 2: cand_read<T, PG, (PG >= 2 ? 2 : PG), 1, 8>(A, C0, ohl, ntile, store_cells); break;
+            case 3: cand_read<T, PG, (PG >= 3 ? 3 : PG), 1, 8>(A, C0, ohl, ntile, store_cells); break;
+            default: cand_read<T, PG, PG, 1, 8>(A, C0, ohl, ntile, store_cells); break;
+        }
+        __builtin_amdgcn_wave_barrier();
+        r0 += 4 * QPB;
+        while (r0 >= d.batch) r0 -= d.batch, bq0++;
+    }
 }
 
 // ---- candidates -> records ---------------------------------------------------------------------------------
@@ -548,6 +662,16 @@ template <int T, int PG>
 static hipError_t launch_cand_tp(const CandArgs& a, hipStream_t st) {
     const int ntg = (a.d.used_tiles + PG - 1) / PG;           // tile groups that hold PWMs
     const int tgb = (a.uniform_eps && ntg == 1) ? 1 : 2;
+    const size_t lds_q = (size_t)4 * 4 * quad_pitch(a.d.ohlen) * 8;
+    if (a.uniform_eps && lds_q <= 40 * 1024) {                // four reads per wave: four blocks still share a CU's LDS
+        CandDims d = a.d;
+        d.spw = std::max(1, (a.d.spw + 3) / 4);               // quads per wave
+        const int64_t per_block = (int64_t)(4 / tgb) * 4 * d.spw;
+        dim3 grid((unsigned)((d.N + per_block - 1) / per_block), (unsigned)((ntg + tgb - 1) / tgb), 1);
+        if (tgb == 1) hipLaunchKernelGGL((scan_cand_kernel_q<T, PG, 1>), grid, dim3(256), lds_q, st, a.afrag, a.codes, a.cells, d);
+        else hipLaunchKernelGGL((scan_cand_kernel_q<T, PG, 2>), grid, dim3(256), lds_q, st, a.afrag, a.codes, a.cells, d);
+        return hipGetLastError();
+    }
     const int rpb = a.uniform_eps ? 4 / tgb : 4;
     const int64_t per_block = (int64_t)rpb * a.d.spw;
     dim3 grid((unsigned)((a.d.N + per_block - 1) / per_block), (unsigned)((ntg + tgb - 1) / tgb), 1);
