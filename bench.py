@@ -306,7 +306,7 @@ def main():
         hbm_copy_gbs = _rate(lambda: hy.copy_(hx), 2 * hx.numel() * 2)
         del hx, hy
         extras["dense_kernel"] = {
-            "kernel": "scan_cand_kernel_u<3,4> + stage_hits<12,.,2> (a17 greedy_search! drop-in, writes (K,nb,L-len+1) fp16: zeros + exact scores of the hits, every byte once)",
+            "kernel": "scan_cand_kernel_q<3,4,2> + stage_hits<12,.,2> (a17 greedy_search! drop-in, writes (K,nb,L-len+1) fp16: zeros + exact scores of the hits, every byte once)",
             "checked": "positive entries == hit records of the same reads, score checksums equal",
             "bound": "hbm", "achieved": dense_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": dense_gbs / HBM_PEAK_GBS, "frac_of_measured_fill": dense_gbs / hbm_fill_gbs,
@@ -475,7 +475,7 @@ def main():
             "parallelism": f"sequence shards x{world}; per step one sum of the 2 x {K} hit histogram: {reducer.kind} ({reducer_note})",
         },
         "roofline": {
-            "kernel": "scan_cand_kernel_u<3,4> (v_mfma_f32_32x32x16_f16 candidate filter, one strand of the shard per launch)",
+            "kernel": "scan_cand_kernel_q<3,4,2> (v_mfma_f32_32x32x16_f16 candidate filter, four reads per wave, one strand of the shard per launch)",
             "bound": "mfma",
             "achieved": cand_tflops,
             "peak": MFMA_F16_PEAK_TFLOPS,
