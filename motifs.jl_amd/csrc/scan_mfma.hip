@@ -637,12 +637,31 @@ __global__ __launch_bounds__(VF_THREADS) void emit_records(FillArgs a) {
             }
         };
         if (!big) {
+            // four 256-byte loads of staged words in flight per wave (one at a time left the pass bound by load latency);
+            // the capacity check is folded into the trip count
             const uint32_t* slots = a.staging + (size_t)r * a.row_slots;
-            for (uint32_t j = lane; j < cnt; j += 64) {
-                const uint32_t e = slots[j];
-                const uint32_t idx = e >> 23, q = (e >> 21) & 3u, i = (e >> 16) & 31u;
-                const uint32_t nin = a.div_nch.div(idx);
-                put(row_at + j, ((idx - nin * a.nch) * 4 + q) * 32 + i, nin, (uint16_t)e);
+            const int64_t room = a.cap - row_at;
+            const uint32_t lim = room <= 0 ? 0u : (room < (int64_t)cnt ? (uint32_t)room : cnt);
+            HitRec* hrow = a.hits + row_at;
+            uint16_t* srow = a.hit_scores + row_at;
+            const uint32_t rec_n = (uint32_t)(g.nrow0 + a.n0 + 1), rec_l = (uint32_t)(g.l + 1);
+            for (uint32_t j0 = 0; j0 < lim; j0 += 256) {
+                uint32_t e[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t j = j0 + u * 64 + lane;
+                    e[u] = j < lim ? slots[j] : 0u;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t j = j0 + u * 64 + lane;
+                    const uint32_t idx = e[u] >> 23, q = (e[u] >> 21) & 3u, i = (e[u] >> 16) & 31u;
+                    const uint32_t nin = a.div_nch.div(idx);
+                    if (j < lim) {
+                        hrow[j] = HitRec{((idx - nin * a.nch) * 4 + q) * 32 + i + 1, rec_n + nin, rec_l};
+                        srow[j] = (uint16_t)e[u];
+                    }
+                }
             }
         } else {
             uint32_t nhit = 0;
