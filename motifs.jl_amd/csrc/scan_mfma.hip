@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((T * PG <= 
 // from its cells there (rare: more than two hits per cell on average).
 constexpr int VF_THREADS = 512;
 constexpr int VF_WAVES = VF_THREADS / 64;
-constexpr int QN = 128;           // candidate ring slots per wave (power of two); fewer than 64 stay behind after a push
+constexpr int QN = 512;           // candidate queue slots per wave; fewer than 64 stay behind after a push
 constexpr int ROW_CELLS_MAX = 512;
 
 // The re-scoring table: one row of binary16 weights per PWM, [k][ind][5] with column 4 = +0 for an all-zero data
@@ -373,35 +373,53 @@ static __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// the candidates of one 64-cell slab into the wave's FIFO ring, draining full batches of 64 through fn(word)
-// candidate word = cell index in the row << 7 | word << 5 | bit
+// the candidates of one 64-cell slab into the wave's queue, draining full batches of 64 through fn(word)
+// candidate word = cell index in the row << 7 | word << 5 | bit.  The queue is a linear buffer (whatever a drain leaves,
+// fewer than 64 words, moves to its front), so that a lane writes its candidates through a running pointer: per set bit
+// ctz, or, store, clear - no ring arithmetic and no capacity test (a slab that does not fit whole, > 448 candidates in 64
+// cells, goes in pieces through the checked loop).
 template <typename F>
-static __device__ __forceinline__ void push_and_drain(uint16_t* queue, uint32_t& head, uint32_t& qlen, const uint32_t (&wd)[4],
-                                                      uint32_t idx, uint32_t ex, uint32_t tot, F&& fn) {
+static __device__ __forceinline__ void push_and_drain(uint16_t* queue, uint32_t& qlen, const uint32_t (&wd)[4], uint32_t idx, uint32_t ex,
+                                                      uint32_t tot, F&& fn) {
     const int lane = threadIdx.x & 63;
     uint32_t done = 0;
     while (true) {                                                    // wave-uniform
         const uint32_t room = QN - qlen;
         const uint32_t take = tot - done < room ? tot - done : room;
-        uint32_t g = ex;
+        if (take == tot) {
+            uint16_t* p = queue + qlen + ex;
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            uint32_t bits = wd[q];
-            while (bits) {
-                const int i = __builtin_ctz(bits);
-                bits &= bits - 1;
-                if (g >= done && g < done + take)
-                    queue[(head + qlen + g - done) & (QN - 1)] = (uint16_t)((idx << 7) | ((uint32_t)q << 5) | (uint32_t)i);
-                g++;
+            for (int q = 0; q < 4; q++) {
+                uint32_t bits = wd[q];
+                const uint32_t pre = (idx << 7) | ((uint32_t)q << 5);
+                while (bits) {
+                    *p++ = (uint16_t)(pre | (uint32_t)__builtin_ctz(bits));
+                    bits &= bits - 1;
+                }
+            }
+        } else {
+            uint32_t g = ex;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                uint32_t bits = wd[q];
+                while (bits) {
+                    const int i = __builtin_ctz(bits);
+                    bits &= bits - 1;
+                    if (g >= done && g < done + take) queue[qlen + g - done] = (uint16_t)((idx << 7) | ((uint32_t)q << 5) | (uint32_t)i);
+                    g++;
+                }
             }
         }
         qlen += take;
         done += take;
         wave_lds_sync();
-        while (qlen >= 64) {
-            fn((uint32_t)queue[(head + lane) & (QN - 1)], true);
-            head += 64;
-            qlen -= 64;
+        uint32_t at = 0;
+        for (; at + 64 <= qlen; at += 64) fn((uint32_t)queue[at + lane], true);
+        if (at) {                                                     // the remainder to the front
+            const uint16_t v = at + lane < (uint32_t)QN ? queue[at + lane] : (uint16_t)0;
+            wave_lds_sync();
+            qlen -= at;
+            if ((uint32_t)lane < qlen) queue[lane] = v;
         }
         wave_lds_sync();
         if (done >= tot) break;
@@ -438,7 +456,7 @@ static __device__ __forceinline__ RowGeom row_geom(const FillArgs& a, int64_t r)
 template <typename F>
 static __device__ __forceinline__ void for_row_candidates(const RowGeom& g, uint16_t* queue, F&& fn) {
     const int lane = threadIdx.x & 63;
-    uint32_t qlen = 0, head = 0;                                      // wave-uniform
+    uint32_t qlen = 0;                                                // wave-uniform
     uint4 m_next = make_uint4(0u, 0u, 0u, 0u);
     if ((uint32_t)lane < g.row_cells) m_next = g.cells[lane];
     for (uint32_t i0 = 0; i0 < g.row_cells; i0 += 64) {               // wave-uniform trip count
@@ -450,9 +468,9 @@ static __device__ __forceinline__ void for_row_candidates(const RowGeom& g, uint
         const uint32_t pc = __builtin_popcount(m.x) + __builtin_popcount(m.y) + __builtin_popcount(m.z) + __builtin_popcount(m.w);
         const uint32_t inc = wave_incl_scan(pc);
         const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
-        if (tot) push_and_drain(queue, head, qlen, wd, idx, inc - pc, tot, fn);
+        if (tot) push_and_drain(queue, qlen, wd, idx, inc - pc, tot, fn);
     }
-    if (qlen) fn((uint32_t)queue[(head + lane) & (QN - 1)], (uint32_t)lane < qlen);   // the remainder (< 64)
+    if (qlen) fn((uint32_t)queue[lane], (uint32_t)lane < qlen);      // the remainder (< 64)
     wave_lds_sync();
 }
 
@@ -497,6 +515,8 @@ __global__ __launch_bounds__(VF_THREADS) __attribute__((amdgpu_waves_per_eu(LEN 
         for (int i = tid; i < VF_WAVES * DWIN / 2; i += VF_THREADS) winbase[i] = 0u;
     const _Float16* tb = stage_table<LDS_TAB, VF_THREADS>(a, ltab);
     __syncthreads();
+    // (rows handed out through one atomic counter instead of this fixed stride: 1.0 ms against 0.28 - ~85k device-scope
+    // atomics on one address serialise at ~10 ns each)
     const int64_t nwaves = (int64_t)gridDim.x * VF_WAVES;
     for (int64_t r = (int64_t)wv * gridDim.x + blockIdx.x; r < a.nrows; r += nwaves) {
         const RowGeom g = row_geom(a, r);
