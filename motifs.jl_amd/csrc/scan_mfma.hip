@@ -702,7 +702,9 @@ static hipError_t launch_cand_tp(const CandArgs& a, hipStream_t st) {
     const int ntg = (a.d.used_tiles + PG - 1) / PG;           // tile groups that hold PWMs
     const int tgb = (a.uniform_eps && ntg == 1) ? 1 : 2;
     const size_t lds_q = (size_t)4 * 4 * quad_pitch(a.d.ohlen) * 8;
-    if (a.uniform_eps && lds_q <= 40 * 1024) {                // four reads per wave: four blocks still share a CU's LDS
+    // four reads per wave while the LDS images leave the CU as many blocks as the registers do (4, 3 or 2 per CU)
+    constexpr int wpe = (T * PG <= 12) ? 4 : (T * PG <= 16 && PG > 1) ? 3 : 2;
+    if (a.uniform_eps && lds_q <= std::min<size_t>(64 * 1024, 160 * 1024 / wpe)) {
         CandDims d = a.d;
         // quads per wave: many small blocks balance the CUs best (N = 100k: 1 or 2 per wave 0.337 ms, 3: 0.354, 8: 0.390)
         d.spw = (int)std::max<int64_t>(1, std::min<int64_t>(8, a.d.N / (16 * 8192)));
