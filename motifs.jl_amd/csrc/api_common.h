@@ -77,6 +77,9 @@ struct motifs_ctx {
     motifs::DevBuf staging, rowx;   // matrix-core scan: staged hit words, per-row offsets
     motifs::BankSlot bank_slot[2];  // [rc]
     void* pinned = nullptr;  // small pinned host block for totals / flags
+    // pinned staging of the host-buffer entries (motifs_pwm_scan*): code rows on the way up, record chunks on the way down
+    void* pin_stage = nullptr;
+    size_t pin_stage_cap = 0;
 };
 
 #define MOTIFS_HIP_CHECK(expr)                                                                   \

@@ -13,6 +13,8 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <thread>
 #include <vector>
 
 #include "api_common.h"
@@ -492,6 +494,7 @@ void motifs_ctx_destroy(motifs_ctx* c) {
         for (DevBuf* b : {&bs.tab, &bs.lim, &bs.afrag, &bs.cinit, &bs.tabk}) b->release();
 
     if (c->pinned) (void)hipHostFree(c->pinned);
+    if (c->pin_stage) (void)hipHostFree(c->pin_stage);
     resolve_timing(c);
     for (hipEvent_t e : c->free_events) (void)hipEventDestroy(e);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -864,34 +867,191 @@ int motifs_pwm_scan_hits_both_dev(motifs_ctx* c, const uint16_t* pwms_fp16, cons
     return MOTIFS_OK;
 }
 
+}  // extern "C"
+
+// ---- host-buffer entries: what crosses PCIe -------------------------------------------------------------------------
+// The reference's data matrix is Float32 one-hot, 16 bytes per base; the device wants 1 byte per base.  Host threads turn
+// the one-hot columns into code rows in a pinned buffer (the same bytes encode_f32 / encode_f16 would produce, the same
+// one-hot check), so 1/16 of the matrix crosses the bus; the records come back through pinned chunks that host threads
+// copy out while the next chunk is on the wire (a pageable hipMemcpy stages every byte through the runtime's own bounce
+// buffer on one thread).
+static hipError_t pin_reserve(motifs_ctx* c, size_t bytes) {
+    if (bytes <= c->pin_stage_cap) return hipSuccess;
+    if (c->pin_stage) (void)hipHostFree(c->pin_stage);
+    c->pin_stage = nullptr;
+    c->pin_stage_cap = 0;
+    const size_t want = bytes + bytes / 8 + 4096;
+    hipError_t e = hipHostMalloc(&c->pin_stage, want, hipHostMallocDefault);
+    if (e != hipSuccess) return e;
+    c->pin_stage_cap = want;
+    return hipSuccess;
+}
+static int host_threads(int64_t work_items, int64_t per_thread) {
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int64_t want = std::max<int64_t>(1, work_items / std::max<int64_t>(per_thread, 1));
+    return (int)std::min<int64_t>(std::min<int64_t>(hw ? hw : 1, 32), want);
+}
+template <typename F>
+static void run_threads(int T, F&& fn) {
+    if (T <= 1) {
+        fn(0);
+        return;
+    }
+    std::vector<std::thread> th;
+    th.reserve(T - 1);
+    for (int t = 1; t < T; t++) th.emplace_back([&fn, t]() { fn(t); });
+    fn(0);
+    for (auto& x : th) x.join();
+}
+
+// one-hot rows [n0, n1) -> code rows (pitch bytes each: codes, zero padding, the row flag in byte pitch - 4); returns
+// whether a column was neither one-hot nor all-zero
+template <typename T4, typename Dec>
+static bool encode_rows_host(const T4* x, int64_t n0, int64_t n1, int L, int pitch, uint8_t* rows, Dec&& decode) {
+    bool bad = false;
+    for (int64_t n = n0; n < n1; n++) {
+        uint8_t* row = rows + (size_t)n * pitch;
+        const T4* src = x + (size_t)n * L;
+        uint8_t flag = 0;
+        for (int p = 0; p < L; p++) {
+            const int code = decode(src[p], bad);
+            row[p] = (uint8_t)code;
+            flag |= (uint8_t)(code == 4);
+        }
+        memset(row + L, 0, (size_t)(pitch - L));
+        row[pitch - 4] = flag;
+    }
+    return bad;
+}
+struct F32x4 {
+    float v[4];
+};
+struct F16x4 {
+    uint16_t v[4];
+};
+
 // host matrix of `kind` -> c->codes (the internal code matrix), checked for one-hot columns
 static int upload_and_encode(motifs_ctx* c, const void* data, int kind, int64_t N, int L) {
-    const size_t elt = kind == MOTIFS_DATA_ONEHOT_F32 ? 16 : kind == MOTIFS_DATA_ONEHOT_F16 ? 8 : 1;
     MOTIFS_HIP_CHECK(c->codes.reserve(motifs_codes_bytes(N, L)));
     MOTIFS_HIP_CHECK(c->small.reserve(4096));
-    // encode in slabs so the staging buffer stays bounded (<= 1 GiB)
-    const int64_t slab = std::max<int64_t>(1, (int64_t)((1ull << 30) / ((size_t)L * elt)));
-    MOTIFS_HIP_CHECK(c->data_tmp.reserve((size_t)std::min<int64_t>(slab, std::max<int64_t>(N, 1)) * L * elt + 64));
-    int32_t* bad_dev = (int32_t*)((char*)c->small.p + 2048);
-    MOTIFS_HIP_CHECK(hipMemsetAsync(bad_dev, 0, 4, c->stream));
     const int pitch = motifs_codes_pitch(L);
-    for (int64_t s0 = 0; s0 < N; s0 += slab) {
-        const int64_t ns = std::min<int64_t>(slab, N - s0);
-        MOTIFS_HIP_CHECK(hipMemcpyAsync(c->data_tmp.p, (const char*)data + (size_t)s0 * L * elt, (size_t)ns * L * elt,
-                                        hipMemcpyHostToDevice, c->stream));
-        int r = motifs_encode_dev(c, c->data_tmp.p, kind, ns, L, (uint8_t*)c->codes.p + (size_t)s0 * pitch, bad_dev);
+    if (kind == MOTIFS_DATA_CODES_U8) {
+        // 1 byte per base already: upload and let the device lay the rows out
+        MOTIFS_HIP_CHECK(c->data_tmp.reserve((size_t)std::max<int64_t>(N, 1) * L + 64));
+        int32_t* bad_dev = (int32_t*)((char*)c->small.p + 2048);
+        MOTIFS_HIP_CHECK(hipMemsetAsync(bad_dev, 0, 4, c->stream));
+        MOTIFS_HIP_CHECK(hipMemcpyAsync(c->data_tmp.p, data, (size_t)N * L, hipMemcpyHostToDevice, c->stream));
+        int r = motifs_encode_dev(c, c->data_tmp.p, kind, N, L, (uint8_t*)c->codes.p, bad_dev);
         if (r) return r;
+        int32_t* h_bad = (int32_t*)((char*)c->pinned + 64);
+        MOTIFS_HIP_CHECK(hipMemcpyAsync(h_bad, bad_dev, 4, hipMemcpyDeviceToHost, c->stream));
         MOTIFS_HIP_CHECK(hipStreamSynchronize(c->stream));
+        if (*h_bad) {
+            set_error("data matrix has a code outside 0..4");
+            return MOTIFS_ERR_NOT_ONEHOT;
+        }
+        return MOTIFS_OK;
     }
-    int32_t* h_bad = (int32_t*)((char*)c->pinned + 64);
-    MOTIFS_HIP_CHECK(hipMemcpyAsync(h_bad, bad_dev, 4, hipMemcpyDeviceToHost, c->stream));
-    MOTIFS_HIP_CHECK(hipStreamSynchronize(c->stream));
-    if (*h_bad) {
+    const size_t total = motifs_codes_bytes(N, L);
+    MOTIFS_HIP_CHECK(hipStreamSynchronize(c->stream));        // an earlier call may still read the staging block
+    MOTIFS_HIP_CHECK(pin_reserve(c, total));
+    uint8_t* rows = (uint8_t*)c->pin_stage;
+    const int T = host_threads(N * (int64_t)L, 1 << 18);
+    std::atomic<int> bad{0};
+    run_threads(T, [&](int t) {
+        const int64_t n0 = N * t / T, n1 = N * (t + 1) / T;
+        bool b;
+        if (kind == MOTIFS_DATA_ONEHOT_F32)
+            b = encode_rows_host((const F32x4*)data, n0, n1, L, pitch, rows, [](const F32x4& q, bool& bad_) {
+                const int ones = (q.v[0] == 1.0f) + (q.v[1] == 1.0f) + (q.v[2] == 1.0f) + (q.v[3] == 1.0f);
+                const int zeros = (q.v[0] == 0.0f) + (q.v[1] == 0.0f) + (q.v[2] == 0.0f) + (q.v[3] == 0.0f);
+                if (ones == 1 && zeros == 3) return q.v[0] == 1.0f ? 0 : q.v[1] == 1.0f ? 1 : q.v[2] == 1.0f ? 2 : 3;
+                if (zeros != 4) bad_ = true;
+                return 4;
+            });
+        else
+            b = encode_rows_host((const F16x4*)data, n0, n1, L, pitch, rows, [](const F16x4& q, bool& bad_) {
+                int ones = 0, zeros = 0, which = 0;
+                for (int u = 0; u < 4; u++) {
+                    if (q.v[u] == 0x3c00u) ones++, which = u;
+                    if ((q.v[u] & 0x7fffu) == 0) zeros++;
+                }
+                if (ones == 1 && zeros == 3) return which;
+                if (zeros != 4) bad_ = true;
+                return 4;
+            });
+        if (b) bad.store(1);
+    });
+    if (bad.load()) {
         set_error("data matrix has a column that is neither one-hot nor all-zero");
         return MOTIFS_ERR_NOT_ONEHOT;
     }
+    memset(rows + (size_t)N * pitch, 0, total - (size_t)N * pitch);   // the guard bytes behind the last row
+    MOTIFS_HIP_CHECK(hipMemcpyAsync(c->codes.p, rows, total, hipMemcpyHostToDevice, c->stream));
+    MOTIFS_HIP_CHECK(hipStreamSynchronize(c->stream));        // the staging block is reused by the download
     return MOTIFS_OK;
 }
+
+// device bytes -> pageable host memory: chunks cross the bus into a ring of pinned buffers; host threads copy chunk i out
+// while chunk i + 1 is in flight.  The stream is idle when this returns.
+static int download_chunked(motifs_ctx* c, void* dst, const void* src_dev, size_t bytes) {
+    if (bytes == 0) return MOTIFS_OK;
+    constexpr size_t CH = (size_t)16 << 20;
+    constexpr int NB = 4;
+    if (bytes <= (size_t)4 << 20) {
+        MOTIFS_HIP_CHECK(hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDeviceToHost, c->stream));
+        MOTIFS_HIP_CHECK(hipStreamSynchronize(c->stream));
+        return MOTIFS_OK;
+    }
+    MOTIFS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    MOTIFS_HIP_CHECK(pin_reserve(c, CH * NB));
+    const int64_t nchunk = (int64_t)((bytes + CH - 1) / CH);
+    const int T = std::max(1, std::min(8, host_threads((int64_t)bytes, 8 << 20)));
+    std::vector<hipEvent_t> ev(NB, nullptr);
+    for (auto& e : ev) MOTIFS_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    std::atomic<int64_t> landed{0};                 // chunks whose DMA has completed
+    std::vector<std::atomic<int>> copied(nchunk);   // copier threads done with chunk i
+    for (auto& x : copied) x.store(0);
+    std::atomic<int> failed{0};
+    auto copier = [&](int t) {
+        for (int64_t i = 0; i < nchunk; i++) {
+            while (landed.load(std::memory_order_acquire) <= i) {
+                if (failed.load()) return;
+                std::this_thread::yield();
+            }
+            const size_t off = (size_t)i * CH, len = std::min(CH, bytes - off);
+            const size_t a = len * t / T, b = len * (t + 1) / T;
+            memcpy((char*)dst + off + a, (const char*)c->pin_stage + (size_t)(i % NB) * CH + a, b - a);
+            copied[i].fetch_add(1, std::memory_order_release);
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; t++) th.emplace_back(copier, t);
+    hipError_t err = hipSuccess;
+    for (int64_t i = 0; i < nchunk + 1 && err == hipSuccess; i++) {
+        if (i < nchunk) {
+            if (i >= NB)                              // the ring slot must have been copied out
+                while (copied[i - NB].load(std::memory_order_acquire) < T) std::this_thread::yield();
+            const size_t off = (size_t)i * CH, len = std::min(CH, bytes - off);
+            err = hipMemcpyAsync((char*)c->pin_stage + (size_t)(i % NB) * CH, (const char*)src_dev + off, len, hipMemcpyDeviceToHost, c->stream);
+            if (err == hipSuccess) err = hipEventRecord(ev[i % NB], c->stream);
+        }
+        if (i >= 1 && err == hipSuccess) {            // chunk i - 1 has landed once its event fires
+            err = hipEventSynchronize(ev[(i - 1) % NB]);
+            if (err == hipSuccess) landed.store(i, std::memory_order_release);
+        }
+    }
+    if (err != hipSuccess) failed.store(1);
+    for (auto& x : th) x.join();
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    if (err != hipSuccess) {
+        set_error("record download failed: %s", hipGetErrorString(err));
+        return MOTIFS_ERR_HIP;
+    }
+    return MOTIFS_OK;
+}
+
+extern "C" {
 
 int motifs_pwm_scan(motifs_ctx* c, const uint16_t* pwms_fp16, const int64_t* lens, int K, int maxlen, const void* data,
                     int kind, int64_t N, int L, int rc, motifs_hit* hits, uint16_t* hit_scores, int64_t cap,
@@ -919,8 +1079,9 @@ int motifs_pwm_scan(motifs_ctx* c, const uint16_t* pwms_fp16, const int64_t* len
     if (per_pwm_counts && (r == MOTIFS_OK || r == MOTIFS_ERR_BUFFER_TOO_SMALL))
         MOTIFS_HIP_CHECK(hipMemcpyAsync(per_pwm_counts, counts_dev, (size_t)K * 8, hipMemcpyDeviceToHost, c->stream));
     if (r == MOTIFS_OK && cap > 0 && *n_out > 0) {
-        MOTIFS_HIP_CHECK(hipMemcpyAsync(hits, c->hits_tmp.p, (size_t)*n_out * sizeof(motifs_hit), hipMemcpyDeviceToHost, c->stream));
-        MOTIFS_HIP_CHECK(hipMemcpyAsync(hit_scores, c->scores_tmp.p, (size_t)*n_out * 2, hipMemcpyDeviceToHost, c->stream));
+        int d = download_chunked(c, hits, c->hits_tmp.p, (size_t)*n_out * sizeof(motifs_hit));
+        if (d == MOTIFS_OK) d = download_chunked(c, hit_scores, c->scores_tmp.p, (size_t)*n_out * 2);
+        if (d) return d;
     }
     MOTIFS_HIP_CHECK(hipStreamSynchronize(c->stream));
     return r;
@@ -964,8 +1125,9 @@ int motifs_pwm_scan_both(motifs_ctx* c, const uint16_t* pwms_fp16, const int64_t
         uint16_t* sh[2] = {scores_fwd, scores_rc};
         for (int s = 0; s < 2; s++)
             if (n_out2[s] > 0) {
-                MOTIFS_HIP_CHECK(hipMemcpyAsync(hh[s], hd[s], (size_t)n_out2[s] * sizeof(motifs_hit), hipMemcpyDeviceToHost, c->stream));
-                MOTIFS_HIP_CHECK(hipMemcpyAsync(sh[s], sd[s], (size_t)n_out2[s] * 2, hipMemcpyDeviceToHost, c->stream));
+                int d = download_chunked(c, hh[s], hd[s], (size_t)n_out2[s] * sizeof(motifs_hit));
+                if (d == MOTIFS_OK) d = download_chunked(c, sh[s], sd[s], (size_t)n_out2[s] * 2);
+                if (d) return d;
             }
     }
     MOTIFS_HIP_CHECK(hipStreamSynchronize(c->stream));
