@@ -338,8 +338,8 @@ def main():
                 "bases_per_s": N * L / bdt, "ms_both_strands": bdt * 1e3,
                 "per_strand_entry": {"entry": "motifs_pwm_scan, one call per strand (get_pos_scores_arr, :57-87)", "bases_per_s": N * L / hdt,
                                      "ms_both_strands": hdt * 1e3},
-                "h2d_bytes": int(onehot.nbytes), "d2h_bytes_both_strands": int(n_h * 14),
-                "note": "PCIe-inclusive and pageable host memory: upload of 16 B/base, download of 14 B/hit; never `value`",
+                "host_matrix_bytes": int(onehot.nbytes), "h2d_bytes": int(lib.Context.codes_bytes(N, L)), "d2h_bytes_both_strands": int(n_h * 14),
+                "note": "PCIe-inclusive, pageable host memory: the 16 B/base one-hot matrix becomes 1 B/base code rows on host threads (pinned) before the upload; 14 B/hit come down through a pinned ring; never `value`",
             }
             del onehot
             # ---- FASTA text -> base codes (loadfasta/helpers.jl:83-139), host threads only ----
