@@ -269,3 +269,33 @@ def test_dp_train_step_single_device_equals_train_step(ctx, pkg):
     finally:
         a.model.close()
         b.model.close()
+
+
+# ---- host-buffer entries: threaded one-hot -> codes on the host, records down through the pinned ring ----
+def test_host_entry_many_records_equal_device_path(torch_cuda, ctx, pkg):
+    """Enough records for more than one 16 MB chunk of the download ring (and several encoder threads): the host entries
+    return exactly what the device-resident path and the CPU port give; all-zero columns and a bad column included."""
+    sy, lib = pkg.synth, pkg._lib
+    N, L, K = 7000, 200, 200
+    codes = sy.gen_codes(N, L, 4242, n_plant=5, k=12)
+    codes[17, 5] = 4
+    codes[6999, 199] = 4
+    pwms, lens = sy.gen_pwm_bank(K, 4243, len_lo=12, len_hi=12)
+    bank = sy.pad_bank(pwms, lens)
+    onehot = sy.codes_to_onehot(codes)
+    both = ctx.pwm_scan_both(bank, lens, onehot, lib.DATA_ONEHOT_F32, N, L)
+    assert len(both[0][0]) * 12 > (16 << 20), "the test wants more than one chunk of records per strand"
+    for rc in (False, True):
+        h, s = dev_scan_hits(torch_cuda, ctx, pkg, bank, lens, codes, rc, 5000)
+        f = both[int(rc)][0]
+        got = np.stack([f["m"], f["n"], f["l"]], axis=1).astype(np.uint32)
+        assert np.array_equal(got, h) and np.array_equal(both[int(rc)][1].view(np.uint16), s)
+        oh, os_ = fast_oracle_hits(bank, lens, codes, rc, 5000)
+        assert np.array_equal(h, oh) and np.array_equal(s, os_)
+        f1, s1 = ctx.pwm_scan(bank, lens, onehot.astype(np.float16), lib.DATA_ONEHOT_F16, N, L, rc)
+        assert np.array_equal(f1, f) and np.array_equal(s1.view(np.uint16), both[int(rc)][1].view(np.uint16))
+    bad = onehot.copy()
+    bad[6000, 4 * 33 + 1] = 0.5
+    with pytest.raises(lib.MotifsError) as e:
+        ctx.pwm_scan_both(bank, lens, bad, lib.DATA_ONEHOT_F32, N, L)
+    assert e.value.code == lib.ERR_NOT_ONEHOT
