@@ -299,3 +299,25 @@ def test_host_entry_many_records_equal_device_path(torch_cuda, ctx, pkg):
     with pytest.raises(lib.MotifsError) as e:
         ctx.pwm_scan_both(bank, lens, bad, lib.DATA_ONEHOT_F32, N, L)
     assert e.value.code == lib.ERR_NOT_ONEHOT
+
+
+# ---- the four-reads-per-wave candidate kernel: quads that straddle ordering batches, ragged ends ----
+@pytest.mark.parametrize("N,L,K,lo,hi,batch", [
+    (11, 37, 130, 9, 12, 5),      # quad 1 = reads 4..7 lies across batches 0|1; two chunks, the second with 1 live tile
+    (6, 31, 33, 12, 12, 3),       # every quad across a batch boundary; Lout = 20: a tail tile of 4 windows
+    (9, 20, 8, 16, 16, 2),        # T = 4; Lout = 5: one partial tile only
+    (13, 45, 257, 17, 20, 7),     # T = 5 (two waves per SIMD), three chunks
+    (5, 300, 64, 12, 12, 5000),   # long enough reads for the one-read-per-wave kernel (LDS images too large for quads)
+])
+@pytest.mark.parametrize("rc", [False, True])
+def test_quad_candidate_kernel_edges(torch_cuda, ctx, pkg, N, L, K, lo, hi, batch, rc):
+    sy = pkg.synth
+    codes = sy.gen_codes(N, L, 31000 + N * 7 + K, n_plant=3, k=min(hi, L))
+    codes[N - 1, L - 1] = 4
+    codes[0, 0] = 4
+    pwms, lens = sy.gen_pwm_bank(K, 32000 + K, len_lo=lo, len_hi=hi, alpha=0.4)
+    bank = sy.pad_bank(pwms, lens)
+    h, s = dev_scan_hits(torch_cuda, ctx, pkg, bank, lens, codes, rc, batch)
+    oh, os_ = oracle_hits(pkg, bank, lens, codes, rc, batch)
+    assert len(oh) > 0
+    assert np.array_equal(h, oh) and np.array_equal(s, os_)
