@@ -378,8 +378,9 @@ static __device__ __forceinline__ void wave_lds_sync() {
 // fewer than 64 words, moves to its front), so that a lane writes its candidates through a running pointer: per set bit
 // ctz, or, store, clear - no ring arithmetic and no capacity test (a slab that does not fit whole, > 448 candidates in 64
 // cells, goes in pieces through the checked loop).
-template <typename F>
-static __device__ __forceinline__ void push_and_drain(uint16_t* queue, uint32_t& qlen, const uint32_t (&wd)[4], uint32_t idx, uint32_t ex,
+// NW = 4 words per cell x the cells a lane holds (idx = its first cell)
+template <int NW, typename F>
+static __device__ __forceinline__ void push_and_drain(uint16_t* queue, uint32_t& qlen, const uint32_t (&wd)[NW], uint32_t idx, uint32_t ex,
                                                       uint32_t tot, F&& fn) {
     const int lane = threadIdx.x & 63;
     uint32_t done = 0;
@@ -389,9 +390,9 @@ static __device__ __forceinline__ void push_and_drain(uint16_t* queue, uint32_t&
         if (take == tot) {
             uint16_t* p = queue + qlen + ex;
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
+            for (int q = 0; q < NW; q++) {
                 uint32_t bits = wd[q];
-                const uint32_t pre = (idx << 7) | ((uint32_t)q << 5);
+                const uint32_t pre = ((idx + (uint32_t)(q >> 2)) << 7) | ((uint32_t)(q & 3) << 5);
                 while (bits) {
                     *p++ = (uint16_t)(pre | (uint32_t)__builtin_ctz(bits));
                     bits &= bits - 1;
@@ -400,12 +401,13 @@ static __device__ __forceinline__ void push_and_drain(uint16_t* queue, uint32_t&
         } else {
             uint32_t g = ex;
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
+            for (int q = 0; q < NW; q++) {
                 uint32_t bits = wd[q];
                 while (bits) {
                     const int i = __builtin_ctz(bits);
                     bits &= bits - 1;
-                    if (g >= done && g < done + take) queue[qlen + g - done] = (uint16_t)((idx << 7) | ((uint32_t)q << 5) | (uint32_t)i);
+                    if (g >= done && g < done + take)
+                        queue[qlen + g - done] = (uint16_t)(((idx + (uint32_t)(q >> 2)) << 7) | ((uint32_t)(q & 3) << 5) | (uint32_t)i);
                     g++;
                 }
             }
@@ -452,23 +454,35 @@ static __device__ __forceinline__ RowGeom row_geom(const FillArgs& a, int64_t r)
     return g;
 }
 
-// walk a row's cells and hand every candidate to fn(candidate word, live) 64 at a time
-template <typename F>
+// walk a row's cells and hand every candidate to fn(candidate word, live) 64 at a time.  CPL = cells per lane and step: with
+// two (adjacent ones, so the candidates still come out in cell order) the popcount / wave scan / loop overhead of a step
+// is shared by 128 cells.
+template <int CPL, typename F>
 static __device__ __forceinline__ void for_row_candidates(const RowGeom& g, uint16_t* queue, F&& fn) {
     const int lane = threadIdx.x & 63;
+    constexpr uint32_t STEP = 64 * CPL;
     uint32_t qlen = 0;                                                // wave-uniform
-    uint4 m_next = make_uint4(0u, 0u, 0u, 0u);
-    if ((uint32_t)lane < g.row_cells) m_next = g.cells[lane];
-    for (uint32_t i0 = 0; i0 < g.row_cells; i0 += 64) {               // wave-uniform trip count
-        const uint32_t idx = i0 + lane;
-        const uint4 m = m_next;
-        m_next = make_uint4(0u, 0u, 0u, 0u);
-        if (idx + 64 < g.row_cells) m_next = g.cells[idx + 64];
-        const uint32_t wd[4] = {m.x, m.y, m.z, m.w};
-        const uint32_t pc = __builtin_popcount(m.x) + __builtin_popcount(m.y) + __builtin_popcount(m.z) + __builtin_popcount(m.w);
+    uint4 m_next[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; c++) {
+        m_next[c] = make_uint4(0u, 0u, 0u, 0u);
+        if ((uint32_t)(lane * CPL + c) < g.row_cells) m_next[c] = g.cells[lane * CPL + c];
+    }
+    for (uint32_t i0 = 0; i0 < g.row_cells; i0 += STEP) {             // wave-uniform trip count
+        const uint32_t idx = i0 + lane * CPL;
+        uint32_t wd[4 * CPL];
+        uint32_t pc = 0;
+#pragma unroll
+        for (int c = 0; c < CPL; c++) {
+            const uint4 m = m_next[c];
+            m_next[c] = make_uint4(0u, 0u, 0u, 0u);
+            if (idx + c + STEP < g.row_cells) m_next[c] = g.cells[idx + c + STEP];
+            wd[4 * c + 0] = m.x, wd[4 * c + 1] = m.y, wd[4 * c + 2] = m.z, wd[4 * c + 3] = m.w;
+            pc += __builtin_popcount(m.x) + __builtin_popcount(m.y) + __builtin_popcount(m.z) + __builtin_popcount(m.w);
+        }
         const uint32_t inc = wave_incl_scan(pc);
         const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
-        if (tot) push_and_drain(queue, qlen, wd, idx, inc - pc, tot, fn);
+        if (tot) push_and_drain<4 * CPL>(queue, qlen, wd, idx, inc - pc, tot, fn);
     }
     if (qlen) fn((uint32_t)queue[lane], (uint32_t)lane < qlen);      // the remainder (< 64)
     wave_lds_sync();
@@ -544,7 +558,7 @@ __global__ __launch_bounds__(VF_THREADS) __attribute__((amdgpu_waves_per_eu(LEN 
             dirty = false;
             win_lo += DWIN;
         };
-        for_row_candidates(g, queue, [&](const uint32_t cw, const bool live) {
+        for_row_candidates<(MODE == 2 ? 1 : 2)>(g, queue, [&](const uint32_t cw, const bool live) {
             uint32_t k, nin;
             uint16_t sc;
             bool hit = score_candidate<LEN>(a, g, tb, cw, live, k, nin, sc);
@@ -685,7 +699,7 @@ __global__ __launch_bounds__(VF_THREADS) void emit_records(FillArgs a) {
             }
         } else {
             uint32_t nhit = 0;
-            for_row_candidates(g, queue, [&](const uint32_t cw, const bool live) {
+            for_row_candidates<2>(g, queue, [&](const uint32_t cw, const bool live) {
                 uint32_t k, nin;
                 uint16_t sc;
                 const bool hit = score_candidate<LEN>(a, g, tb, cw, live, k, nin, sc);
