@@ -165,14 +165,15 @@ def main():
         hsc = [torch.empty(cap, dtype=torch.int16, device=dev) for _ in range(2)]
         counts = torch.zeros((2, K), dtype=torch.int64, device=dev)
         sync()
-        return {"n": n, "n0": n0, "codes": dcodes, "need": need, "cap": cap, "hits": hits, "hsc": hsc, "counts": counts}
+        return {"n": n, "n0": n0, "codes": dcodes, "need": need, "cap": cap, "hits": hits, "hsc": hsc, "counts": counts,
+                "ptrs": (dcodes.data_ptr(), [h.data_ptr() for h in hits], [s.data_ptr() for s in hsc], counts.data_ptr())}
 
     def scan_step(sh):
         tot = 0
         if sh["n"]:
             # gpu_scan (_h3_1_alignment.jl:89-99): forward and reverse strand in one call, one host wait
-            tot = sum(ctx.pwm_scan_hits_both_dev(bank, lens, sh["codes"].data_ptr(), sh["n"], L, [h.data_ptr() for h in sh["hits"]],
-                                                 [s.data_ptr() for s in sh["hsc"]], sh["cap"], n0=sh["n0"], counts_ptr=sh["counts"].data_ptr()))
+            pc, ph, ps, pk = sh["ptrs"]
+            tot = sum(ctx.pwm_scan_hits_both_dev(bank, lens, pc, sh["n"], L, ph, ps, sh["cap"], n0=sh["n0"], counts_ptr=pk))
         if world > 1:   # the one real exchange of the scan: the K int64 hit counts of both strands, queued on the
             reducer.sum_i64_(sh["counts"])   # scan's stream behind the kernels that wrote them; the next scan queues behind it
         return tot

@@ -73,7 +73,8 @@ struct FillArgs {
     int row_slots;
     uint32_t* row_excl;           // [nrows] hits before the row inside its block of 1024 rows
     unsigned long long* blk_base; // [ceil(nrows / 1024)] block totals, then records before the block
-    const int64_t* base_in;       // records emitted before this super-batch
+    const int64_t* base_in;       // records emitted before this super-batch (nullptr: none, the first one)
+    int64_t* total_host;          // optional pinned host copy of *total (the host reads it after its stream wait)
     int64_t cap;                  // records the output arrays can hold
     struct {
         uint32_t d, m, s;

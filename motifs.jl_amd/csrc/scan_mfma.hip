@@ -615,7 +615,7 @@ __global__ __launch_bounds__(1024) void row_scan_local(const uint32_t* __restric
     if (tid == 0) blk_total[blockIdx.x] = tot;
 }
 __global__ __launch_bounds__(1024) void row_scan_blocks(unsigned long long* __restrict__ blk, int64_t nblk, const int64_t* __restrict__ base_in,
-                                                        int64_t* __restrict__ total_out) {
+                                                        int64_t* __restrict__ total_out, int64_t* __restrict__ total_host) {
     __shared__ unsigned long long part[1024];
     const int tid = threadIdx.x;
     const int64_t per = (nblk + 1023) / 1024;
@@ -632,13 +632,17 @@ __global__ __launch_bounds__(1024) void row_scan_blocks(unsigned long long* __re
         part[tid] += v;
         __syncthreads();
     }
-    unsigned long long run = part[tid] - s + (unsigned long long)*base_in;
+    const unsigned long long base = base_in ? (unsigned long long)*base_in : 0ull;
+    unsigned long long run = part[tid] - s + base;
     for (int64_t i = lo; i < hi; i++) {
         const unsigned long long v = blk[i];
         blk[i] = run;                                                 // records before this block of rows
         run += v;
     }
-    if (tid == 1023) *total_out = (int64_t)(part[1023] + (unsigned long long)*base_in);
+    if (tid == 1023) {
+        *total_out = (int64_t)(part[1023] + base);
+        if (total_host) *total_host = (int64_t)(part[1023] + base);   // pinned host memory: no copy kernel behind this one
+    }
 }
 
 // staged words -> records.  One wave per row; a row that overflowed its staging slots is re-scored from its cells.
@@ -811,7 +815,7 @@ hipError_t launch_stage_hits(const FillArgs& a, int mode, hipStream_t st) {
 hipError_t launch_row_scan(const FillArgs& a, hipStream_t st) {
     const int64_t nblk = (a.nrows + 1023) / 1024;
     hipLaunchKernelGGL(row_scan_local, dim3((unsigned)nblk), dim3(1024), 0, st, a.row_sum, a.nrows, a.row_excl, a.blk_base);
-    hipLaunchKernelGGL(row_scan_blocks, dim3(1), dim3(1024), 0, st, a.blk_base, nblk, a.base_in, a.total);
+    hipLaunchKernelGGL(row_scan_blocks, dim3(1), dim3(1024), 0, st, a.blk_base, nblk, a.base_in, a.total, a.total_host);
     return hipGetLastError();
 }
 hipError_t launch_emit_records(const FillArgs& a, hipStream_t st) {
