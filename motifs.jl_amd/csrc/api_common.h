@@ -109,16 +109,17 @@ struct KernelTimer {
         (void)hipEventCreate(&e);
         return e;
     }
-    KernelTimer(motifs_ctx* ctx, int s) : c(ctx), slot(s) {
+    bool attached;     // the events are handed to one launch (hipExtLaunchKernelGGL stamps them); nothing is recorded here
+    KernelTimer(motifs_ctx* ctx, int s, bool attach = false) : c(ctx), slot(s), attached(attach) {
         if ((c->timing >> slot) & 1u) {
             e0 = get(c);
             e1 = get(c);
-            (void)hipEventRecord(e0, c->stream);
+            if (!attached) (void)hipEventRecord(e0, c->stream);
         }
     }
     ~KernelTimer() {
         if (e0 && e1) {
-            (void)hipEventRecord(e1, c->stream);
+            if (!attached) (void)hipEventRecord(e1, c->stream);
             c->pending.push_back({slot, e0, e1});
         }
     }

@@ -419,8 +419,8 @@ static int scan_hits_mfma(motifs_ctx* c, const BankSlot& bank, int K, const uint
         if (ns < nb * batch)   // cells of reads the last batch does not have are never written by the scan
             MOTIFS_HIP_CHECK(hipMemsetAsync((char*)c->cnt.p + (size_t)(nb - 1) * per_batch, 0, per_batch, c->stream));
         {
-            KernelTimer t(c, KS_SCAN_COUNT);
-            MOTIFS_HIP_CHECK(launch_cand(a, c->stream));
+            KernelTimer t(c, KS_SCAN_COUNT, true);
+            MOTIFS_HIP_CHECK(launch_cand(a, c->stream, t.e0, t.e1));
         }
         {
             KernelTimer t(c, KS_SCAN_OFFSETS);

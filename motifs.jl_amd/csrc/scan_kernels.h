@@ -104,7 +104,7 @@ struct CandArgs {
     int uniform_eps;          // afrag holds the bank scaled so that the slack is 4.0 for every PWM (cinit unused)
 };
 int cand_tile_group(int lenp);
-hipError_t launch_cand(const CandArgs& a, hipStream_t st);
+hipError_t launch_cand(const CandArgs& a, hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 int stage_row_reads(int nch);                                              // reads per row of cells
 int dense_row_reads(int nch);                                              // the same for the dense tensor (mode 2)
 // candidates -> row counts (mode 0), + staged hits (1), or a17's dense tensor, zeros included (2); + histogram

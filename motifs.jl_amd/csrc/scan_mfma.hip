@@ -18,6 +18,7 @@
 // the reference's record order (5000-read batches, then findall's column-major walk), so record
 // offsets are a plain exclusive scan of popcounts.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include <algorithm>
@@ -716,7 +717,7 @@ __global__ __launch_bounds__(VF_THREADS) void emit_records(FillArgs a) {
 }
 
 template <int T, int PG>
-static hipError_t launch_cand_tp(const CandArgs& a, hipStream_t st) {
+static hipError_t launch_cand_tp(const CandArgs& a, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
     const int ntg = (a.d.used_tiles + PG - 1) / PG;           // tile groups that hold PWMs
     const int tgb = (a.uniform_eps && ntg == 1) ? 1 : 2;
     const size_t lds_q = (size_t)4 * 4 * quad_pitch(a.d.ohlen) * 8;
@@ -728,34 +729,36 @@ static hipError_t launch_cand_tp(const CandArgs& a, hipStream_t st) {
         d.spw = (int)std::max<int64_t>(1, std::min<int64_t>(8, a.d.N / (16 * 8192)));
         const int64_t per_block = (int64_t)(4 / tgb) * 4 * d.spw;
         dim3 grid((unsigned)((d.N + per_block - 1) / per_block), (unsigned)((ntg + tgb - 1) / tgb), 1);
-        if (tgb == 1) hipLaunchKernelGGL((scan_cand_kernel_q<T, PG, 1>), grid, dim3(256), lds_q, st, a.afrag, a.codes, a.cells, d);
-        else hipLaunchKernelGGL((scan_cand_kernel_q<T, PG, 2>), grid, dim3(256), lds_q, st, a.afrag, a.codes, a.cells, d);
+        if (tgb == 1) hipExtLaunchKernelGGL((scan_cand_kernel_q<T, PG, 1>), grid, dim3(256), (uint32_t)lds_q, st, ev0, ev1, 0, a.afrag, a.codes, a.cells, d);
+        else hipExtLaunchKernelGGL((scan_cand_kernel_q<T, PG, 2>), grid, dim3(256), (uint32_t)lds_q, st, ev0, ev1, 0, a.afrag, a.codes, a.cells, d);
         return hipGetLastError();
     }
     const int rpb = a.uniform_eps ? 4 / tgb : 4;
     const int64_t per_block = (int64_t)rpb * a.d.spw;
     dim3 grid((unsigned)((a.d.N + per_block - 1) / per_block), (unsigned)((ntg + tgb - 1) / tgb), 1);
     const size_t lds = (size_t)tgb * rpb * ((a.d.ohlen + 3) & ~3) * 8;
-    if (a.uniform_eps && tgb == 1) hipLaunchKernelGGL((scan_cand_kernel_u<T, PG, 1>), grid, dim3(256), lds, st, a.afrag, a.codes, a.cells, a.d);
-    else if (a.uniform_eps) hipLaunchKernelGGL((scan_cand_kernel_u<T, PG, 2>), grid, dim3(256), lds, st, a.afrag, a.codes, a.cells, a.d);
-    else hipLaunchKernelGGL((scan_cand_kernel<T, PG>), grid, dim3(512), lds, st, a.afrag, a.cinit, a.codes, a.cells, a.d);
+    if (a.uniform_eps && tgb == 1) hipExtLaunchKernelGGL((scan_cand_kernel_u<T, PG, 1>), grid, dim3(256), (uint32_t)lds, st, ev0, ev1, 0, a.afrag, a.codes, a.cells, a.d);
+    else if (a.uniform_eps) hipExtLaunchKernelGGL((scan_cand_kernel_u<T, PG, 2>), grid, dim3(256), (uint32_t)lds, st, ev0, ev1, 0, a.afrag, a.codes, a.cells, a.d);
+    else hipExtLaunchKernelGGL((scan_cand_kernel<T, PG>), grid, dim3(512), (uint32_t)lds, st, ev0, ev1, 0, a.afrag, a.cinit, a.codes, a.cells, a.d);
     return hipGetLastError();
 }
 
 // tiles of 32 PWMs a wave carries: its A fragments are PG * lenp / 4 registers x 4
 int cand_tile_group(int lenp) { return lenp <= 20 ? 4 : lenp <= 32 ? 2 : 1; }
 
-hipError_t launch_cand(const CandArgs& a, hipStream_t st) {
+// ev0 / ev1 (optional): events that take the kernel's own start and stop time stamps (hipExtLaunchKernelGGL): timing the
+// dominant kernel then puts no extra packets on the stream (an event recorded before and after cost ~5 us each per launch)
+hipError_t launch_cand(const CandArgs& a, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
     switch (a.lenp) {
-        case 8: return launch_cand_tp<2, 4>(a, st);
-        case 12: return launch_cand_tp<3, 4>(a, st);
-        case 16: return launch_cand_tp<4, 4>(a, st);
-        case 20: return launch_cand_tp<5, 4>(a, st);
-        case 24: return launch_cand_tp<6, 2>(a, st);
-        case 32: return launch_cand_tp<8, 2>(a, st);
-        case 40: return launch_cand_tp<10, 1>(a, st);
-        case 48: return launch_cand_tp<12, 1>(a, st);
-        case 64: return launch_cand_tp<16, 1>(a, st);
+        case 8: return launch_cand_tp<2, 4>(a, st, ev0, ev1);
+        case 12: return launch_cand_tp<3, 4>(a, st, ev0, ev1);
+        case 16: return launch_cand_tp<4, 4>(a, st, ev0, ev1);
+        case 20: return launch_cand_tp<5, 4>(a, st, ev0, ev1);
+        case 24: return launch_cand_tp<6, 2>(a, st, ev0, ev1);
+        case 32: return launch_cand_tp<8, 2>(a, st, ev0, ev1);
+        case 40: return launch_cand_tp<10, 1>(a, st, ev0, ev1);
+        case 48: return launch_cand_tp<12, 1>(a, st, ev0, ev1);
+        case 64: return launch_cand_tp<16, 1>(a, st, ev0, ev1);
         default: return hipErrorInvalidValue;
     }
 }
