@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MOTIFS_ABI_VERSION 2
+#define MOTIFS_ABI_VERSION 3
 
 enum motifs_status {
     MOTIFS_OK = 0,
@@ -86,6 +86,9 @@ void motifs_ctx_destroy(motifs_ctx* ctx);
  * (e.g. torch.cuda.ExternalStream).  Every `*_dev` entry point and every collective below runs on that stream. */
 int motifs_ctx_set_stream(motifs_ctx* ctx, void* hip_stream);
 int motifs_ctx_get_stream(motifs_ctx* ctx, void** hip_stream_out);
+/* Back to a private non-blocking stream of the library's own (the state a fresh context is in); the stream in use is
+ * drained first.  (ABI 1 spelled this motifs_ctx_set_stream(ctx, NULL); since ABI 2 that binds HIP's null stream.) */
+int motifs_ctx_use_private_stream(motifs_ctx* ctx);
 int motifs_ctx_synchronize(motifs_ctx* ctx);
 /* Upper bound in bytes for the scan's candidate / staging workspace (0 = the default, 8 GiB).  A scan that needs
  * more walks the reads in super-batches of whole ordering batches; the records do not depend on the bound. */
@@ -107,6 +110,18 @@ enum motifs_kernel_slot {
 int motifs_ctx_enable_timing(motifs_ctx* ctx, int on);
 int motifs_ctx_reset_timing(motifs_ctx* ctx);
 int motifs_ctx_kernel_ms(motifs_ctx* ctx, int slot, double* ms, int64_t* launches);
+
+/* ---- device memory for a host without a GPU array package ----------------- */
+
+/* north_star keeps the host in Julia without CUDA.jl / AMDGPU.jl, so a Julia caller has no way of its own to make the
+ * device pointers the `*_dev` entry points take: these five give it one.  Buffers belong to the caller (free them before
+ * motifs_ctx_destroy); upload / download block until the bytes have arrived (the copy is enqueued on the context's
+ * stream, behind whatever the library queued before); memset is enqueued like a kernel. */
+int motifs_dev_alloc(motifs_ctx* ctx, size_t bytes, void** out_dev);
+int motifs_dev_free(motifs_ctx* ctx, void* ptr_dev);
+int motifs_dev_upload(motifs_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int motifs_dev_download(motifs_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+int motifs_dev_memset(motifs_ctx* ctx, void* dst_dev, int byte_value, size_t bytes);
 
 /* ---- sequence encoding (input side of every kernel) ----------------------- */
 
@@ -263,7 +278,9 @@ int motifs_comm_unique_id(uint8_t id[MOTIFS_COMM_ID_BYTES]);
 int motifs_comm_create(motifs_ctx* ctx, const uint8_t id[MOTIFS_COMM_ID_BYTES], int nranks, int rank, motifs_comm** out);
 /* All ranks of a single-process communicator over the devices of ctxs[0..n_dev) (ncclCommInitAll): the form a
  * single Julia process driving the 8 GPUs of a node uses; bracket the per-device collective calls of one step
- * with motifs_comm_group_start / _end (ncclGroupStart / ncclGroupEnd). */
+ * with motifs_comm_group_start / _end (ncclGroupStart / ncclGroupEnd).  Only collectives belong inside a group: RCCL
+ * launches them at the closing _end, so a kernel that reads a sum must be enqueued after it (see
+ * motifs_model_dp_train_step_all). */
 int motifs_comm_create_all(motifs_ctx* const* ctxs, int n_dev, motifs_comm** out);
 void motifs_comm_destroy(motifs_comm* comm);   /* before the context it was made on */
 int motifs_comm_rank(motifs_comm* comm, int* rank, int* nranks);
@@ -271,6 +288,8 @@ int motifs_comm_group_start(void);
 int motifs_comm_group_end(void);
 int motifs_comm_allreduce_sum_f32_dev(motifs_comm* comm, float* buf_dev, int64_t n);
 int motifs_comm_allreduce_sum_i64_dev(motifs_comm* comm, int64_t* buf_dev, int64_t n);
+/* Out of place: recv_dev = sum over ranks of send_dev (send_dev is left as it was). */
+int motifs_comm_allreduce_sum_f32_to_dev(motifs_comm* comm, const float* send_dev, float* recv_dev, int64_t n);
 /* Sum over ranks of the flat gradient motifs_model_loss_grad_dev wrote (nD + nF + nV floats). */
 int motifs_model_allreduce_grad(motifs_model* m, motifs_comm* comm, float* grad_flat_dev);
 /* Sum over ranks of the per-PWM hit counts of a scan (K int64 per strand, n_strands = 1 or 2). */
@@ -281,6 +300,44 @@ int motifs_hist_allreduce(motifs_comm* comm, int64_t* per_pwm_counts_dev, int K,
  * comm == NULL: single device.  grad_flat_dev: nD + nF + nV floats of scratch; loss_dev: n_groups_local floats. */
 int motifs_model_dp_train_step_dev(motifs_model* m, motifs_comm* comm, const uint8_t* codes_dev, int n_groups_local,
                                    int64_t n_groups_total, float* loss_dev, float* grad_flat_dev);
+/* NOT inside motifs_comm_group_start / _end: between them RCCL only records a collective and launches it at the closing
+ * ncclGroupEnd, so the AdaBelief kernel this call enqueues behind its all-reduce would run BEFORE the sum.  The call
+ * refuses (MOTIFS_ERR_INVALID) while a group is open on the calling thread.  One host thread driving several devices
+ * uses motifs_model_dp_train_step_all below, or the three phases of the step themselves:
+ *   motifs_model_dp_grad_dev    this device's summed gradient (zeros for n_groups_local == 0)      -- every device
+ *   motifs_comm_group_start();  motifs_model_allreduce_grad per device;  motifs_comm_group_end();  -- the only grouped part
+ *   motifs_model_dp_update_dev  AdaBelief on gradient / n_groups_total                             -- every device */
+int motifs_model_dp_grad_dev(motifs_model* m, const uint8_t* codes_dev, int n_groups_local, float* loss_dev, float* grad_flat_dev);
+int motifs_model_dp_update_dev(motifs_model* m, const float* grad_flat_dev, int64_t n_groups_total);
+/* One data-parallel optimiser step of n_dev replicas driven by ONE host thread (the communicators of
+ * motifs_comm_create_all): every device's gradient is enqueued, then ncclGroupStart, every device's all-reduce,
+ * ncclGroupEnd, then every device's AdaBelief - in that order on each device's stream.  models / comms / codes_dev /
+ * n_groups_local / loss_dev / grad_dev: arrays of n_dev entries (device d's model lives on comms[d]'s context);
+ * reduced_dev: NULL (sum in place in grad_dev[d]) or n_dev buffers of nD + nF + nV floats that receive the sum while
+ * grad_dev[d] keeps device d's own gradient.  comms == NULL is allowed for n_dev == 1. */
+int motifs_model_dp_train_step_all(motifs_model* const* models, motifs_comm* const* comms, int n_dev,
+                                   const uint8_t* const* codes_dev, const int* n_groups_local, int64_t n_groups_total,
+                                   float* const* loss_dev, float* const* grad_dev, float* const* reduced_dev);
+/* The same step on HOST data (what a Julia process without device pointers calls): `data` holds n_groups * batch_size
+ * reads of `kind` in loader order; mini-batches are dealt to the n_dev replicas in contiguous blocks, uploaded and
+ * encoded by one host thread per device, and the step above runs.  loss_out[n_groups] in the order of `data`;
+ * l1F_out (optional): sum(abs.(prep_syntax_filters(F))) after the step (train.jl:47), from replica 0. */
+int motifs_model_dp_train_step_host(motifs_model* const* models, motifs_comm* const* comms, int n_dev, const void* data,
+                                    int kind, int n_groups, float* loss_out, float* l1F_out);
+/* gpu_scan (_h3_1_alignment.jl:89-99) of a HOST matrix over the n_dev devices of ctxs: reads shard in contiguous
+ * blocks whose edges are multiples of shard_align, device d scans its block with n0 = its first read (one host thread
+ * per device: upload + encode, count, fill, download), the record lists are concatenated in device order into the
+ * caller's buffers and the 2 x K hit histograms are summed (RCCL all-reduce inside one group when comms != NULL, on the
+ * host otherwise).  shard_align = MOTIFS_SCAN_BATCH: the concatenation IS the single-device record list, bit for bit;
+ * shard_align = 1 (or any other value): even blocks, global order = sequence-block-major, and for every (m, n) the
+ * records still come forward strand first, ascending l within a strand - the order the dictionaries of
+ * modify_w_found! (_h3_1_alignment.jl:38-52) depend on.  Other arguments as motifs_pwm_scan_both;
+ * shard_counts (optional): n_dev x 2 record counts per device {forward, reverse}. */
+int motifs_pwm_scan_both_sharded(motifs_ctx* const* ctxs, motifs_comm* const* comms, int n_dev, const uint16_t* pwms_fp16,
+                                 const int64_t* lens, int K, int maxlen, const void* data, int kind, int64_t N, int L,
+                                 int64_t shard_align, motifs_hit* hits_fwd, uint16_t* scores_fwd, motifs_hit* hits_rc,
+                                 uint16_t* scores_rc, int64_t cap, int64_t* n_out2, int64_t* per_pwm_counts2,
+                                 int64_t* shard_counts);
 
 /* ---- either side of the scan ----------------------------------------------------- */
 

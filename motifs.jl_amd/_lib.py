@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MOTIFS_HIP_LIB") or os.path.join(HERE, "libmotifs_hip.so")   # MOTIFS_HIP_LIB: another build (A/B timing)
 
 OK, ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_BUFFER_TOO_SMALL, ERR_NOT_ONEHOT, ERR_NONFINITE, ERR_UNSUPPORTED, ERR_COMM = range(9)
-ABI_VERSION = 2
+ABI_VERSION = 3
 COMM_ID_BYTES = 128
 DATA_CODES_U8, DATA_ONEHOT_F32, DATA_ONEHOT_F16 = 0, 1, 2
 KS_ENCODE, KS_SCAN_DENSE, KS_SCAN_COUNT, KS_SCAN_OFFSETS, KS_SCAN_FILL, KS_TRAIN_STEP = range(6)
@@ -54,6 +54,12 @@ SIGNATURES = {
     "motifs_ctx_destroy": (None, [_p]),
     "motifs_ctx_set_stream": (_int, [_p, _p]),
     "motifs_ctx_get_stream": (_int, [_p, C.POINTER(_p)]),
+    "motifs_ctx_use_private_stream": (_int, [_p]),
+    "motifs_dev_alloc": (_int, [_p, C.c_size_t, C.POINTER(_p)]),
+    "motifs_dev_free": (_int, [_p, _p]),
+    "motifs_dev_upload": (_int, [_p, _p, _p, C.c_size_t]),
+    "motifs_dev_download": (_int, [_p, _p, _p, C.c_size_t]),
+    "motifs_dev_memset": (_int, [_p, _p, _int, C.c_size_t]),
     "motifs_ctx_set_workspace_limit": (_int, [_p, C.c_size_t]),
     "motifs_ctx_synchronize": (_int, [_p]),
     "motifs_ctx_enable_timing": (_int, [_p, _int]),
@@ -91,7 +97,18 @@ SIGNATURES = {
     "motifs_comm_group_end": (_int, []),
     "motifs_comm_allreduce_sum_f32_dev": (_int, [_p, _p, _i64]),
     "motifs_comm_allreduce_sum_i64_dev": (_int, [_p, _p, _i64]),
+    "motifs_comm_allreduce_sum_f32_to_dev": (_int, [_p, _p, _p, _i64]),
     "motifs_model_allreduce_grad": (_int, [_p, _p, _p]),
+    "motifs_model_dp_grad_dev": (_int, [_p, _p, _int, _p, _p]),
+    "motifs_model_dp_update_dev": (_int, [_p, _p, _i64]),
+    "motifs_model_dp_train_step_all": (_int, [C.POINTER(_p), C.POINTER(_p), _int, C.POINTER(_p), C.POINTER(_int), _i64,
+                                              C.POINTER(_p), C.POINTER(_p), C.POINTER(_p)]),
+    "motifs_model_dp_train_step_host": (_int, [C.POINTER(_p), C.POINTER(_p), _int, _p, _int, _int, _p, C.POINTER(C.c_float)]),
+    "motifs_pwm_scan_both_sharded": (
+        _int,
+        [C.POINTER(_p), C.POINTER(_p), _int, _p, _p, _int, _int, _p, _int, _i64, _int, _i64, _p, _p, _p, _p, _i64,
+         C.POINTER(_i64), _p, _p],
+    ),
     "motifs_hist_allreduce": (_int, [_p, _p, _int, _int]),
     "motifs_model_dp_train_step_dev": (_int, [_p, _p, _p, _int, _i64, _p, _p]),
     "motifs_model_retrieve_codes": (_int, [_p, _p, _int, _i64, _p, _i64, C.POINTER(_i64)]),
@@ -141,6 +158,9 @@ def lib():
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
+        got = handle.motifs_abi_version()
+        if got != ABI_VERSION:      # e.g. NULL in motifs_ctx_set_stream changed meaning between ABI 1 and 2
+            raise MotifsError(ERR_INVALID, f"{LIB_PATH} has ABI {got}, this binding is written for ABI {ABI_VERSION}: rebuild the library")
         _lib = handle
     return _lib
 
@@ -190,6 +210,31 @@ class Context:
         out = _p()
         check(lib().motifs_ctx_get_stream(self._h, C.byref(out)))
         return out.value or 0
+
+    def use_private_stream(self):
+        """Back to a private non-blocking stream of the library's own (the state of a fresh context)."""
+        check(lib().motifs_ctx_use_private_stream(self._h))
+
+    # ---- device memory (for hosts without a GPU array package; tests use it next to torch's allocator) ----
+    def dev_alloc(self, nbytes):
+        out = _p()
+        check(lib().motifs_dev_alloc(self._h, int(nbytes), C.byref(out)))
+        return out.value
+
+    def dev_free(self, ptr):
+        check(lib().motifs_dev_free(self._h, _p(ptr)))
+
+    def dev_upload(self, dst_ptr, arr):
+        arr = np.ascontiguousarray(arr)
+        check(lib().motifs_dev_upload(self._h, _p(dst_ptr), _np_ptr(arr), arr.nbytes))
+
+    def dev_download(self, src_ptr, shape, dtype):
+        out = np.empty(shape, dtype=dtype)
+        check(lib().motifs_dev_download(self._h, _np_ptr(out), _p(src_ptr), out.nbytes))
+        return out
+
+    def dev_memset(self, ptr, byte_value, nbytes):
+        check(lib().motifs_dev_memset(self._h, _p(ptr), int(byte_value), int(nbytes)))
 
     def set_workspace_limit(self, nbytes):
         """Bound of the scan's candidate/staging workspace (0 = default 8 GiB); larger scans run in super-batches."""
@@ -446,6 +491,14 @@ class Model:
         check(lib().motifs_model_dp_train_step_dev(self._h, comm._h if comm is not None else None, _p(codes_ptr), int(n_groups_local),
                                                    int(n_groups_total), _p(loss_ptr), _p(grad_ptr)))
 
+    def dp_grad_dev(self, codes_ptr, n_groups_local, loss_ptr, grad_ptr):
+        """Phase 1 of a data-parallel step: this device's summed gradient (zeros for no mini-batch)."""
+        check(lib().motifs_model_dp_grad_dev(self._h, _p(codes_ptr), int(n_groups_local), _p(loss_ptr), _p(grad_ptr)))
+
+    def dp_update_dev(self, grad_ptr, n_groups_total):
+        """Phase 3: AdaBelief on gradient / n_groups_total."""
+        check(lib().motifs_model_dp_update_dev(self._h, _p(grad_ptr), int(n_groups_total)))
+
     def allreduce_grad(self, comm, grad_ptr):
         check(lib().motifs_model_allreduce_grad(self._h, comm._h, _p(grad_ptr)))
 
@@ -475,13 +528,36 @@ class Model:
 class Comm:
     """Owns a motifs_comm: one rank of an RCCL communicator on a context's device (collectives run on its stream)."""
 
-    def __init__(self, ctx, uid, nranks, rank):
+    def __init__(self, ctx, uid, nranks, rank, _handle=None):
         self.ctx = ctx
         self._h = _p()
-        uid = np.frombuffer(bytes(uid), dtype=np.uint8)
-        assert uid.size == COMM_ID_BYTES
-        check(lib().motifs_comm_create(ctx._h, _np_ptr(uid), int(nranks), int(rank), C.byref(self._h)))
+        if _handle is not None:          # a rank of Comm.create_all
+            self._h = _p(_handle)
+        else:
+            uid = np.frombuffer(bytes(uid), dtype=np.uint8)
+            assert uid.size == COMM_ID_BYTES
+            check(lib().motifs_comm_create(ctx._h, _np_ptr(uid), int(nranks), int(rank), C.byref(self._h)))
         self.rank, self.nranks = int(rank), int(nranks)
+
+    @staticmethod
+    def create_all(ctxs):
+        """ncclCommInitAll: every rank of a single-process communicator over the devices of `ctxs` (one Comm per context)."""
+        n = len(ctxs)
+        hs = (_p * n)(*[c._h for c in ctxs])
+        out = (_p * n)()
+        check(lib().motifs_comm_create_all(hs, n, out))
+        return [Comm(ctxs[i], None, n, i, _handle=out[i]) for i in range(n)]
+
+    @staticmethod
+    def group_start():
+        check(lib().motifs_comm_group_start())
+
+    @staticmethod
+    def group_end():
+        check(lib().motifs_comm_group_end())
+
+    def allreduce_sum_f32_to(self, send_ptr, recv_ptr, n):
+        check(lib().motifs_comm_allreduce_sum_f32_to_dev(self._h, _p(send_ptr), _p(recv_ptr), int(n)))
 
     @staticmethod
     def unique_id():
@@ -508,3 +584,58 @@ class Comm:
             self.close()
         except Exception:
             pass
+
+
+def _parr(ptrs, n):
+    """n pointers (ints / None / objects with ._h) as a C array of void*."""
+    vals = []
+    for x in ptrs:
+        x = getattr(x, "_h", x)
+        vals.append(x.value if isinstance(x, _p) else (x or None))
+    assert len(vals) == n
+    return (_p * n)(*vals)
+
+
+def dp_train_step_all(models, comms, codes_ptrs, n_groups_local, n_groups_total, loss_ptrs, grad_ptrs, reduced_ptrs=None):
+    """One data-parallel optimiser step of len(models) replicas driven by this host thread: every device's gradient,
+    then the grouped all-reduces, then every device's AdaBelief (motifs_model_dp_train_step_all)."""
+    n = len(models)
+    check(lib().motifs_model_dp_train_step_all(
+        _parr(models, n), _parr(comms, n) if comms is not None else None, n, _parr(codes_ptrs, n),
+        (_int * n)(*[int(g) for g in n_groups_local]), int(n_groups_total), _parr(loss_ptrs, n), _parr(grad_ptrs, n),
+        _parr(reduced_ptrs, n) if reduced_ptrs is not None else None))
+
+
+def dp_train_step_host(models, comms, data, kind, n_groups, want_l1=True):
+    """The same step on a host matrix of `kind` holding n_groups * batch_size reads; returns (losses, l1F)."""
+    n = len(models)
+    data = np.ascontiguousarray(data)
+    loss = np.zeros(n_groups, np.float32)
+    l1 = C.c_float(0)
+    check(lib().motifs_model_dp_train_step_host(_parr(models, n), _parr(comms, n) if comms is not None else None, n, _np_ptr(data),
+                                                int(kind), int(n_groups), _np_ptr(loss), C.byref(l1) if want_l1 else None))
+    return loss, l1.value
+
+
+def pwm_scan_both_sharded(ctxs, comms, pwms, lens, data, kind, N, L, shard_align=SCAN_BATCH, cap=None):
+    """gpu_scan of a host matrix over the devices of `ctxs` (one process, one host thread per device).  Returns
+    ((found_fwd, score_fwd), (found_rc, score_rc), counts[2, K], shard_counts[n_dev, 2])."""
+    n = len(ctxs)
+    pwms, lens, K, maxlen = _bank(pwms, lens)
+    data = np.ascontiguousarray(data)
+    n_out = (_i64 * 2)(0, 0)
+    counts = np.zeros((2, K), dtype=np.int64)
+    shard = np.zeros((n, 2), dtype=np.int64)
+    cs, cm = _parr(ctxs, n), (_parr(comms, n) if comms is not None else None)
+    if cap is None:
+        check(lib().motifs_pwm_scan_both_sharded(cs, cm, n, _np_ptr(pwms), _np_ptr(lens), K, maxlen, _np_ptr(data), int(kind), int(N), int(L),
+                                                 int(shard_align), None, None, None, None, 0, n_out, None, None))
+        cap = max(n_out[0], n_out[1])
+    hits = [np.zeros(max(cap, 1), dtype=HIT_DTYPE) for _ in range(2)]
+    scores = [np.zeros(max(cap, 1), dtype=np.uint16) for _ in range(2)]
+    check(lib().motifs_pwm_scan_both_sharded(cs, cm, n, _np_ptr(pwms), _np_ptr(lens), K, maxlen, _np_ptr(data), int(kind), int(N), int(L),
+                                             int(shard_align), _np_ptr(hits[0]) if cap else None, _np_ptr(scores[0]) if cap else None,
+                                             _np_ptr(hits[1]) if cap else None, _np_ptr(scores[1]) if cap else None, int(cap), n_out,
+                                             _np_ptr(counts), _np_ptr(shard)))
+    fwd, rcs = [(hits[s][: n_out[s]], scores[s][: n_out[s]].view(np.float16)) for s in range(2)]
+    return fwd, rcs, counts, shard

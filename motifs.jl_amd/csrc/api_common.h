@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/motifs_hip.h"
@@ -75,6 +76,7 @@ struct motifs_ctx {
     // scan workspaces
     motifs::DevBuf tab, lim, cnt, off, tilesum, small, codes, hits_tmp, scores_tmp, pwmcnt, data_tmp, afrag, cinit;
     motifs::DevBuf staging, rowx;   // matrix-core scan: staged hit words, per-row offsets
+    motifs::DevBuf dp_scratch;      // host-buffer data-parallel step: flat gradient + losses
     motifs::BankSlot bank_slot[2];  // [rc]
     void* pinned = nullptr;  // small pinned host block for totals / flags
     // pinned staging of the host-buffer entries (motifs_pwm_scan*): code rows on the way up, record chunks on the way down
@@ -110,6 +112,7 @@ struct KernelTimer {
         return e;
     }
     bool attached;     // the events are handed to one launch (hipExtLaunchKernelGGL stamps them); nothing is recorded here
+    bool stamped = true;   // attached form: cleared by the caller when the launch that should stamp the events failed
     KernelTimer(motifs_ctx* ctx, int s, bool attach = false) : c(ctx), slot(s), attached(attach) {
         if ((c->timing >> slot) & 1u) {
             e0 = get(c);
@@ -120,10 +123,43 @@ struct KernelTimer {
     ~KernelTimer() {
         if (e0 && e1) {
             if (!attached) (void)hipEventRecord(e1, c->stream);
-            c->pending.push_back({slot, e0, e1});
+            if (stamped) c->pending.push_back({slot, e0, e1});
+            else c->free_events.push_back(e0), c->free_events.push_back(e1);   // never recorded: nothing to resolve
         }
     }
 };
+
+// shared host-side helpers of the host-buffer entries (scan_api.hip)
+int upload_and_encode(motifs_ctx* c, const void* data, int kind, int64_t N, int L);   // host matrix of `kind` -> c->codes
+int download_chunked(motifs_ctx* c, void* dst, const void* src_dev, size_t bytes);    // device bytes -> pageable host memory
+const char* last_error_text();                                                        // this thread's motifs_last_error()
+// ncclGroupStart / ncclGroupEnd nesting depth on this thread (comm_rccl.hip): inside an open group RCCL only records a
+// collective and launches it at the closing ncclGroupEnd, so nothing that consumes its result may be enqueued before that
+int comm_group_depth();
+motifs_ctx* comm_ctx(motifs_comm* c);     // the context a communicator rank was made on (nullptr for nullptr)
+
+// run fn(d) for d in [0, n): on the calling thread for n == 1, else one host thread per device (each binds its own device);
+// returns the first non-zero status and leaves that thread's error text as this thread's
+template <typename F>
+inline int for_each_device(int n, F&& fn) {
+    if (n == 1) return fn(0);
+    std::vector<int> rc(n, 0);
+    std::vector<std::string> why(n);
+    std::vector<std::thread> th;
+    th.reserve(n);
+    for (int d = 0; d < n; d++)
+        th.emplace_back([&, d]() {
+            rc[d] = fn(d);
+            if (rc[d]) why[d] = last_error_text();
+        });
+    for (auto& t : th) t.join();
+    for (int d = 0; d < n; d++)
+        if (rc[d]) {
+            set_error("device slot %d: %s", d, why[d].c_str());
+            return rc[d];
+        }
+    return MOTIFS_OK;
+}
 
 inline void resolve_timing(motifs_ctx* c) {
     for (auto& sp : c->pending) {

@@ -11,6 +11,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "api_common.h"
@@ -352,6 +354,10 @@ static int enqueue_loss_grad(motifs_model* m, hipStream_t st, const uint8_t* cod
                              int keep_intermediates) {
     Engine& e = m->eng;
     e.st = st;
+    struct RestoreStream {          // the engine goes back to the context's stream on every way out of this function
+        motifs_model* m;
+        ~RestoreStream() { m->eng.st = m->ctx->stream; }
+    } restore{m};
     e.reset();
     e.recording = grad_flat_dev != nullptr;
     e.keep_named = keep_intermediates != 0;
@@ -371,7 +377,6 @@ static int enqueue_loss_grad(motifs_model* m, hipStream_t st, const uint8_t* cod
     }
     if (loss_dev) MOTIFS_HIP_CHECK(hipMemcpyAsync(loss_dev, Lv->v, (size_t)n_groups * 4, hipMemcpyDeviceToDevice, e.st));
     if (grad_flat_dev) MOTIFS_HIP_CHECK(hipMemcpyAsync(grad_flat_dev, m->grads, m->nP * 4, hipMemcpyDeviceToDevice, e.st));
-    e.st = m->ctx->stream;
     MOTIFS_HIP_CHECK(hipGetLastError());
     return MOTIFS_OK;
 }
@@ -564,8 +569,8 @@ int motifs_model_loss_grad_dev(motifs_model* m, const uint8_t* codes_dev, int n_
         if (rc != MOTIFS_OK || ce != hipSuccess || !graph) {
             if (graph) (void)hipGraphDestroy(graph);
             (void)hipGetLastError();
+            if (rc != MOTIFS_OK) return rc;   // the step itself failed (arena exhausted, a HIP error): not a capture problem, graphs stay on
             m->use_graphs = false;     // something in the step cannot be captured on this runtime: stay eager from here on
-            if (rc != MOTIFS_OK) return rc;
             return enqueue_loss_grad(m, m->ctx->stream, codes_dev, n_groups, loss_dev, grad_flat_dev, 0);
         }
         const hipError_t ie = hipGraphInstantiate(&sg->exec, graph, nullptr, nullptr, 0);
@@ -608,10 +613,35 @@ int motifs_model_allreduce_grad(motifs_model* m, motifs_comm* comm, float* grad_
     return motifs_comm_allreduce_sum_f32_dev(comm, grad_flat_dev, (int64_t)m->nP);
 }
 
-// train.jl:42-46 for a shard: local summed gradient -> sum over ranks -> AdaBelief on the mean over all mini-batches.
-// Every rank applies the same update to the same parameters, so the replicas never diverge.  A rank without
+// train.jl:42-46 for a shard, in three phases: local summed gradient -> sum over ranks -> AdaBelief on the mean over all
+// mini-batches.  Every rank applies the same update to the same parameters, so the replicas never diverge.  A rank without
 // mini-batches (more ranks than mini-batches, or the tail of an uneven split) contributes zeros and still joins
 // the exchange: skipping it would leave the other ranks waiting in the all-reduce.
+int motifs_model_dp_grad_dev(motifs_model* m, const uint8_t* codes_dev, int n_groups_local, float* loss_dev, float* grad_flat_dev) {
+    int r = check_model(m, "motifs_model_dp_grad_dev");
+    if (r) return r;
+    if (!grad_flat_dev || n_groups_local < 0 || (n_groups_local > 0 && !codes_dev)) {
+        set_error("motifs_model_dp_grad_dev: bad argument (local=%d)", n_groups_local);
+        return MOTIFS_ERR_INVALID;
+    }
+    MOTIFS_HIP_CHECK(hipSetDevice(m->ctx->device));
+    if (n_groups_local > 0) return motifs_model_loss_grad_dev(m, codes_dev, n_groups_local, loss_dev, grad_flat_dev, 0);
+    MOTIFS_HIP_CHECK(hipMemsetAsync(grad_flat_dev, 0, m->nP * 4, m->ctx->stream));
+    return MOTIFS_OK;
+}
+
+int motifs_model_dp_update_dev(motifs_model* m, const float* grad_flat_dev, int64_t n_groups_total) {
+    int r = check_model(m, "motifs_model_dp_update_dev");
+    if (r) return r;
+    if (!grad_flat_dev || n_groups_total < 1) {
+        set_error("motifs_model_dp_update_dev: bad argument (total=%lld)", (long long)n_groups_total);
+        return MOTIFS_ERR_INVALID;
+    }
+    return motifs_model_adabelief_dev(m, grad_flat_dev, (float)(1.0 / (double)n_groups_total));
+}
+
+// One rank of a one-rank-per-process (or per-thread) communicator.  Inside an open ncclGroupStart/End RCCL defers the
+// all-reduce to the group's end, and the AdaBelief kernel below would be enqueued - and run - before it: refused.
 int motifs_model_dp_train_step_dev(motifs_model* m, motifs_comm* comm, const uint8_t* codes_dev, int n_groups_local,
                                    int64_t n_groups_total, float* loss_dev, float* grad_flat_dev) {
     int r = check_model(m, "motifs_model_dp_train_step_dev");
@@ -621,18 +651,139 @@ int motifs_model_dp_train_step_dev(motifs_model* m, motifs_comm* comm, const uin
         set_error("motifs_model_dp_train_step_dev: bad argument (local=%d total=%lld)", n_groups_local, (long long)n_groups_total);
         return MOTIFS_ERR_INVALID;
     }
-    MOTIFS_HIP_CHECK(hipSetDevice(m->ctx->device));
-    if (n_groups_local > 0) {
-        r = motifs_model_loss_grad_dev(m, codes_dev, n_groups_local, loss_dev, grad_flat_dev, 0);
-        if (r) return r;
-    } else {
-        MOTIFS_HIP_CHECK(hipMemsetAsync(grad_flat_dev, 0, m->nP * 4, m->ctx->stream));
+    if (comm && comm_group_depth() > 0) {
+        set_error("motifs_model_dp_train_step_dev called between motifs_comm_group_start and _end: the all-reduce would only be launched "
+                  "at the group's end, after the optimiser kernel; use motifs_model_dp_train_step_all, or group only motifs_model_allreduce_grad");
+        return MOTIFS_ERR_INVALID;
     }
+    r = motifs_model_dp_grad_dev(m, codes_dev, n_groups_local, loss_dev, grad_flat_dev);
+    if (r) return r;
     if (comm) {
         r = motifs_model_allreduce_grad(m, comm, grad_flat_dev);
         if (r) return r;
     }
-    return motifs_model_adabelief_dev(m, grad_flat_dev, (float)(1.0 / (double)n_groups_total));
+    return motifs_model_dp_update_dev(m, grad_flat_dev, n_groups_total);
+}
+
+// One host thread, n_dev replicas (motifs_comm_create_all): gradients first, then the grouped all-reduces, then the updates.
+int motifs_model_dp_train_step_all(motifs_model* const* models, motifs_comm* const* comms, int n_dev, const uint8_t* const* codes_dev,
+                                   const int* n_groups_local, int64_t n_groups_total, float* const* loss_dev, float* const* grad_dev,
+                                   float* const* reduced_dev) {
+    if (!models || n_dev < 1 || !codes_dev || !n_groups_local || !loss_dev || !grad_dev || n_groups_total < 1 || (!comms && n_dev != 1)) {
+        set_error("motifs_model_dp_train_step_all: bad argument (n_dev=%d total=%lld)", n_dev, (long long)n_groups_total);
+        return MOTIFS_ERR_INVALID;
+    }
+    int64_t local_sum = 0;
+    for (int d = 0; d < n_dev; d++) {
+        int r = check_model(models[d], "motifs_model_dp_train_step_all");
+        if (r) return r;
+        if (!grad_dev[d] || n_groups_local[d] < 0 || (reduced_dev && !reduced_dev[d]) || models[d]->nP != models[0]->nP ||
+            (comms && comm_ctx(comms[d]) != models[d]->ctx)) {
+            set_error("motifs_model_dp_train_step_all: slot %d: null buffer, negative count, a replica of another shape, or a communicator "
+                      "that was not made on the model's context", d);
+            return MOTIFS_ERR_INVALID;
+        }
+        for (int j = 0; j < d; j++)
+            if (models[j]->ctx == models[d]->ctx) {
+                set_error("motifs_model_dp_train_step_all: slots %d and %d share a context (one replica per device)", j, d);
+                return MOTIFS_ERR_INVALID;
+            }
+        local_sum += n_groups_local[d];
+    }
+    if (local_sum > n_groups_total) {
+        set_error("motifs_model_dp_train_step_all: %lld local mini-batches > total %lld", (long long)local_sum, (long long)n_groups_total);
+        return MOTIFS_ERR_INVALID;
+    }
+    if (comm_group_depth() > 0) {
+        set_error("motifs_model_dp_train_step_all opens its own group around the all-reduces: call it outside motifs_comm_group_start/_end");
+        return MOTIFS_ERR_INVALID;
+    }
+    // phase 1: every device's gradient (the launches of one device are enqueued by one host thread)
+    int r = for_each_device(n_dev, [&](int d) {
+        return motifs_model_dp_grad_dev(models[d], codes_dev[d], n_groups_local[d], loss_dev[d], grad_dev[d]);
+    });
+    if (r) return r;
+    // phase 2: the sums - the only part inside the group; RCCL launches them at the group's end, each on its device's stream
+    // behind that device's backward kernels
+    if (comms) {
+        r = motifs_comm_group_start();
+        if (r) return r;
+        int rr = MOTIFS_OK;
+        for (int d = 0; d < n_dev && rr == MOTIFS_OK; d++)
+            rr = reduced_dev ? motifs_comm_allreduce_sum_f32_to_dev(comms[d], grad_dev[d], reduced_dev[d], (int64_t)models[d]->nP)
+                             : motifs_model_allreduce_grad(models[d], comms[d], grad_dev[d]);
+        std::string why = rr ? last_error_text() : "";
+        r = motifs_comm_group_end();                     // the group is closed whatever happened inside it
+        if (rr) {
+            set_error("%s", why.c_str());
+            return rr;
+        }
+        if (r) return r;
+    } else if (reduced_dev) {
+        MOTIFS_HIP_CHECK(hipSetDevice(models[0]->ctx->device));
+        MOTIFS_HIP_CHECK(hipMemcpyAsync(reduced_dev[0], grad_dev[0], models[0]->nP * 4, hipMemcpyDeviceToDevice, models[0]->ctx->stream));
+    }
+    // phase 3: the identical update on every replica, enqueued behind its device's all-reduce
+    for (int d = 0; d < n_dev; d++) {
+        r = motifs_model_dp_update_dev(models[d], reduced_dev ? reduced_dev[d] : grad_dev[d], n_groups_total);
+        if (r) return r;
+    }
+    return MOTIFS_OK;
+}
+
+// The step above for a host that holds no device pointers: mini-batches dealt to the replicas in contiguous blocks.
+int motifs_model_dp_train_step_host(motifs_model* const* models, motifs_comm* const* comms, int n_dev, const void* data, int kind,
+                                    int n_groups, float* loss_out, float* l1F_out) {
+    if (!models || n_dev < 1 || !data || n_groups < 1 || kind < 0 || kind > 2 || (!comms && n_dev != 1)) {
+        set_error("motifs_model_dp_train_step_host: bad argument (n_dev=%d n_groups=%d kind=%d)", n_dev, n_groups, kind);
+        return MOTIFS_ERR_INVALID;
+    }
+    for (int d = 0; d < n_dev; d++) {
+        int r = check_model(models[d], "motifs_model_dp_train_step_host");
+        if (r) return r;
+        if (models[d]->B != models[0]->B || models[d]->L != models[0]->L || models[d]->nP != models[0]->nP) {
+            set_error("motifs_model_dp_train_step_host: replica %d has another shape than replica 0", d);
+            return MOTIFS_ERR_INVALID;
+        }
+    }
+    const int B = models[0]->B, L = models[0]->L;
+    const size_t nP = models[0]->nP;
+    const size_t elt = kind == MOTIFS_DATA_ONEHOT_F32 ? 16 : kind == MOTIFS_DATA_ONEHOT_F16 ? 8 : 1;
+    std::vector<int> g_lo(n_dev + 1, 0), g_n(n_dev, 0);
+    for (int d = 0; d < n_dev; d++) {                      // contiguous blocks, sizes differ by at most one mini-batch
+        g_n[d] = n_groups / n_dev + (d < n_groups % n_dev ? 1 : 0);
+        g_lo[d + 1] = g_lo[d] + g_n[d];
+    }
+    std::vector<const uint8_t*> codes(n_dev, nullptr);
+    std::vector<float*> loss(n_dev, nullptr), grad(n_dev, nullptr);
+    int r = for_each_device(n_dev, [&](int d) -> int {
+        motifs_ctx* c = models[d]->ctx;
+        MOTIFS_HIP_CHECK(hipSetDevice(c->device));
+        if (g_n[d] > 0) {
+            const int rr = upload_and_encode(c, (const char*)data + (size_t)g_lo[d] * B * L * elt, kind, (int64_t)g_n[d] * B, L);
+            if (rr) return rr;
+            codes[d] = (const uint8_t*)c->codes.p;
+        }
+        MOTIFS_HIP_CHECK(c->dp_scratch.reserve(nP * 4 + (size_t)std::max(g_n[d], 1) * 4 + 64));
+        grad[d] = (float*)c->dp_scratch.p;
+        loss[d] = grad[d] + nP;
+        return MOTIFS_OK;
+    });
+    if (r) return r;
+    r = motifs_model_dp_train_step_all(models, comms, n_dev, codes.data(), g_n.data(), n_groups, loss.data(), grad.data(), nullptr);
+    if (r) return r;
+    for (int d = 0; d < n_dev; d++) {
+        motifs_ctx* c = models[d]->ctx;
+        MOTIFS_HIP_CHECK(hipSetDevice(c->device));
+        if (loss_out && g_n[d] > 0)
+            MOTIFS_HIP_CHECK(hipMemcpyAsync(loss_out + g_lo[d], loss[d], (size_t)g_n[d] * 4, hipMemcpyDeviceToHost, c->stream));
+    }
+    for (int d = 0; d < n_dev; d++) {
+        MOTIFS_HIP_CHECK(hipSetDevice(models[d]->ctx->device));
+        MOTIFS_HIP_CHECK(hipStreamSynchronize(models[d]->ctx->stream));
+    }
+    if (l1F_out) return motifs_model_l1_syntax(models[0], l1F_out);
+    return MOTIFS_OK;
 }
 
 // sum(abs.(prep_syntax_filters(cdl.F))) (train.jl:47): the early-stop statistic

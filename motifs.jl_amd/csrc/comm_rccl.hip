@@ -5,7 +5,7 @@
 // blocks, the parameters and the PWM bank are replicated, and per optimiser step ONE sum of the flat gradient
 // [dD | dF | dvecs] (124 833 floats at BASELINE configs[1]) crosses the links, per scan ONE sum of K int64 hit
 // counts per strand.  Both are far below the size at which xGMI's per-link rate matters (0.5 MB = a few
-// microseconds of wire time on a 7 x ~153 GB/s fabric): they are latency-bound, so each is a single in-place
+// microseconds of wire time on a 7 x ~153 GB/s fabric): they are latency-bound, so each is a single
 // ncclAllReduce on the context's stream, queued directly behind the kernel that produced the operand — no bucketing,
 // no second stream, no host wait.
 //
@@ -94,8 +94,8 @@ int nccl_check(ncclResult_t e, const char* what) {
     return MOTIFS_ERR_COMM;
 }
 
-int allreduce(motifs_comm* c, void* buf, int64_t n, ncclDataType_t ty, const char* who) {
-    if (!c || !c->ctx || n < 0 || (n > 0 && !buf)) {
+int allreduce(motifs_comm* c, const void* send, void* recv, int64_t n, ncclDataType_t ty, const char* who) {
+    if (!c || !c->ctx || n < 0 || (n > 0 && (!send || !recv))) {
         set_error("%s: bad argument", who);
         return MOTIFS_ERR_INVALID;
     }
@@ -103,10 +103,15 @@ int allreduce(motifs_comm* c, void* buf, int64_t n, ncclDataType_t ty, const cha
     int r = need_rccl(who);
     if (r) return r;
     MOTIFS_HIP_CHECK(hipSetDevice(c->ctx->device));
-    return nccl_check(g_rccl.AllReduce(buf, buf, (size_t)n, ty, ncclSum, c->comm, c->ctx->stream), who);
+    return nccl_check(g_rccl.AllReduce(send, recv, (size_t)n, ty, ncclSum, c->comm, c->ctx->stream), who);
 }
 
+thread_local int g_group_depth = 0;     // ncclGroupStart / ncclGroupEnd are per thread
+
 }  // namespace
+
+int motifs::comm_group_depth() { return g_group_depth; }
+motifs_ctx* motifs::comm_ctx(motifs_comm* c) { return c ? c->ctx : nullptr; }
 
 extern "C" {
 
@@ -200,20 +205,33 @@ int motifs_comm_rank(motifs_comm* c, int* rank, int* nranks) {
 
 int motifs_comm_group_start(void) {
     int r = need_rccl("motifs_comm_group_start");
-    return r ? r : nccl_check(g_rccl.GroupStart(), "ncclGroupStart");
+    if (r) return r;
+    r = nccl_check(g_rccl.GroupStart(), "ncclGroupStart");
+    if (r == MOTIFS_OK) g_group_depth++;
+    return r;
 }
 
 int motifs_comm_group_end(void) {
     int r = need_rccl("motifs_comm_group_end");
-    return r ? r : nccl_check(g_rccl.GroupEnd(), "ncclGroupEnd");
+    if (r) return r;
+    if (g_group_depth <= 0) {
+        set_error("motifs_comm_group_end without motifs_comm_group_start on this thread");
+        return MOTIFS_ERR_INVALID;
+    }
+    g_group_depth--;
+    return nccl_check(g_rccl.GroupEnd(), "ncclGroupEnd");
 }
 
 int motifs_comm_allreduce_sum_f32_dev(motifs_comm* c, float* buf_dev, int64_t n) {
-    return allreduce(c, buf_dev, n, ncclFloat32, "motifs_comm_allreduce_sum_f32_dev");
+    return allreduce(c, buf_dev, buf_dev, n, ncclFloat32, "motifs_comm_allreduce_sum_f32_dev");
 }
 
 int motifs_comm_allreduce_sum_i64_dev(motifs_comm* c, int64_t* buf_dev, int64_t n) {
-    return allreduce(c, buf_dev, n, ncclInt64, "motifs_comm_allreduce_sum_i64_dev");
+    return allreduce(c, buf_dev, buf_dev, n, ncclInt64, "motifs_comm_allreduce_sum_i64_dev");
+}
+
+int motifs_comm_allreduce_sum_f32_to_dev(motifs_comm* c, const float* send_dev, float* recv_dev, int64_t n) {
+    return allreduce(c, send_dev, recv_dev, n, ncclFloat32, "motifs_comm_allreduce_sum_f32_to_dev");
 }
 
 int motifs_hist_allreduce(motifs_comm* c, int64_t* per_pwm_counts_dev, int K, int n_strands) {
@@ -221,7 +239,7 @@ int motifs_hist_allreduce(motifs_comm* c, int64_t* per_pwm_counts_dev, int K, in
         set_error("motifs_hist_allreduce: bad argument (K=%d n_strands=%d)", K, n_strands);
         return MOTIFS_ERR_INVALID;
     }
-    return allreduce(c, per_pwm_counts_dev, (int64_t)K * n_strands, ncclInt64, "motifs_hist_allreduce");
+    return allreduce(c, per_pwm_counts_dev, per_pwm_counts_dev, (int64_t)K * n_strands, ncclInt64, "motifs_hist_allreduce");
 }
 
 }  // extern "C"

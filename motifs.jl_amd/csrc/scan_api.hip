@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -30,6 +31,7 @@ void set_error(const char* fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
+const char* last_error_text() { return g_err; }
 
 struct PackedBank {
     std::vector<uint32_t> tab;
@@ -420,7 +422,9 @@ static int scan_hits_mfma(motifs_ctx* c, const BankSlot& bank, int K, const uint
             MOTIFS_HIP_CHECK(hipMemsetAsync((char*)c->cnt.p + (size_t)(nb - 1) * per_batch, 0, per_batch, c->stream));
         {
             KernelTimer t(c, KS_SCAN_COUNT, true);
-            MOTIFS_HIP_CHECK(launch_cand(a, c->stream, t.e0, t.e1));
+            const hipError_t le = launch_cand(a, c->stream, t.e0, t.e1);
+            t.stamped = le == hipSuccess;            // events of a failed launch are never stamped: do not queue them
+            MOTIFS_HIP_CHECK(le);
         }
         {
             KernelTimer t(c, KS_SCAN_OFFSETS);
@@ -490,7 +494,7 @@ void motifs_ctx_destroy(motifs_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : {&c->tab, &c->lim, &c->cnt, &c->off, &c->tilesum, &c->small, &c->codes, &c->hits_tmp,
-                      &c->scores_tmp, &c->pwmcnt, &c->data_tmp, &c->afrag, &c->cinit, &c->staging, &c->rowx})
+                      &c->scores_tmp, &c->pwmcnt, &c->data_tmp, &c->afrag, &c->cinit, &c->staging, &c->rowx, &c->dp_scratch})
         b->release();
     for (BankSlot& bs : c->bank_slot)
         for (DevBuf* b : {&bs.tab, &bs.lim, &bs.afrag, &bs.cinit, &bs.tabk}) b->release();
@@ -513,6 +517,18 @@ int motifs_ctx_set_stream(motifs_ctx* c, void* hip_stream) {
     // then silently unordered against the library's kernels.)
     c->stream = (hipStream_t)hip_stream;
     c->own_stream = false;
+    return MOTIFS_OK;
+}
+
+int motifs_ctx_use_private_stream(motifs_ctx* c) {
+    if (!c) return MOTIFS_ERR_INVALID;
+    if (c->own_stream) return MOTIFS_OK;
+    MOTIFS_HIP_CHECK(hipSetDevice(c->device));
+    MOTIFS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    hipStream_t st = nullptr;
+    MOTIFS_HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    c->stream = st;
+    c->own_stream = true;
     return MOTIFS_OK;
 }
 
@@ -933,7 +949,7 @@ struct F16x4 {
 };
 
 // host matrix of `kind` -> c->codes (the internal code matrix), checked for one-hot columns
-static int upload_and_encode(motifs_ctx* c, const void* data, int kind, int64_t N, int L) {
+int motifs::upload_and_encode(motifs_ctx* c, const void* data, int kind, int64_t N, int L) {
     MOTIFS_HIP_CHECK(c->codes.reserve(motifs_codes_bytes(N, L)));
     MOTIFS_HIP_CHECK(c->small.reserve(4096));
     const int pitch = motifs_codes_pitch(L);
@@ -954,49 +970,69 @@ static int upload_and_encode(motifs_ctx* c, const void* data, int kind, int64_t 
         }
         return MOTIFS_OK;
     }
-    const size_t total = motifs_codes_bytes(N, L);
+    // Rows are encoded into a ring of pinned chunks (a few tens of MiB each, whatever N is) by host threads while the
+    // previous chunk is on the wire; the page-locked footprint no longer grows with the input.
+    constexpr size_t CH_BYTES = (size_t)32 << 20;
+    constexpr int NB = 3;
+    const int64_t rows_per_chunk = std::max<int64_t>(1, (int64_t)(CH_BYTES / (size_t)pitch));
+    const size_t slot_bytes = (size_t)std::min<int64_t>(rows_per_chunk, std::max<int64_t>(N, 1)) * pitch;
     MOTIFS_HIP_CHECK(hipStreamSynchronize(c->stream));        // an earlier call may still read the staging block
-    MOTIFS_HIP_CHECK(pin_reserve(c, total));
-    uint8_t* rows = (uint8_t*)c->pin_stage;
-    const int T = host_threads(N * (int64_t)L, 1 << 18);
+    MOTIFS_HIP_CHECK(pin_reserve(c, slot_bytes * NB));
+    hipEvent_t ev[NB] = {nullptr, nullptr, nullptr};
+    for (auto& e : ev) MOTIFS_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     std::atomic<int> bad{0};
-    run_threads(T, [&](int t) {
-        const int64_t n0 = N * t / T, n1 = N * (t + 1) / T;
-        bool b;
-        if (kind == MOTIFS_DATA_ONEHOT_F32)
-            b = encode_rows_host((const F32x4*)data, n0, n1, L, pitch, rows, [](const F32x4& q, bool& bad_) {
-                const int ones = (q.v[0] == 1.0f) + (q.v[1] == 1.0f) + (q.v[2] == 1.0f) + (q.v[3] == 1.0f);
-                const int zeros = (q.v[0] == 0.0f) + (q.v[1] == 0.0f) + (q.v[2] == 0.0f) + (q.v[3] == 0.0f);
-                if (ones == 1 && zeros == 3) return q.v[0] == 1.0f ? 0 : q.v[1] == 1.0f ? 1 : q.v[2] == 1.0f ? 2 : 3;
-                if (zeros != 4) bad_ = true;
-                return 4;
-            });
-        else
-            b = encode_rows_host((const F16x4*)data, n0, n1, L, pitch, rows, [](const F16x4& q, bool& bad_) {
-                int ones = 0, zeros = 0, which = 0;
-                for (int u = 0; u < 4; u++) {
-                    if (q.v[u] == 0x3c00u) ones++, which = u;
-                    if ((q.v[u] & 0x7fffu) == 0) zeros++;
-                }
-                if (ones == 1 && zeros == 3) return which;
-                if (zeros != 4) bad_ = true;
-                return 4;
-            });
-        if (b) bad.store(1);
-    });
+    hipError_t err = hipSuccess;
+    int64_t chunk_no = 0;
+    for (int64_t r0 = 0; r0 < N && err == hipSuccess && !bad.load(); r0 += rows_per_chunk, chunk_no++) {
+        const int64_t nr = std::min<int64_t>(rows_per_chunk, N - r0);
+        const int slot = (int)(chunk_no % NB);
+        if (chunk_no >= NB) err = hipEventSynchronize(ev[slot]);          // the slot's previous upload has left it
+        if (err != hipSuccess) break;
+        uint8_t* rows = (uint8_t*)c->pin_stage + (size_t)slot * slot_bytes;   // row r0 + i of the matrix at rows + i * pitch
+        const int T = host_threads(nr * (int64_t)L, 1 << 18);
+        run_threads(T, [&](int t) {
+            const int64_t n0 = nr * t / T, n1 = nr * (t + 1) / T;
+            bool b;
+            if (kind == MOTIFS_DATA_ONEHOT_F32)
+                b = encode_rows_host((const F32x4*)data + (size_t)r0 * L, n0, n1, L, pitch, rows, [](const F32x4& q, bool& bad_) {
+                    const int ones = (q.v[0] == 1.0f) + (q.v[1] == 1.0f) + (q.v[2] == 1.0f) + (q.v[3] == 1.0f);
+                    const int zeros = (q.v[0] == 0.0f) + (q.v[1] == 0.0f) + (q.v[2] == 0.0f) + (q.v[3] == 0.0f);
+                    if (ones == 1 && zeros == 3) return q.v[0] == 1.0f ? 0 : q.v[1] == 1.0f ? 1 : q.v[2] == 1.0f ? 2 : 3;
+                    if (zeros != 4) bad_ = true;
+                    return 4;
+                });
+            else
+                b = encode_rows_host((const F16x4*)data + (size_t)r0 * L, n0, n1, L, pitch, rows, [](const F16x4& q, bool& bad_) {
+                    int ones = 0, zeros = 0, which = 0;
+                    for (int u = 0; u < 4; u++) {
+                        if (q.v[u] == 0x3c00u) ones++, which = u;
+                        if ((q.v[u] & 0x7fffu) == 0) zeros++;
+                    }
+                    if (ones == 1 && zeros == 3) return which;
+                    if (zeros != 4) bad_ = true;
+                    return 4;
+                });
+            if (b) bad.store(1);
+        });
+        err = hipMemcpyAsync((uint8_t*)c->codes.p + (size_t)r0 * pitch, rows, (size_t)nr * pitch, hipMemcpyHostToDevice, c->stream);
+        if (err == hipSuccess) err = hipEventRecord(ev[slot], c->stream);
+    }
+    if (err == hipSuccess)                                       // the guard bytes behind the last row
+        err = hipMemsetAsync((uint8_t*)c->codes.p + (size_t)N * pitch, 0, motifs_codes_bytes(N, L) - (size_t)N * pitch, c->stream);
+    const hipError_t serr = hipStreamSynchronize(c->stream);     // the staging block is reused by the download
+    for (auto& e : ev) (void)hipEventDestroy(e);
     if (bad.load()) {
         set_error("data matrix has a column that is neither one-hot nor all-zero");
         return MOTIFS_ERR_NOT_ONEHOT;
     }
-    memset(rows + (size_t)N * pitch, 0, total - (size_t)N * pitch);   // the guard bytes behind the last row
-    MOTIFS_HIP_CHECK(hipMemcpyAsync(c->codes.p, rows, total, hipMemcpyHostToDevice, c->stream));
-    MOTIFS_HIP_CHECK(hipStreamSynchronize(c->stream));        // the staging block is reused by the download
+    MOTIFS_HIP_CHECK(err);
+    MOTIFS_HIP_CHECK(serr);
     return MOTIFS_OK;
 }
 
 // device bytes -> pageable host memory: chunks cross the bus into a ring of pinned buffers; host threads copy chunk i out
 // while chunk i + 1 is in flight.  The stream is idle when this returns.
-static int download_chunked(motifs_ctx* c, void* dst, const void* src_dev, size_t bytes) {
+int motifs::download_chunked(motifs_ctx* c, void* dst, const void* src_dev, size_t bytes) {
     if (bytes == 0) return MOTIFS_OK;
     constexpr size_t CH = (size_t)16 << 20;
     constexpr int NB = 4;
@@ -1134,6 +1170,206 @@ int motifs_pwm_scan_both(motifs_ctx* c, const uint16_t* pwms_fp16, const int64_t
     }
     MOTIFS_HIP_CHECK(hipStreamSynchronize(c->stream));
     return r;
+}
+
+// ---- device memory for a host without a GPU array package (include/motifs_hip.h) ---------------------------------------
+int motifs_dev_alloc(motifs_ctx* c, size_t bytes, void** out_dev) {
+    if (!c || !out_dev) {
+        set_error("motifs_dev_alloc: null argument");
+        return MOTIFS_ERR_INVALID;
+    }
+    *out_dev = nullptr;
+    MOTIFS_HIP_CHECK(hipSetDevice(c->device));
+    MOTIFS_HIP_CHECK(hipMalloc(out_dev, std::max<size_t>(bytes, 16)));
+    return MOTIFS_OK;
+}
+
+int motifs_dev_free(motifs_ctx* c, void* ptr_dev) {
+    if (!c) return MOTIFS_ERR_INVALID;
+    if (!ptr_dev) return MOTIFS_OK;
+    MOTIFS_HIP_CHECK(hipSetDevice(c->device));
+    MOTIFS_HIP_CHECK(hipStreamSynchronize(c->stream));     // nothing queued by the library may still touch the buffer
+    MOTIFS_HIP_CHECK(hipFree(ptr_dev));
+    return MOTIFS_OK;
+}
+
+int motifs_dev_upload(motifs_ctx* c, void* dst_dev, const void* src_host, size_t bytes) {
+    if (!c || (bytes > 0 && (!dst_dev || !src_host))) {
+        set_error("motifs_dev_upload: null argument");
+        return MOTIFS_ERR_INVALID;
+    }
+    if (bytes == 0) return MOTIFS_OK;
+    MOTIFS_HIP_CHECK(hipSetDevice(c->device));
+    MOTIFS_HIP_CHECK(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, c->stream));
+    MOTIFS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return MOTIFS_OK;
+}
+
+int motifs_dev_download(motifs_ctx* c, void* dst_host, const void* src_dev, size_t bytes) {
+    if (!c || (bytes > 0 && (!dst_host || !src_dev))) {
+        set_error("motifs_dev_download: null argument");
+        return MOTIFS_ERR_INVALID;
+    }
+    MOTIFS_HIP_CHECK(hipSetDevice(c->device));
+    return download_chunked(c, dst_host, src_dev, bytes);    // pinned ring for large blocks; the stream is idle on return
+}
+
+int motifs_dev_memset(motifs_ctx* c, void* dst_dev, int byte_value, size_t bytes) {
+    if (!c || (bytes > 0 && !dst_dev)) {
+        set_error("motifs_dev_memset: null argument");
+        return MOTIFS_ERR_INVALID;
+    }
+    if (bytes == 0) return MOTIFS_OK;
+    MOTIFS_HIP_CHECK(hipSetDevice(c->device));
+    MOTIFS_HIP_CHECK(hipMemsetAsync(dst_dev, byte_value, bytes, c->stream));
+    return MOTIFS_OK;
+}
+
+// gpu_scan of a host matrix over several devices of one process: one host thread per device (upload + encode, count,
+// fill, download into the device's slice of the caller's buffers); records concatenated in device order.
+int motifs_pwm_scan_both_sharded(motifs_ctx* const* ctxs, motifs_comm* const* comms, int n_dev, const uint16_t* pwms_fp16,
+                                 const int64_t* lens, int K, int maxlen, const void* data, int kind, int64_t N, int L,
+                                 int64_t shard_align, motifs_hit* hits_fwd, uint16_t* scores_fwd, motifs_hit* hits_rc, uint16_t* scores_rc,
+                                 int64_t cap, int64_t* n_out2, int64_t* per_pwm_counts2, int64_t* shard_counts) {
+    if (!ctxs || n_dev < 1 || !n_out2 || N < 0 || L <= 0 || K <= 0 || kind < 0 || kind > 2 || (N > 0 && !data) || cap < 0 || shard_align < 1 ||
+        (cap > 0 && (!hits_fwd || !scores_fwd || !hits_rc || !scores_rc))) {
+        set_error("motifs_pwm_scan_both_sharded: bad argument (n_dev=%d N=%lld L=%d K=%d cap=%lld align=%lld)", n_dev, (long long)N, L, K,
+                  (long long)cap, (long long)shard_align);
+        return MOTIFS_ERR_INVALID;
+    }
+    for (int d = 0; d < n_dev; d++) {
+        if (!ctxs[d] || (comms && comm_ctx(comms[d]) != ctxs[d])) {
+            set_error("motifs_pwm_scan_both_sharded: slot %d: null context, or a communicator made on another context", d);
+            return MOTIFS_ERR_INVALID;
+        }
+        for (int j = 0; j < d; j++)
+            if (ctxs[j] == ctxs[d]) {
+                set_error("motifs_pwm_scan_both_sharded: slots %d and %d are the same context", j, d);
+                return MOTIFS_ERR_INVALID;
+            }
+    }
+    if (comms && comm_group_depth() > 0) {
+        set_error("motifs_pwm_scan_both_sharded opens its own group around the histogram sums: call it outside motifs_comm_group_start/_end");
+        return MOTIFS_ERR_INVALID;
+    }
+    n_out2[0] = n_out2[1] = 0;
+    // contiguous blocks of whole units of shard_align reads; sizes differ by at most one unit (parallel.shard_range)
+    const int64_t units = (N + shard_align - 1) / shard_align;
+    std::vector<int64_t> lo(n_dev + 1, 0);
+    for (int d = 0; d < n_dev; d++) {
+        const int64_t u = units / n_dev + (d < units % n_dev ? 1 : 0);
+        lo[d + 1] = std::min<int64_t>(N, lo[d] + u * shard_align);
+    }
+    const size_t elt = kind == MOTIFS_DATA_ONEHOT_F32 ? 16 : kind == MOTIFS_DATA_ONEHOT_F16 ? 8 : 1;
+    std::vector<int64_t> need(2 * (size_t)n_dev, 0);
+    auto on_devices = [&](auto&& fn) -> int { return for_each_device(n_dev, fn); };
+    // phase A: reads to the device, count-only scan (the records of a shard need their offset in the caller's buffers)
+    int r = on_devices([&](int d) -> int {
+        motifs_ctx* c = ctxs[d];
+        const int64_t n = lo[d + 1] - lo[d];
+        MOTIFS_HIP_CHECK(hipSetDevice(c->device));
+        MOTIFS_HIP_CHECK(c->pwmcnt.reserve((size_t)2 * K * 8 + 64));
+        MOTIFS_HIP_CHECK(hipMemsetAsync(c->pwmcnt.p, 0, (size_t)2 * K * 8, c->stream));
+        if (n == 0) return MOTIFS_OK;
+        int rr = upload_and_encode(c, (const char*)data + (size_t)lo[d] * L * elt, kind, n, L);
+        if (rr) return rr;
+        return motifs_pwm_scan_hits_both_dev(c, pwms_fp16, lens, K, maxlen, (const uint8_t*)c->codes.p, n, L, lo[d], MOTIFS_SCAN_BATCH, nullptr, nullptr,
+                                             nullptr, nullptr, 0, &need[2 * (size_t)d], nullptr);
+    });
+    if (r) return r;
+    std::vector<int64_t> off(2 * (size_t)(n_dev + 1), 0);     // off[2 d + s]: records of strand s before device d
+    for (int d = 0; d < n_dev; d++)
+        for (int sdx = 0; sdx < 2; sdx++) off[2 * (size_t)(d + 1) + sdx] = off[2 * (size_t)d + sdx] + need[2 * (size_t)d + sdx];
+    n_out2[0] = off[2 * (size_t)n_dev];
+    n_out2[1] = off[2 * (size_t)n_dev + 1];
+    if (shard_counts) memcpy(shard_counts, need.data(), need.size() * 8);
+    const bool too_small = n_out2[0] > cap || n_out2[1] > cap;
+    const bool count_only = cap == 0 && !hits_fwd;
+    // phase B: the records (and the histogram: a shard's counts are only written by a filling or counting scan; take the filling one)
+    if (!too_small || count_only) {
+        r = on_devices([&](int d) -> int {
+            motifs_ctx* c = ctxs[d];
+            const int64_t n = lo[d + 1] - lo[d];
+            if (n == 0) return MOTIFS_OK;
+            MOTIFS_HIP_CHECK(hipSetDevice(c->device));
+            const int64_t cap_d = count_only ? 0 : std::max<int64_t>(std::max(need[2 * (size_t)d], need[2 * (size_t)d + 1]), 1);
+            motifs_hit* hd[2] = {nullptr, nullptr};
+            uint16_t* sd[2] = {nullptr, nullptr};
+            if (!count_only) {
+                const int64_t cap8 = (cap_d + 7) & ~(int64_t)7;
+                MOTIFS_HIP_CHECK(c->hits_tmp.reserve((size_t)2 * cap_d * sizeof(motifs_hit)));
+                MOTIFS_HIP_CHECK(c->scores_tmp.reserve((size_t)(cap8 + cap_d) * 2));
+                hd[0] = (motifs_hit*)c->hits_tmp.p;
+                hd[1] = hd[0] + cap_d;
+                sd[0] = (uint16_t*)c->scores_tmp.p;
+                sd[1] = sd[0] + cap8;
+            }
+            int64_t got[2] = {0, 0};
+            int rr = motifs_pwm_scan_hits_both_dev(c, pwms_fp16, lens, K, maxlen, (const uint8_t*)c->codes.p, n, L, lo[d], MOTIFS_SCAN_BATCH, hd[0],
+                                                   sd[0], hd[1], sd[1], cap_d, got, (int64_t*)c->pwmcnt.p);
+            if (rr) return rr;
+            if (count_only) return MOTIFS_OK;
+            motifs_hit* hh[2] = {hits_fwd, hits_rc};
+            uint16_t* sh[2] = {scores_fwd, scores_rc};
+            for (int sdx = 0; sdx < 2; sdx++)
+                if (got[sdx] > 0) {
+                    rr = download_chunked(c, hh[sdx] + off[2 * (size_t)d + sdx], hd[sdx], (size_t)got[sdx] * sizeof(motifs_hit));
+                    if (rr == MOTIFS_OK) rr = download_chunked(c, sh[sdx] + off[2 * (size_t)d + sdx], sd[sdx], (size_t)got[sdx] * 2);
+                    if (rr) return rr;
+                }
+            return MOTIFS_OK;
+        });
+        if (r) return r;
+    } else if (per_pwm_counts2) {
+        // too small a buffer: the caller still gets the histogram (a counting scan writes it as well)
+        r = on_devices([&](int d) -> int {
+            motifs_ctx* c = ctxs[d];
+            const int64_t n = lo[d + 1] - lo[d];
+            if (n == 0) return MOTIFS_OK;
+            MOTIFS_HIP_CHECK(hipSetDevice(c->device));
+            int64_t got[2] = {0, 0};
+            return motifs_pwm_scan_hits_both_dev(c, pwms_fp16, lens, K, maxlen, (const uint8_t*)c->codes.p, n, L, lo[d], MOTIFS_SCAN_BATCH, nullptr, nullptr,
+                                                 nullptr, nullptr, 0, got, (int64_t*)c->pwmcnt.p);
+        });
+        if (r) return r;
+    }
+    // phase C: the one exchange of the scan: the 2 x K hit counts
+    if (per_pwm_counts2) {
+        if (comms && n_dev > 1) {
+            r = motifs_comm_group_start();
+            if (r) return r;
+            int rr = MOTIFS_OK;
+            for (int d = 0; d < n_dev && rr == MOTIFS_OK; d++) rr = motifs_hist_allreduce(comms[d], (int64_t*)ctxs[d]->pwmcnt.p, K, 2);
+            std::string why = rr ? last_error_text() : "";
+            r = motifs_comm_group_end();
+            if (rr) {
+                set_error("%s", why.c_str());
+                return rr;
+            }
+            if (r) return r;
+            MOTIFS_HIP_CHECK(hipSetDevice(ctxs[0]->device));
+            MOTIFS_HIP_CHECK(hipMemcpyAsync(per_pwm_counts2, ctxs[0]->pwmcnt.p, (size_t)2 * K * 8, hipMemcpyDeviceToHost, ctxs[0]->stream));
+            for (int d = 0; d < n_dev; d++) {
+                MOTIFS_HIP_CHECK(hipSetDevice(ctxs[d]->device));
+                MOTIFS_HIP_CHECK(hipStreamSynchronize(ctxs[d]->stream));
+            }
+        } else {
+            std::vector<int64_t> part((size_t)2 * K);
+            memset(per_pwm_counts2, 0, (size_t)2 * K * 8);
+            for (int d = 0; d < n_dev; d++) {
+                MOTIFS_HIP_CHECK(hipSetDevice(ctxs[d]->device));
+                MOTIFS_HIP_CHECK(hipMemcpyAsync(part.data(), ctxs[d]->pwmcnt.p, (size_t)2 * K * 8, hipMemcpyDeviceToHost, ctxs[d]->stream));
+                MOTIFS_HIP_CHECK(hipStreamSynchronize(ctxs[d]->stream));
+                for (int i = 0; i < 2 * K; i++) per_pwm_counts2[i] += part[i];
+            }
+        }
+    }
+    if (too_small && !count_only) {
+        set_error("hit buffer too small: need %lld / %lld records (forward / reverse), cap %lld", (long long)n_out2[0], (long long)n_out2[1],
+                  (long long)cap);
+        return MOTIFS_ERR_BUFFER_TOO_SMALL;
+    }
+    return MOTIFS_OK;
 }
 
 }  // extern "C"

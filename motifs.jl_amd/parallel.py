@@ -43,11 +43,22 @@ class RcclReducer:
     def __init__(self, comm):
         self.comm = comm
 
+    def _order(self, t):
+        """The collective runs on the context's stream.  An operand torch produced on ANOTHER stream (a fill on torch's
+        current stream while the context keeps its private one) is not ordered against it by anything: wait for torch's
+        stream first.  When the two are the same stream (bench.py, ctx.set_stream) the stream itself orders them."""
+        if t.is_cuda:
+            cur = torch.cuda.current_stream(t.device)
+            if int(cur.cuda_stream) != int(self.comm.ctx.get_stream()):
+                cur.synchronize()
+
     def sum_f32_(self, t):
+        self._order(t)
         self.comm.allreduce_sum_f32(t.data_ptr(), t.numel())
         return t
 
     def sum_i64_(self, t):
+        self._order(t)
         self.comm.allreduce_sum_i64(t.data_ptr(), t.numel())
         return t
 
@@ -165,17 +176,37 @@ def gather_hits(local_hits, local_scores):
     return np.concatenate([o[0] for o in objs]), np.concatenate([o[1] for o in objs])
 
 
-def sharded_gpu_scan(ctx, pwms, lens, codes, reducer=None, batch=_lib.SCAN_BATCH):
-    """gpu_scan (_h3_1_alignment.jl:89-99) over a read matrix sharded across the ranks: every rank scans its block of
-    whole ordering batches with n0 = its first read, the per-PWM histograms are summed, the records concatenated in
-    rank order.  codes: (N, L) uint8 host array, the same on every rank.  Returns, on every rank,
+def records_to_dicts(found_fwd, found_rc, num_motifs):
+    """positions[m][n] / use_comp[m][n] as gpu_scan builds them (modify_w_found!, _h3_1_alignment.jl:38-52, forward records
+    then reverse ones): what a consumer of the scan sees.  Two record lists that differ only in the global order of
+    their (m, n) groups give equal dictionaries."""
+    from .scan import modify_w_found
+
+    pos = [dict() for _ in range(num_motifs)]
+    sco = [dict() for _ in range(num_motifs)]
+    comp = [dict() for _ in range(num_motifs)]
+    modify_w_found(found_fwd[0], found_fwd[1], pos, sco, comp, rc=False)
+    modify_w_found(found_rc[0], found_rc[1], pos, sco, comp, rc=True)
+    return pos, sco, comp
+
+
+def sharded_gpu_scan(ctx, pwms, lens, codes, reducer=None, batch=_lib.SCAN_BATCH, align=None):
+    """gpu_scan (_h3_1_alignment.jl:89-99) over a read matrix sharded across the ranks: every rank scans its block
+    with n0 = its first read, the per-PWM histograms are summed, the records concatenated in rank order.
+    align = batch (the default): shard edges on whole ordering batches, the concatenation IS the single-device record
+    list bit for bit, but 20 batches over 8 ranks split 3,3,3,3,2,2,2,2.  align = 1 (or the 6 of a mini-batch): even
+    shards; the global order is then sequence-block-major (each shard numbers its ordering batches from its own first
+    read), while for every (m, n) the records keep the order modify_w_found! depends on - ascending l per strand - so
+    the dictionaries are the single-device ones (records_to_dicts).
+    codes: (N, L) uint8 host array, the same on every rank.  Returns, on every rank,
     ((found_fwd, score_fwd), (found_rc, score_rc), counts[2, K])."""
     rank, ws = world()
     N, L = codes.shape
     K = len(lens)
-    lo, hi = shard_range(N, rank, ws, align=batch)
+    lo, hi = shard_range(N, rank, ws, align=batch if align is None else align)
     n_loc = hi - lo
     counts = torch.zeros((2, K), dtype=torch.int64, device=f"cuda:{ctx.device}")
+    torch.cuda.synchronize(counts.device)      # the fill above is on torch's stream; an empty rank goes straight to the sum
     out = []
     if n_loc > 0:
         raw = torch.from_numpy(np.ascontiguousarray(codes[lo:hi])).to(counts.device)

@@ -41,7 +41,7 @@ def test_binding_covers_every_declared_symbol(built):
 
 
 def test_abi_version(built):
-    assert built._lib.lib().motifs_abi_version() == built._lib.ABI_VERSION == 2
+    assert built._lib.lib().motifs_abi_version() == built._lib.ABI_VERSION == 3
 
 
 def test_comm_entry_points_fail_cleanly_without_a_device(built):

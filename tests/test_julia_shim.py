@@ -120,12 +120,38 @@ def test_shim_binds_what_discover_motifs_needs():
     need = {"motifs_ctx_create", "motifs_ctx_destroy", "motifs_model_create", "motifs_model_destroy", "motifs_model_init_random",
             "motifs_model_get_params", "motifs_model_set_params", "motifs_model_train_step_onehot", "motifs_model_l1_syntax",
             "motifs_model_retrieve_codes", "motifs_pwm_scan", "motifs_comm_create_all", "motifs_comm_create",
-            "motifs_model_dp_train_step_dev", "motifs_hist_allreduce", "motifs_model_allreduce_grad"}
+            "motifs_model_dp_train_step_dev", "motifs_hist_allreduce", "motifs_model_allreduce_grad",
+            # round 3: what a Julia host needs to REACH the device-resident and multi-device paths without CUDA.jl / AMDGPU.jl
+            "motifs_abi_version", "motifs_dev_alloc", "motifs_dev_free", "motifs_dev_upload", "motifs_dev_download", "motifs_dev_memset",
+            "motifs_encode_dev", "motifs_codes_bytes", "motifs_pwm_scan_hits_both_dev", "motifs_pwm_scan_dense_dev", "motifs_pwm_scan_both",
+            "motifs_fasta_read", "motifs_hits_minmax_dev", "motifs_hits_threshold_counts_dev", "motifs_hits_filter_dev",
+            "motifs_hits_count_matrices_dev", "motifs_codes_mag_histogram_dev", "motifs_codes_filter_dev", "motifs_triplets_offsets_dev",
+            "motifs_triplets_enumerate_dev", "motifs_triplets_group_dev", "motifs_model_dp_train_step_all", "motifs_model_dp_train_step_host",
+            "motifs_model_dp_grad_dev", "motifs_model_dp_update_dev", "motifs_comm_allreduce_sum_f32_to_dev", "motifs_pwm_scan_both_sharded",
+            "motifs_ctx_use_private_stream", "motifs_comm_group_start", "motifs_comm_group_end"}
     assert need <= bound, sorted(need - bound)
     text = open(SHIM).read()
     for fn in ("function train_ucdl(data;", "function code_retrieval(data, cdl", "function get_pos_scores_arr(ms, data;",
-               "function gpu_scan(ms, data;", "function scan_w_gpu!(ms, data;", "function modify_w_found!("):
+               "function gpu_scan(ms, data;", "function scan_w_gpu!(ms, data;", "function modify_w_found!(",
+               "function gpu_scan(ms, reads::DeviceReads", "function gpu_scan_sharded(ms, data, ctxs", "function dp_train_step!(cdls::Vector{ucdl}",
+               "__init__() = abi_version() == ABI_VERSION"):
         assert fn in text, fn
+
+
+def test_every_dev_pointer_in_the_integration_example_has_a_source():
+    """INTEGRATION.md's multi-GPU example used codes_dev[d] / loss_dev[d] / grad_dev[d] that came from nowhere and
+    wrapped the per-rank step in a group.  The example must only use names the shim defines, and must not group the step."""
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    shim = open(SHIM).read()
+    blocks = re.findall(r"```julia\n(.*?)```", text, flags=re.S)
+    assert blocks
+    for b in blocks:
+        for name in re.findall(r"(?<![A-Za-z])HIP\.([A-Za-z_!]+)", b):
+            assert re.search(r"(function |^|\n)(%s)(?![A-Za-z_!])" % re.escape(name), shim) or ("struct " + name) in shim or ("const " + name) in shim, \
+                f"INTEGRATION.md uses HIP.{name}, which julia/MotifsHIP.jl does not define"
+        if "group_start" in b:
+            inside = b.split("group_start", 1)[1].split("group_end", 1)[0]
+            assert "dp_train_step" not in inside, "a whole optimiser step inside an RCCL group runs AdaBelief before the sum"
 
 
 def test_struct_layouts_match():

@@ -132,3 +132,44 @@ def test_rank_without_a_mini_batch_still_joins_the_exchange():
         assert kinds == (["grad", "step"] if ret[r]["local"] else ["step"])
         assert ret[r]["calls"][-1][1] == 0.5
     assert np.array_equal(ret[0]["params"], ret[1]["params"]) and np.array_equal(ret[0]["params"], ret[2]["params"])
+
+
+def test_fine_shards_keep_the_per_pwm_per_read_order(pkg):
+    """shard edges inside an ordering batch (align = 1: even shards) change the GLOBAL record order to
+    sequence-block-major, but for every (m, n) the records still come in ascending l per strand, so the dictionaries
+    modify_w_found! builds (_h3_1_alignment.jl:38-52) are the single-device ones.  The per-shard scan here is the CPU
+    oracle (the GPU equivalent is tests/test_parallel_gpu.py); what is under test is the shard layout and the
+    concatenation rule."""
+    from oracle import scan_oracle as so
+
+    sy, par = pkg.synth, pkg.parallel
+    N, L, K, batch = 230, 40, 12, 50
+    codes = sy.gen_codes(N, L, 5, n_plant=2, k=8)
+    pwms, lens = sy.gen_pwm_bank(K, 3, len_lo=6, len_hi=9, alpha=0.4)
+    bank = sy.pad_bank(pwms, lens)
+    onehot = sy.codes_to_onehot(codes)
+
+    def scan(lo, hi, rc):
+        f, s = so.get_pos_scores_arr(bank, lens, onehot[lo:hi], rc=rc, batch_size=batch)
+        f = f.copy()
+        f["n"] += lo                     # n0 of the shard (_h3_1_alignment.jl:83 adds the batch offset the same way)
+        return f, s
+
+    one = [scan(0, N, rc) for rc in (False, True)]
+    want = par.records_to_dicts(one[0], one[1], K)
+    for ws, align in [(8, 1), (3, 6), (8, batch), (5, 7)]:
+        edges = [par.shard_range(N, r, ws, align=align) for r in range(ws)]
+        if align == 1:
+            sizes = [b - a for a, b in edges]
+            assert max(sizes) - min(sizes) <= 1           # even: configs[2] splits 12500 x 8, not 3,3,3,3,2,2,2,2 batches
+        parts = [[scan(a, b, rc) for a, b in edges if b > a] for rc in (False, True)]
+        cat = [(np.concatenate([p[0] for p in parts[rc]]), np.concatenate([p[1] for p in parts[rc]])) for rc in (0, 1)]
+        assert len(cat[0][0]) == len(one[0][0]) and len(cat[1][0]) == len(one[1][0])
+        got = par.records_to_dicts(cat[0], cat[1], K)
+        assert got == want                               # positions, scores and use_comp, list by list
+        if align == batch:                               # whole ordering batches: the record lists themselves are equal
+            for rc in (0, 1):
+                assert np.array_equal(cat[rc][0], one[rc][0])
+                assert np.array_equal(cat[rc][1].view(np.uint16), one[rc][1].view(np.uint16))
+        elif ws > 1 and align == 1:
+            assert not np.array_equal(cat[0][0], one[0][0])   # ... and otherwise they are NOT: only the per-(m, n) order holds

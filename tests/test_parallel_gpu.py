@@ -35,7 +35,7 @@ def _setup(rank, ws, port):
     return pkg, ctx, reducer
 
 
-def _scan_worker(rank, ws, port, ret):
+def _scan_worker(rank, ws, port, align, ret):
     import torch
     import torch.distributed as dist
 
@@ -45,7 +45,7 @@ def _scan_worker(rank, ws, port, ret):
     codes = sy.gen_codes(N, L, 2024, n_plant=3, k=10)
     pwms, lens = sy.gen_pwm_bank(K, 11, len_lo=8, len_hi=12, alpha=0.35)
     bank = sy.pad_bank(pwms, lens)
-    fwd, rcs, counts = par.sharded_gpu_scan(ctx, bank, lens, codes, reducer=reducer, batch=batch)
+    fwd, rcs, counts = par.sharded_gpu_scan(ctx, bank, lens, codes, reducer=reducer, batch=batch, align=align)
     if rank == 0:                                             # the same scan on one device, in this process
         raw = torch.from_numpy(codes).cuda()
         dcodes = torch.zeros(lib.Context.codes_bytes(N, L), dtype=torch.uint8, device="cuda")
@@ -59,14 +59,22 @@ def _scan_worker(rank, ws, port, ret):
                                          cap, batch=batch, counts_ptr=c1.data_ptr())
         ctx.synchronize()
         ok = True
+        single = []
         for rc, (f, s) in enumerate((fwd, rcs)):
             one = hits[rc][: got[rc]].cpu().numpy().view(np.uint32)
             ok &= len(f) == got[rc] and got[rc] > 1000
-            ok &= np.array_equal(np.stack([f["m"], f["n"], f["l"]], axis=1), one)
-            ok &= np.array_equal(s.view(np.uint16), hsc[rc][: got[rc]].cpu().numpy().view(np.uint16))
+            same = np.array_equal(np.stack([f["m"], f["n"], f["l"]], axis=1), one)
+            same &= np.array_equal(s.view(np.uint16), hsc[rc][: got[rc]].cpu().numpy().view(np.uint16))
+            # whole ordering batches per shard: the record lists are equal; shard edges inside a batch: they are not
+            ok &= same if align in (None, batch) else not same
+            rec = np.zeros(got[rc], dtype=lib.HIT_DTYPE)
+            rec["m"], rec["n"], rec["l"] = one[:, 0], one[:, 1], one[:, 2]
+            single.append((rec, hsc[rc][: got[rc]].cpu().numpy().view(np.float16)))
+        # ... but what gpu_scan hands its callers - the per-(PWM, read) lists of modify_w_found! - is the same either way
+        ok &= par.records_to_dicts(fwd, rcs, K) == par.records_to_dicts(single[0], single[1], K)
         ok &= np.array_equal(counts, c1.cpu().numpy())
         ret["scan_ok"] = bool(ok)
-        ret["shards"] = [par.shard_range(N, r, ws, align=batch) for r in range(ws)]
+        ret["shards"] = [par.shard_range(N, r, ws, align=batch if align is None else align) for r in range(ws)]
     ctx.close()
     dist.destroy_process_group()
 
@@ -137,8 +145,16 @@ def _spawn(fn, ws, *args):
 
 
 def test_sharded_scan_equals_single_device_bit_for_bit():
-    ret = _spawn(_scan_worker, 2)
+    ret = _spawn(_scan_worker, 2, None)
     assert ret["shards"] == [(0, 1500), (1500, 2300)]
+    assert ret["scan_ok"]
+
+
+def test_even_shards_give_the_single_device_dictionaries():
+    """The fine shard mode (align = 1): BASELINE configs[2] then splits 12 500 x 8 instead of 3,3,3,3,2,2,2,2 ordering
+    batches.  Global order = sequence-block-major; per (m, n): forward hits in ascending l, then reverse ones."""
+    ret = _spawn(_scan_worker, 3, 1)
+    assert ret["shards"] == [(0, 767), (767, 1534), (1534, 2300)]
     assert ret["scan_ok"]
 
 
