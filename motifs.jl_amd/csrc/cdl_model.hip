@@ -542,7 +542,12 @@ int motifs_model_loss_grad_dev(motifs_model* m, const uint8_t* codes_dev, int n_
     }
     MOTIFS_HIP_CHECK(hipSetDevice(m->ctx->device));
     KernelTimer tm(m->ctx, KS_TRAIN_STEP);
-    if (!m->use_graphs || keep_intermediates || n_groups > m->graph_max_groups)
+    // Replays only on the context's own private stream.  On a caller's stream (motifs_ctx_set_stream; HIP's legacy null stream
+    // in particular) a replayed step came back with gradients of ~1e28 on ROCm 7.0 / 7.2 - also with the replay fenced off on a
+    // side stream and with the device idle around it, so it is the captured graph, not its ordering, that goes wrong there
+    // (tests/test_round3_gpu.py::test_step_graph_on_the_null_stream; found in round 3).  The replay is worth 1.5 % of a
+    // 6-read step: such contexts stay eager.
+    if (!m->use_graphs || !m->ctx->own_stream || keep_intermediates || n_groups > m->graph_max_groups)
         return enqueue_loss_grad(m, m->ctx->stream, codes_dev, n_groups, loss_dev, grad_flat_dev, keep_intermediates);
     motifs_model::StepGraph* sg = nullptr;
     for (auto& g : m->step_graphs)

@@ -485,6 +485,10 @@ int motifs_ctx_create(int device, motifs_ctx** out) {
     MOTIFS_HIP_CHECK(hipHostMalloc(&c->pinned, 256, hipHostMallocDefault));
     const char* ev = getenv("MOTIFS_SCAN_VALU");
     c->scan_valu = ev && ev[0] == '1';
+    if (const char* wl = getenv("MOTIFS_WS_LIMIT_MB")) {       // experiments: the default of motifs_ctx_set_workspace_limit
+        const long long mb = atoll(wl);
+        if (mb > 0) c->ws_limit = (size_t)mb << 20;
+    }
     *out = c;
     return MOTIFS_OK;
 }

@@ -156,6 +156,49 @@ def test_grouped_step_reduces_before_it_updates(torch_cuda, pkg):
         c.close()
 
 
+@pytest.mark.parametrize("null_stream", [False, True])
+def test_step_graph_on_the_null_stream(torch_cuda, pkg, null_stream):
+    """Found in round 3 by the test above: from its third call on a step of <= 8 mini-batches was replayed from a captured
+    hipGraph, and with the context on HIP's legacy null stream (motifs_ctx_set_stream(ctx, NULL): torch's default stream)
+    replays returned gradients of ~1e28.  Steps are now replayed only on the context's own private stream and stay eager on a
+    caller's.  Six steps of two default models against an always-eager one, nothing synchronised in between, on either."""
+    import os
+
+    torch = torch_cuda
+    sy, lib, md = pkg.synth, pkg._lib, pkg.model
+    c = lib.Context(0)
+    if null_stream:
+        c.set_stream(0)
+    try:
+        hp = md.Hyperparam(filter_len=8, M=16, K=8, q=8, h=6)
+        G, L = 3, 60
+        os.environ["MOTIFS_NO_GRAPH"] = "1"
+        try:
+            eager = md.ucdl(hp, L, ctx=c, seed=9, arena_bytes=1 << 30)
+        finally:
+            del os.environ["MOTIFS_NO_GRAPH"]
+        models = [eager, md.ucdl(hp, L, ctx=c, seed=9, arena_bytes=1 << 30), md.ucdl(hp, L, ctx=c, seed=9, arena_bytes=1 << 30)]
+        codes = sy.gen_codes(G * hp.batch_size, L, 123, n_plant=2, k=8)
+        raw = torch.from_numpy(codes).cuda()
+        dcodes = torch.zeros(lib.Context.codes_bytes(codes.shape[0], L), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        c.encode_dev(raw.data_ptr(), lib.DATA_CODES_U8, codes.shape[0], L, dcodes.data_ptr())
+        bufs = [(torch.zeros(G, dtype=torch.float32, device="cuda"), torch.zeros(eager.model.nP, dtype=torch.float32, device="cuda")) for _ in models]
+        torch.cuda.synchronize()
+        for it in range(6):
+            for m, (lo, gr) in zip(models, bufs):
+                m.model.dp_train_step_dev(None, dcodes.data_ptr(), G, G, lo.data_ptr(), gr.data_ptr())
+            c.synchronize()
+            g = [float(gr.abs().sum().item()) for _, gr in bufs]
+            assert all(np.isfinite(x) and abs(x - g[0]) <= 1e-4 * g[0] for x in g), (it, g)
+        for m in models[1:]:
+            same_step(eager.model.get_params(), m.model.get_params())
+        for m in models:
+            m.model.close()
+    finally:
+        c.close()
+
+
 def test_dp_train_step_host_equals_train_step(ctx, pkg):
     """motifs_model_dp_train_step_host on one device (no communicator) is train_step; on the reference's Float32 batches too."""
     md, sy, lib = pkg.model, pkg.synth, pkg._lib

@@ -1,11 +1,16 @@
-import csv, sys, collections
+"""Per-launch counter values from rocprofv3 --pmc passes, one line per (kernel, grid size, counter): the same kernel at
+another launch size is another line, never folded into one average.
+usage: python tools/pmc_summary.py <kernel-name substring> <pass dir> [<pass dir> ...]"""
+import collections
+import csv
+import sys
+
 pat = sys.argv[1]
 for d in sys.argv[2:]:
-    acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
+    acc = collections.defaultdict(list)
     for r in csv.DictReader(open(d + "/out_counter_collection.csv")):
         if pat in r["Kernel_Name"]:
-            acc[r["Kernel_Name"].split("(")[0][:40]][r["Counter_Name"]] += float(r["Counter_Value"])
-            cnt[(r["Kernel_Name"].split("(")[0][:40], r["Counter_Name"])] += 1
-    for k, v in acc.items():
-        for c, x in v.items():
-            print(k, c, "%.4g per launch" % (x / cnt[(k, c)]), "launches", cnt[(k, c)])
+            name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("motifs::", "")[:40]
+            acc[(name, int(r["Grid_Size"]) // int(r["Workgroup_Size"]), r["Counter_Name"])].append(float(r["Counter_Value"]))
+    for (k, blocks, c), v in sorted(acc.items()):
+        print("%-40s blocks %8d %-28s %.4g per launch (launches %d, min %.4g max %.4g)" % (k, blocks, c, sum(v) / len(v), len(v), min(v), max(v)))

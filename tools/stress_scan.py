@@ -4,6 +4,7 @@ import numpy as np, torch
 from _pkg import load_pkg
 pkg = load_pkg(); lib, sy = pkg._lib, pkg.synth
 ctx = lib.Context(0)
+ctx.set_stream(0)      # torch's fills / uploads run on the null stream: the library's kernels must queue behind them, not beside
 N, L, K = 100000, 200, 200
 codes = sy.gen_codes(N, L, 11, n_plant=5, k=12)
 codes[::977, 3] = 4
