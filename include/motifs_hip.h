@@ -39,7 +39,7 @@ enum motifs_status {
     MOTIFS_ERR_BUFFER_TOO_SMALL = 4, /* *n_out holds the required record count           */
     MOTIFS_ERR_NOT_ONEHOT = 5,   /* a data column is not exactly one-hot / all-zero      */
     MOTIFS_ERR_NONFINITE = 6,    /* PWM bank holds NaN/Inf (reference semantics differ)  */
-    MOTIFS_ERR_UNSUPPORTED = 7,  /* e.g. maxlen > MOTIFS_SCAN_MAX_LEN                    */
+    MOTIFS_ERR_UNSUPPORTED = 7,  /* e.g. the engine arena is too small for n_groups       */
     MOTIFS_ERR_COMM = 8          /* RCCL missing or a collective failed                  */
 };
 
@@ -58,8 +58,9 @@ enum motifs_hit_order {
     MOTIFS_ORDER_REFERENCE = 0
 };
 
-#define MOTIFS_SCAN_MAX_LEN 64          /* longest PWM supported by the scan kernels (the reference has no cap,
-                                         * _h3_1_alignment.jl:25-31; motif length is d13 + h, _2_enumerate.jl:43) */
+#define MOTIFS_SCAN_MAX_LEN 64          /* longest PWM on the compile-time-length kernels.  NOT a cap (the reference has
+                                         * none: _h3_1_alignment.jl:25-31; motif length is d13 + h, _2_enumerate.jl:43):
+                                         * a longer bank is scanned by run-time-length kernels, same records, slower */
 #define MOTIFS_SCAN_BATCH 5000          /* batch_size_greedy, _h3_1_alignment.jl:12  */
 
 typedef struct motifs_ctx motifs_ctx;   /* opaque: device id, stream, workspaces */

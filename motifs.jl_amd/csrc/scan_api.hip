@@ -55,10 +55,6 @@ static int pack_bank(const uint16_t* pwms, const int64_t* lens, int K, int maxle
         minlen = std::min<int>(minlen, (int)lens[k]);
         maxtrue = std::max<int>(maxtrue, (int)lens[k]);
     }
-    if (maxtrue > MOTIFS_SCAN_MAX_LEN) {      // the padded third dimension (maxlen) may be anything
-        set_error("pwm bank: longest PWM has %d positions > MOTIFS_SCAN_MAX_LEN %d", maxtrue, MOTIFS_SCAN_MAX_LEN);
-        return MOTIFS_ERR_UNSUPPORTED;
-    }
     out.lenp = scan_len_padded(maxtrue);
     out.minlen = minlen;
     out.maxlen_true = maxtrue;
@@ -168,7 +164,7 @@ static void pack_mfma(const PackedBank& bank, const int64_t* lens, int K, MfmaBa
         }
         const double c = std::pow(1.0 + std::ldexp(1.0, -11), len) * std::ldexp(1.0, -11);
         eps[k] = (float)(1.001 * c * E / (1.0 - c * len) + std::ldexp((double)len, -24) + std::ldexp(A, -20));
-        if (A * 1.04 >= 60000.0) eps[k] = INFINITY;      // a partial sum may overflow binary16: keep every window
+        if (A * 1.04 >= 60000.0 || c * len >= 0.5) eps[k] = INFINITY;      // a partial sum may overflow binary16 (or the bound has no fixed point: len > ~900): keep every window
         eps_max = std::max(eps_max, eps[k]);
     }
     // The kernel wants "candidate" as a SET sign bit (its packing then needs no complement), so the operands are negated:
@@ -220,7 +216,7 @@ static void pack_mfma(const PackedBank& bank, const int64_t* lens, int K, MfmaBa
 static int bank_lenp(const int64_t* lens, int K) {
     int64_t mx = 0;
     for (int k = 0; lens && k < K; k++) mx = std::max<int64_t>(mx, lens[k]);
-    return mx > MOTIFS_SCAN_MAX_LEN ? -1 : scan_len_padded((int)std::max<int64_t>(mx, 1));
+    return scan_len_padded((int)std::max<int64_t>(mx, 1));
 }
 
 static int pick_cpb(int nch) {
@@ -359,6 +355,7 @@ static void scan_args(motifs_ctx* c, const BankSlot& bank, int K, const uint8_t*
     f.lim = (const int32_t*)bank.lim.p;
     f.N = ns;
     f.K = K;
+    f.L = L;
     f.lim_min = L - bank.maxlen_true;
     uint32_t d = (uint32_t)bank.nch, sh = 0;
     while ((1u << sh) < d) sh++;

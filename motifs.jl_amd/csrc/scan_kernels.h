@@ -63,6 +63,7 @@ struct FillArgs {
     const int32_t* lim;       // matrix-core path: last valid start per PWM
     int64_t N;                // reads in this super-batch (cells of later reads are empty)
     int K;
+    int L;                    // read length (matrix-core path; lens[k] = L - lim[k])
     int lim_min;              // starts <= lim_min are valid for every PWM
     // matrix-core path (stage_hits / emit_records): a (batch, l) line of cells is split into `parts` rows of `rpr` reads
     int parts, rpr;

@@ -483,7 +483,7 @@ int scan_len_padded(int maxlen) {
     static const int sizes[] = {8, 12, 16, 20, 24, 32, 40, 48, 64};   // > 32: matrix-core path only
     for (int s : sizes)
         if (maxlen <= s) return s;
-    return -1;
+    return (maxlen + 3) & ~3;                                         // > 64: the run-time-length kernels (scan_mfma.hip)
 }
 
 int scan_lout_padded(int Lout, int lenp) {

@@ -307,6 +307,68 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((T * PG <= 
     }
 }
 
+// Any PWM length (the reference has no cap: _h3_1_alignment.jl:25-31; motif length is d13 + h, _2_enumerate.jl:43, and grows
+// in the expansions of _h5): the k-steps of the contraction are a run-time loop, so the PWM fragments cannot live in
+// registers - they are re-read from L2 per step (16 bytes per lane and MFMA).  One read per wave, one tile of 32 PWMs per wave
+// (the PG = 1 cell layout of cand_read); the slack is the inline -4 of a scaled bank or the per-PWM row of cinit.  Not a
+// fast path - a bank this long is rare and its scan is bound by these loads - but no bank is refused.
+__global__ __launch_bounds__(256) void scan_cand_kernel_g(const uint4* __restrict__ afrag, const float* __restrict__ cinit,
+                                                          const uint8_t* __restrict__ codes, uint32_t* __restrict__ cells, const CandDims d,
+                                                          const int T, const int uniform_eps) {
+    extern __shared__ uint2 oh_all[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int w = lane & 31, h = lane >> 5;
+    const int wpb = blockDim.x >> 6;
+    uint2* oh = oh_all + (size_t)wave * ((d.ohlen + 3) & ~3);
+    const int tile = blockIdx.y;                                   // one tile of 32 PWMs per wave
+    if (tile >= d.used_tiles) return;
+    const int chunk = tile >> 2, word0 = tile & 3;
+    f32x16 c0;
+#pragma unroll
+    for (int r = 0; r < 16; r++) c0[r] = uniform_eps ? -4.0f : cinit[((size_t)tile * 2 + h) * 16 + r];
+    const uint4* af = afrag + (size_t)tile * T * 64 + lane;
+    const int ntile = (d.Lout + 31) / 32;
+    const size_t lstride4 = (size_t)d.batch * d.nch * 4;
+    for (int s = 0; s < d.spw; s++) {
+        const int64_t n = ((int64_t)blockIdx.x * d.spw + s) * wpb + wave;      // wave-uniform
+        if (n >= d.N) break;
+        const uint32_t* srow = (const uint32_t*)(codes + n * d.pitch);
+        for (int p4 = lane; p4 * 4 < d.ohlen; p4 += 64) {
+            const uint32_t wv = p4 * 4 < d.L ? srow[p4] : 0x04040404u;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int p = p4 * 4 + u;
+                const uint32_t c = p < d.L ? (wv >> (8 * u)) & 0xffu : 4u;
+                const uint64_t one = c < 4 ? (uint64_t)0x3c00u << (16 * c) : 0ull;
+                if (p < d.ohlen) oh[p] = make_uint2((uint32_t)one, (uint32_t)(one >> 32));
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int64_t bq = n / d.batch;
+        const size_t cell0 = ((size_t)bq * d.Lout * d.batch + (size_t)(n - bq * d.batch)) * d.nch + chunk;
+        uint32_t* cp = cells + cell0 * 4 + word0 + (size_t)w * lstride4;
+        const uint2* ohl = oh + w + 2 * h;
+        for (int wt = 0; wt < ntile; wt++) {
+            const int l0 = wt * 32;
+            f32x16 acc = c0;
+            for (int t = 0; t < T; t++) {
+                const uint2 a0 = ohl[l0 + 4 * t], a1 = ohl[l0 + 4 * t + 1];
+                const f16x8 B = __builtin_bit_cast(f16x8, make_uint4(a0.x, a0.y, a1.x, a1.y));
+                const f16x8 A = __builtin_bit_cast(f16x8, af[(size_t)t * 64]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, acc, 0, 0, 0);
+            }
+            uint32_t m = 0;
+#pragma unroll
+            for (int r = 15; r >= 0; r--) m = __builtin_amdgcn_alignbit(m, __float_as_uint(acc[r]), 31);
+            const auto s00 = __builtin_amdgcn_permlane32_swap(m, m, false, false);
+            if (l0 + w < d.Lout && h == 0) *cp = s00[0] | (s00[1] << 16);
+            cp += 32 * lstride4;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // ---- candidates -> records ---------------------------------------------------------------------------------
 // stage_hits: every WAVE takes rows of cells (a row = the (read, chunk) cells of a few reads at one start l),
 // pushes the set bits of a row into an LDS ring and re-scores the ring 64 candidates at a time in the
@@ -337,6 +399,14 @@ static __device__ __forceinline__ uint16_t exact_score(const _Float16* row, cons
     _Float16 acc = t[0];
 #pragma unroll
     for (int ind = 1; ind < LEN; ind++) acc = acc + t[ind];
+    return __builtin_bit_cast(uint16_t, acc);
+}
+// the same for a run-time length (banks past the template sizes): one byte load per position of THIS PWM (len = lens[k]: the
+// template form runs to the padded length, where the table holds +0 and the reads stay inside the guard bytes; here the padded
+// length has no bound, so the loop stops at the window's end), adds in the reference's order
+static __device__ __forceinline__ uint16_t exact_score_dyn(const _Float16* row, const uint8_t* win, int len) {
+    _Float16 acc = row[win[0]];
+    for (int ind = 1; ind < len; ind++) acc = acc + row[ind * 5 + win[ind]];
     return __builtin_bit_cast(uint16_t, acc);
 }
 // binary16 bits > 0, as `pos_scores > 0f0` decides it (_h3_1_alignment.jl:33): +Inf counts, NaN (an Inf - Inf of
@@ -499,11 +569,16 @@ static __device__ __forceinline__ bool score_candidate(const FillArgs& a, const 
     k = (ch * 4 + q) * 32 + i;
     sc = 0;
     if (!(live && nin < g.nvalid && (int)k < a.K && (g.l <= a.lim_min || g.l <= a.lim[k]))) return false;
-    uint32_t W[LEN / 4 + 1];
-    const uint32_t* sw = (const uint32_t*)(g.codes + __umul24(nin, (uint32_t)a.pitch));
+    if constexpr (LEN == 0) {      // run-time length: the window's bytes straight from the code row
+        const uint8_t* win = g.codes + (size_t)nin * (size_t)a.pitch + (g.l & 3);
+        sc = exact_score_dyn(tb + (size_t)k * (size_t)a.tabk_stride, win, a.L - a.lim[k]);
+    } else {
+        uint32_t W[LEN / 4 + 1];
+        const uint32_t* sw = (const uint32_t*)(g.codes + __umul24(nin, (uint32_t)a.pitch));
 #pragma unroll
-    for (int j = 0; j <= LEN / 4; j++) W[j] = sw[j];
-    sc = exact_score<LEN>(tb + __umul24(k, (uint32_t)a.tabk_stride), W, g.l);
+        for (int j = 0; j <= LEN / 4; j++) W[j] = sw[j];
+        sc = exact_score<LEN>(tb + __umul24(k, (uint32_t)a.tabk_stride), W, g.l);
+    }
     return half_pos(sc);
 }
 
@@ -517,7 +592,7 @@ static __device__ __forceinline__ bool score_candidate(const FillArgs& a, const 
 // should be.  Needs K % 8 == 0 (16-byte stores).
 constexpr int DWIN = 2048;        // halves per window (4 KB: four 16-byte stores per lane and flush; 2-3 % faster than 1 KB windows)
 template <int LEN, bool LDS_TAB, int MODE>
-__global__ __launch_bounds__(VF_THREADS) __attribute__((amdgpu_waves_per_eu(LEN <= 32 ? 8 : 4, 8))) void stage_hits(FillArgs a) {
+__global__ __launch_bounds__(VF_THREADS) __attribute__((amdgpu_waves_per_eu((LEN != 0 && LEN <= 32) ? 8 : 4, 8))) void stage_hits(FillArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: the row geometry stays on the scalar unit
     uint16_t* queue = (uint16_t*)smem + wv * QN;                      // [VF_WAVES][QN]
@@ -748,7 +823,26 @@ int cand_tile_group(int lenp) { return lenp <= 20 ? 4 : lenp <= 32 ? 2 : 1; }
 
 // ev0 / ev1 (optional): events that take the kernel's own start and stop time stamps (hipExtLaunchKernelGGL): timing the
 // dominant kernel then puts no extra packets on the stream (an event recorded before and after cost ~5 us each per launch)
+// run-time length: one tile per wave, as many waves per block as the one-hot images leave room for
+static hipError_t launch_cand_generic(const CandArgs& a, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
+    const size_t per_wave = (size_t)((a.d.ohlen + 3) & ~3) * 8;
+    int wpb = 4;
+    while (wpb > 1 && per_wave * wpb > 64 * 1024) wpb >>= 1;
+    if (per_wave * wpb > 160 * 1024 || a.d.used_tiles > 65535) return hipErrorInvalidValue;   // a read of > ~20k positions
+    CandDims d = a.d;
+    d.spw = (int)std::max<int64_t>(1, std::min<int64_t>(8, a.d.N * a.d.used_tiles / 65536));
+    const int64_t per_block = (int64_t)wpb * d.spw;
+    dim3 grid((unsigned)((d.N + per_block - 1) / per_block), (unsigned)d.used_tiles, 1);
+    const size_t lds = per_wave * wpb;
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute((const void*)scan_cand_kernel_g, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipExtLaunchKernelGGL(scan_cand_kernel_g, grid, dim3(64 * wpb), (uint32_t)lds, st, ev0, ev1, 0, a.afrag, a.cinit, a.codes, a.cells, d, a.lenp / 4,
+                          a.uniform_eps);
+    return hipGetLastError();
+}
+
 hipError_t launch_cand(const CandArgs& a, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
+    if (a.lenp > 64) return launch_cand_generic(a, st, ev0, ev1);
     switch (a.lenp) {
         case 8: return launch_cand_tp<2, 4>(a, st, ev0, ev1);
         case 12: return launch_cand_tp<3, 4>(a, st, ev0, ev1);
@@ -807,7 +901,7 @@ static hipError_t launch_emit_len(const FillArgs& a, hipStream_t st) {
         case 40: return CALL(40);           \
         case 48: return CALL(48);           \
         case 64: return CALL(64);           \
-        default: return hipErrorInvalidValue; \
+        default: return (lenp) > 64 ? CALL(0) : hipErrorInvalidValue;   /* LEN = 0: run-time length */ \
     }
 
 hipError_t launch_stage_hits(const FillArgs& a, int mode, hipStream_t st) {

@@ -99,12 +99,70 @@ def test_long_pwms_dense_tensor(torch_cuda, ctx, pkg, N, L, K, lo, hi):
     assert np.array_equal(dense.cpu().numpy().view(np.uint16), want.view(np.uint16))
 
 
-def test_pwm_longer_than_max_is_refused(ctx, pkg):
+# ---- no cap on the PWM length (_h3_1_alignment.jl:25-31 has none; round 2 refused more than 64 positions) ----
+VERY_LONG_CASES = [
+    # N, L, K, len_lo, len_hi, batch
+    (14, 160, 8, 65, 65, 5),        # one position past the last template size; K % 8 == 0: the streamed dense form too
+    (12, 200, 11, 66, 120, 5000),   # mixed lengths up to 120, odd K
+    (9, 260, 40, 20, 97, 4),        # short and very long PWMs in one bank (the short ones' windows end long before the padded length)
+    (6, 130, 130, 100, 128, 3),     # two chunks of 128 PWMs
+    (5, 104, 6, 88, 120, 5),        # PWMs nearly as long as the read (a few windows) and longer than it (none)
+]
+
+
+@pytest.mark.parametrize("N,L,K,lo,hi,batch", VERY_LONG_CASES)
+@pytest.mark.parametrize("rc", [False, True])
+def test_pwms_past_64_positions_match_oracle(torch_cuda, ctx, pkg, N, L, K, lo, hi, batch, rc):
+    """The run-time-length kernels (scan_cand_kernel_g, stage_hits<0>, emit_records<0>) against the literal restatement."""
     sy = pkg.synth
-    pwms, lens = sy.gen_pwm_bank(4, 1, len_lo=65, len_hi=65)
-    with pytest.raises(pkg._lib.MotifsError) as e:
-        ctx.pwm_scan(sy.pad_bank(pwms, lens), lens, sy.codes_to_onehot(sy.gen_codes(3, 80, 1)), pkg._lib.DATA_ONEHOT_F32, 3, 80, False)
-    assert e.value.code == pkg._lib.ERR_UNSUPPORTED
+    codes = sy.gen_codes(N, L, 1900 + N + K)
+    pwms, lens = sy.gen_pwm_bank(K, 1700 + K, len_lo=lo, len_hi=hi, alpha=0.5)
+    plant_consensus(codes, pwms, lens, 5 + K, frac=0.9)
+    codes[N // 3, L // 2] = 4
+    codes[N - 1, L - 1] = 4
+    bank = sy.pad_bank(pwms, lens)
+    h, s, counts = dev_scan_hits(torch_cuda, ctx, pkg, bank, lens, codes, rc, batch, want_counts=True)
+    oh, os_ = oracle_hits(pkg, bank, lens, codes, rc, batch)
+    assert len(oh) > 0
+    assert np.array_equal(h, oh), "hit records (m,n,l) or their order differ"
+    assert np.array_equal(s, os_), "fp16 scores differ"
+    assert np.array_equal(counts, np.bincount(oh[:, 0] - 1, minlength=K))
+
+
+@pytest.mark.parametrize("N,L,K,lo,hi", [(10, 160, 8, 65, 80), (8, 200, 11, 66, 120)])
+def test_pwms_past_64_positions_dense_tensor(torch_cuda, ctx, pkg, N, L, K, lo, hi):
+    torch = torch_cuda
+    lib, sy = pkg._lib, pkg.synth
+    codes = sy.gen_codes(N, L, 131 + K)
+    pwms, lens = sy.gen_pwm_bank(K, 117 + K, len_lo=lo, len_hi=hi, alpha=0.5)
+    plant_consensus(codes, pwms, lens, 12 + K, frac=0.9)
+    bank = sy.pad_bank(pwms, lens)
+    raw = torch.from_numpy(codes).cuda()
+    dcodes = torch.zeros(lib.Context.codes_bytes(N, L), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    ctx.encode_dev(raw.data_ptr(), lib.DATA_CODES_U8, N, L, dcodes.data_ptr())
+    ld = L - int(lens.min()) + 2
+    dense = torch.full((ld, N, K), 0x5555, dtype=torch.int16, device="cuda")
+    torch.cuda.synchronize()
+    ctx.pwm_scan_dense_dev(bank, lens, dcodes.data_ptr(), N, L, dense.data_ptr(), ld)
+    ctx.synchronize()
+    want = so.scan_gather(bank, lens, codes, Lout=ld)
+    assert (want > 0).sum() > 0
+    assert np.array_equal(dense.cpu().numpy().view(np.uint16), want.view(np.uint16))
+
+
+def test_host_entry_with_a_very_long_pwm(ctx, pkg):
+    """What round 2 refused with MOTIFS_ERR_UNSUPPORTED: the ccall entry on a bank of 65-position PWMs."""
+    sy = pkg.synth
+    codes = sy.gen_codes(30, 80, 1)
+    pwms, lens = sy.gen_pwm_bank(4, 1, len_lo=65, len_hi=65, alpha=0.5)
+    plant_consensus(codes, pwms, lens, 3, frac=1.0)
+    bank = sy.pad_bank(pwms, lens)
+    for rc in (False, True):
+        f, s = ctx.pwm_scan(bank, lens, sy.codes_to_onehot(codes), pkg._lib.DATA_ONEHOT_F32, 30, 80, rc)
+        of, os_ = so.get_pos_scores_arr(bank, lens, sy.codes_to_onehot(codes), rc=rc)
+        assert np.array_equal(f, of) and np.array_equal(s.view(np.uint16), os_.view(np.uint16))
+    assert len(f) + 1 > 0
 
 
 # ---- the super-batch chain (scan_api.hip: launch_no > 0, ping-pong totals, n0 + s0) ----
