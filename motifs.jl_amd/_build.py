@@ -29,8 +29,21 @@ def _newer(src_paths, out):
     return any(os.path.getmtime(p) > t for p in src_paths)
 
 
-def build(verbose=True, force=False):
+def build(verbose=True, force=False, defs=None, out=None):
+    """defs / out: an experimental build beside the shipped one (A/B timing through MOTIFS_HIP_LIB): extra -D flags, another
+    library path; its objects go to their own directory."""
+    global OBJ, LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    obj_dir, lib_path = OBJ, LIB
+    if defs or out:
+        assert out, "an experimental build needs its own output path"
+        lib_path = os.path.abspath(out)
+        obj_dir = os.path.join(CSRC, "_obj_" + os.path.basename(lib_path).replace(".so", ""))
+        force = True
+    return _build(hipcc, obj_dir, lib_path, list(defs or []), verbose, force)
+
+
+def _build(hipcc, OBJ, LIB, defs, verbose, force):
     os.makedirs(OBJ, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(HERE, "..", "include", "motifs_hip.h"))
@@ -42,7 +55,7 @@ def build(verbose=True, force=False):
         obj = os.path.join(OBJ, f[:-4] + ".o")
         objs.append(obj)
         if force or _newer([src] + headers, obj):
-            cmd = [hipcc] + COMMON + EXTRA.get(f, []) + ["-c", src, "-o", obj]
+            cmd = [hipcc] + COMMON + defs + EXTRA.get(f, []) + ["-c", src, "-o", obj]
             if verbose:
                 print("[build]", " ".join(cmd), file=sys.stderr, flush=True)
             subprocess.check_call(cmd)
@@ -55,4 +68,7 @@ def build(verbose=True, force=False):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    # python motifs.jl_amd/_build.py [--force] [--out path.so -DNAME=1 ...]
+    args = [a for a in sys.argv[1:] if a != "--force"]
+    out = args[args.index("--out") + 1] if "--out" in args else None
+    build(force="--force" in sys.argv, defs=[a for a in args if a.startswith("-D")], out=out)
