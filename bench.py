@@ -33,7 +33,9 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_F16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak (no sparsity)
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_scan_hbm_traffic.json")   # written by tools/pmc_scan.sh
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32-input matrix peak (= vector peak), v_mfma_f32_32x32x2_f32
+# PMC traffic per (kernel, launch shape), written by tools/summarize_traffic.py from the passes of tools/profile_round.sh
+TRAFFIC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r03_scan_hbm_traffic.json", "r02_scan_hbm_traffic_by_shape.json")]
 
 
 def parse():
@@ -54,6 +56,7 @@ def parse():
     ap.add_argument("--no-train", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="only the timed scan (+ train): skip dense / consumers / host-entry legs")
+    ap.add_argument("--no-big", action="store_true", help="skip the configs[3] / configs[4] shard-shape legs")
     return ap.parse_args()
 
 
@@ -186,6 +189,15 @@ def main():
     # five steps after an idle spell).  A fixed untimed pre-heat precedes the W warm-up steps so that the K timed steps
     # measure the steady state whatever W is.
     PREHEAT = 40
+    # ... and the other clock, for the record: the first five steps after the set-up and half a second of idling, each
+    # waited for on its own (what a caller who scans once sees)
+    time.sleep(0.5)
+    cold = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        scan_step(weak)
+        sync()
+        cold.append((time.perf_counter() - t0) * 1e3)
     for _ in range(PREHEAT):
         scan_step(weak)
     for _ in range(args.warmup):
@@ -217,20 +229,24 @@ def main():
     strong = None
     if world > 1:
         all_codes = sy.gen_codes(N, L, seed, n_plant=5, k=PL)          # the rank-0 shard of the weak run, on every rank
-        lo, hi = par.shard_range(N, rank, world, align=lib.SCAN_BATCH)
-        sh = make_shard(np.ascontiguousarray(all_codes[lo:hi]), lo)
-        for _ in range(PREHEAT + args.warmup):
-            scan_step(sh)
-        sdt, sh_hits = timed_region(lambda: scan_step(sh), args.steps, sync, barrier)
-        sdt = float(par.host_all_reduce(torch.tensor([sdt], dtype=torch.float64), dist.ReduceOp.MAX).item())
-        sizes = [b - a for a, b in (par.shard_range(N, r, world, align=lib.SCAN_BATCH) for r in range(world))]
-        strong = {"value": float(N) * L * args.steps / sdt, "unit": "bases/s", "ms_per_step": sdt / args.steps * 1e3,
-                  "scaling": "strong", "seqs_total": N, "shard_sizes": sizes,
-                  "hist_total_hits": int(sh["counts"].sum().item()),
-                  "note": "BASELINE configs[2]: the same reads split on whole 5000-read ordering batches, so that the records "
-                          "concatenated in rank order are the single-device records; the step is launch- and host-wait-bound at "
-                          "these shard sizes"}
-        del sh, all_codes
+        modes = {}
+        for mode, align in (("ordering_batches", lib.SCAN_BATCH), ("even", 1)):
+            lo, hi = par.shard_range(N, rank, world, align=align)
+            sh = make_shard(np.ascontiguousarray(all_codes[lo:hi]), lo)
+            for _ in range(PREHEAT + args.warmup):
+                scan_step(sh)
+            sdt, sh_hits = timed_region(lambda: scan_step(sh), args.steps, sync, barrier)
+            sdt = float(par.host_all_reduce(torch.tensor([sdt], dtype=torch.float64), dist.ReduceOp.MAX).item())
+            sizes = [b - a for a, b in (par.shard_range(N, r, world, align=align) for r in range(world))]
+            modes[mode] = {"value": float(N) * L * args.steps / sdt, "unit": "bases/s", "ms_per_step": sdt / args.steps * 1e3,
+                           "shard_align": align, "shard_sizes": sizes, "hist_total_hits": int(sh["counts"].sum().item())}
+            del sh
+        strong = dict(modes["even"], scaling="strong", seqs_total=N, modes=modes,
+                      note="BASELINE configs[2]: the same reads split over the ranks.  'even' (shard_align 1): 12 500 reads per rank at 8 ranks; "
+                           "the concatenated records are in sequence-block-major order and give the single-device dictionaries of modify_w_found! "
+                           "(_h3_1_alignment.jl:38-52).  'ordering_batches' (shard_align 5000): the concatenation is the single-device record list "
+                           "bit for bit, but 20 batches over 8 ranks split 3,3,3,3,2,2,2,2.  The value quoted is the even mode's")
+        del all_codes
     else:
         strong = {"value": float(N) * L * args.steps / dt, "unit": "bases/s", "ms_per_step": dt / args.steps * 1e3, "scaling": "strong",
                   "seqs_total": N, "shard_sizes": [N], "note": "N = 1: the same workload as the headline line"}
@@ -382,6 +398,75 @@ def main():
                                       "host_threads": min(32, os.cpu_count() or 1),
                                       "note": "motifs_fasta_read, query + fill call (the file is parsed twice), page-cache resident file"}
 
+    # ---- BASELINE configs[3] and configs[4] at the shape of ONE rank's shard of the 8-GPU job (untimed side legs, rank 0) ----
+    if not args.no_extras and rank == 0 and not args.no_big:
+
+        def shard_leg(tag, n_, L_, K_, len_lo, len_hi, ws_limit, note):
+            pw, ln = sy.gen_pwm_bank(K_, seed + 7, len_lo=len_lo, len_hi=len_hi, alpha=0.3)
+            bk = sy.pad_bank(pw, ln)
+            cd = sy.gen_codes(n_, L_, seed + 31, n_plant=5, k=len_hi)
+            raw_ = torch.from_numpy(cd).to(dev)
+            dc_ = torch.zeros(lib.Context.codes_bytes(n_, L_), dtype=torch.uint8, device=dev)
+            ctx.encode_dev(raw_.data_ptr(), lib.DATA_CODES_U8, n_, L_, dc_.data_ptr())
+            del raw_
+            ctx.set_workspace_limit(ws_limit)
+            need_ = ctx.pwm_scan_hits_both_dev(bk, ln, dc_.data_ptr(), n_, L_, None, None, 0)
+            cap_ = int(max(need_)) + 1024
+            h_ = [torch.empty((cap_, 3), dtype=torch.int32, device=dev) for _ in range(2)]
+            s_ = [torch.empty(cap_, dtype=torch.int16, device=dev) for _ in range(2)]
+            k_ = torch.zeros((2, K_), dtype=torch.int64, device=dev)
+
+            def one():
+                return ctx.pwm_scan_hits_both_dev(bk, ln, dc_.data_ptr(), n_, L_, [x.data_ptr() for x in h_], [x.data_ptr() for x in s_], cap_,
+                                                  counts_ptr=k_.data_ptr())
+            for _ in range(2):
+                got_ = one()
+            ctx.enable_timing(slots=[lib.KS_SCAN_COUNT])
+            ctx.reset_timing()
+            reps_ = 3
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(reps_):
+                got_ = one()
+            sync()
+            leg_dt = (time.perf_counter() - t0) / reps_
+            cms, cn = ctx.kernel_ms(lib.KS_SCAN_COUNT)
+            ctx.enable_timing(False)
+            ctx.set_workspace_limit(0)
+            assert tuple(got_) == tuple(need_), (got_, need_)
+            assert int(k_.sum().item()) == sum(got_)                           # histogram == records, both strands
+            # records of every ordering batch in findall order (l slowest) - a full-size, size-independent property
+            f0 = h_[0][: got_[0]]
+            bq_ = torch.div(f0[:, 1] - 1, lib.SCAN_BATCH, rounding_mode="floor").to(torch.int64)
+            key_ = (bq_ * (L_ + 1) + f0[:, 2].to(torch.int64)) * lib.SCAN_BATCH + (f0[:, 1].to(torch.int64) - 1) % lib.SCAN_BATCH
+            key_ = key_ * (K_ + 1) + f0[:, 0].to(torch.int64)
+            assert bool((key_[1:] > key_[:-1]).all()), "records are not in the reference's order"
+            del key_, bq_
+            windows = float(n_) * float(np.sum(L_ - ln + 1))                   # (PWM, start) pairs per strand
+            flops = 2.0 * 4.0 * float(n_) * float(np.sum((L_ - ln + 1) * ln))  # 2 * 4 * len_k flop per pair (GEMM form)
+            per_launch_ms = cms / max(cn, 1)
+            launches_per_strand = cn / (2 * reps_)
+            tfl = flops / (cms / (2 * reps_) * 1e-3) / 1e12                    # over all candidate launches of one strand
+            out_ = {
+                "workload": note, "seqs": n_, "seq_len": L_, "pwms": K_, "pwm_len": [int(ln.min()), int(ln.max())],
+                "ms_per_step_both_strands": leg_dt * 1e3, "bases_per_s": n_ * L_ / leg_dt, "hits_per_step": int(sum(got_)),
+                "pwm_window_pairs_per_strand": windows, "workspace_limit_bytes": int(ws_limit),
+                "candidate_launches_per_strand": launches_per_strand,
+                "roofline": {"kernel": "scan_cand_kernel_* (the launches of one strand pass, summed)", "bound": "mfma", "achieved": tfl,
+                             "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfl / MFMA_F16_PEAK_TFLOPS, "flops_per_strand": flops,
+                             "avg_launch_ms": per_launch_ms, "traffic": None},
+                "checked": "both strands: totals == the count-only pass, histogram == records, forward records strictly ascending in "
+                           "(batch, l, n, m): the reference's order",
+            }
+            del h_, s_, dc_, k_
+            torch.cuda.empty_cache()
+            return out_
+        extras["cfg3_shard"] = shard_leg("cfg3", 62_500, 500, 512, 20, 20, 0,
+                                         "BASELINE configs[3], one rank's shard of 8: 62 500 seqs x 500 bp vs 512 PWMs len 20, both strands, ordered records")
+        extras["cfg4_shard"] = shard_leg("cfg4", 25_000, 1000, 2048, 8, 20, 4 << 30,
+                                         "BASELINE configs[4] at a fifth of one rank's shard of 8: 25 000 seqs x 1000 bp vs 2048 PWMs len 8-20 (mixed), both strands, "
+                                         "ordered records; workspace bound 4 GiB so that a strand crosses three super-batch launches")
+
     # ---- conv-train step (BASELINE metric, second half): unrolled-ADMM forward/backward + AdaBelief ----
     train = None
     if not args.no_train:
@@ -412,6 +497,10 @@ def main():
         a4_ms = cdl.model.time_filter_scan(tdev.data_ptr(), Gt, reps=10)
         c_rows = L - args.filter_len + 1
         a4_bytes = St * (L + 2 * c_rows * args.filters * 4)
+        # a7's dense contraction on its own ("MFMA fraction is computed on the syntax-layer GEMM flops", f32 matrix peak)
+        a7_ms = cdl.model.time_syntax_conv(tdev.data_ptr(), Gt, reps=10)
+        l_rows = c_rows - hp.h + 1
+        a7_flops = 2.0 * St * l_rows * hp.K * hp.h * 2 * args.filters
         # the reference's own schedule: one optimiser step per 6-read mini-batch (train.jl:40-46)
         for _ in range(3):
             tstep(1)
@@ -432,6 +521,14 @@ def main():
                 "bound": "hbm", "achieved": a4_bytes / (a4_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": a4_bytes / (a4_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_launch_ms": a4_ms, "algorithmic_bytes": a4_bytes,
                 "reads_per_launch": St, "bases_per_s": St * L / (a4_ms * 1e-3),
+            },
+            "roofline": {
+                "kernel": "k_ana_lds (a7: conv(ZY, F, flipped=true), model.jl:214,251, on v_mfma_f32_32x32x2_f32; rows = reads x l, columns = K, "
+                          "reduction = h * 2M)",
+                "bound": "mfma", "achieved": a7_flops / (a7_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": a7_flops / (a7_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, "avg_launch_ms": a7_ms, "flops_per_launch": a7_flops,
+                "reads_per_launch": St, "traffic": None,
+                "note": "algorithmic flops 2 * l * K * h * 2M per read (SURVEY 8d); the kernel pads K 24 -> 32 and l 178 -> 192",
             },
             "loss_first_group": float(tloss[0].item()),
             "grad_allreduce_floats": int(cdl.model.nP) if world > 1 else 0,
@@ -469,11 +566,17 @@ def main():
     cand_flops = 2.0 * 4 * PL * K * float(N) * Lout
     cand_tflops = cand_flops / (cand_ms * 1e-3) / 1e12
     traffic, traffic_src = None, None
-    if os.path.exists(TRAFFIC_FILE) and (N, L, K, PL) == (100_000, 200, 200, 12):
-        with open(TRAFFIC_FILE) as fh:
-            tj = json.load(fh)
-        traffic = tj.get("scan_cand_kernel", {}).get("hbm_bytes_per_launch")
-        traffic_src = {"file": os.path.relpath(TRAFFIC_FILE, ROOT), "commit": tj.get("commit"), "command": tj.get("command")}
+    # the PMC entry of the launch that was timed: same kernel, same grid (blocks of 8 reads, tools/summarize_traffic.py keys by shape)
+    cand_blocks = (N + 7) // 8
+    for tf in TRAFFIC_FILES:
+        if traffic is None and os.path.exists(tf) and (N, L, K, PL) == (100_000, 200, 200, 12):
+            with open(tf) as fh:
+                tj = json.load(fh)
+            for e in tj.get("launches", []):
+                if e["kernel"].startswith("scan_cand_kernel") and e["blocks"] == cand_blocks:
+                    traffic = e["hbm_bytes_per_launch"]
+                    traffic_src = {"file": os.path.relpath(tf, ROOT), "commit": tj.get("commit"), "command": tj.get("command"),
+                                   "kernel": e["kernel"], "blocks": e["blocks"], "launches_averaged": e["launches"]}
     out = {
         "metric": "bases scanned/sec",
         "value": value,
@@ -482,6 +585,8 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3,
+        "cold_start_ms_per_step": sum(cold) / len(cold),
+        "cold_start_ms_each": cold,
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -550,8 +655,8 @@ def main():
         if best is not None:
             assert c_hits == g_ns, "vectorised CPU port and GPU disagree on the sample"
             out["cpu_baseline"] = {
-                "value": ns * L / best, "unit": "bases/s", "cores": so.num_threads(), "kind": "port",
-                "sample": f"first {ns} sequences x {L} bp, both strands; AVX2/F16C port of the reference arithmetic (8 PWMs per register, "
+                "value": ns * L / best, "unit": "bases/s", "cores": so.num_threads(), "physical_cores": so.physical_cores(), "kind": "port",
+                "sample": f"first {ns} sequences x {L} bp, both strands; AVX2/F16C port of the reference arithmetic (8 PWMs per register, 5-8 independent chains in flight, "
                           f"binary16 rounding after every add, records in findall order), OpenMP, 1 warm-up + best of 3: {best:.2f} s; "
                           f"hits {c_hits} == GPU on the same reads",
                 "literal": {"value": nl * L / ldt, "unit": "bases/s", "kind": "port-literal", "cores": so.num_threads(),

@@ -260,6 +260,10 @@ int motifs_model_retrieve_codes(motifs_model* m, const void* data, int kind, int
  * with the filter bank (model.jl:171-173), one Toeplitz GEMM over the expanded bank -- launched `reps` times for
  * n_groups mini-batches; *ms_out = average device time per launch (HIP events on the context's stream). */
 int motifs_model_time_filter_scan(motifs_model* m, const uint8_t* codes_dev, int n_groups, int reps, float* ms_out);
+/* Measurement hook (bench.py, SURVEY.md 8d "MFMA fraction is computed on the syntax-layer GEMM"): a7's dense contraction alone --
+ * conv(ZY, F, flipped=true) of model.jl:214,251: rows = reads x l, columns = K, reduction = h * 2M, 2 * l * K * h * 2M flop per
+ * read -- launched `reps` times for n_groups mini-batches; *ms_out = average device time per launch. */
+int motifs_model_time_syntax_conv(motifs_model* m, const uint8_t* codes_dev, int n_groups, int reps, float* ms_out);
 /* Test hook: a named intermediate of the last loss_grad call made with keep_intermediates != 0. */
 int motifs_model_dump(motifs_model* m, const char* name, float* out, int64_t cap, int64_t* n);
 

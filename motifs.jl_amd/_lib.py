@@ -113,6 +113,7 @@ SIGNATURES = {
     "motifs_model_dp_train_step_dev": (_int, [_p, _p, _p, _int, _i64, _p, _p]),
     "motifs_model_retrieve_codes": (_int, [_p, _p, _int, _i64, _p, _i64, C.POINTER(_i64)]),
     "motifs_model_time_filter_scan": (_int, [_p, _p, _int, _int, C.POINTER(C.c_float)]),
+    "motifs_model_time_syntax_conv": (_int, [_p, _p, _int, _int, C.POINTER(C.c_float)]),
     "motifs_model_dump": (_int, [_p, C.c_char_p, _p, _i64, C.POINTER(_i64)]),
     "motifs_fasta_read": (_int, [C.c_char_p, _i64, _p, _i64, C.POINTER(_i64), C.POINTER(C.c_int32)]),
     "motifs_hits_minmax_dev": (_int, [_p, _p, _p, _i64, _int, _p, _p]),
@@ -515,6 +516,12 @@ class Model:
         """Average device ms of a4 (warmup_ZY's filter-bank scan) alone, a measurement hook for bench.py."""
         ms = C.c_float(0)
         check(lib().motifs_model_time_filter_scan(self._h, _p(codes_ptr), int(n_groups), int(reps), C.byref(ms)))
+        return ms.value
+
+    def time_syntax_conv(self, codes_ptr, n_groups, reps=5):
+        """Average device ms of a7's dense contraction (the syntax-layer analysis GEMM) alone, a measurement hook for bench.py."""
+        ms = C.c_float(0)
+        check(lib().motifs_model_time_syntax_conv(self._h, _p(codes_ptr), int(n_groups), int(reps), C.byref(ms)))
         return ms.value
 
     def dump(self, name):

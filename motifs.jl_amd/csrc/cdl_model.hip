@@ -996,6 +996,49 @@ int motifs_model_time_filter_scan(motifs_model* m, const uint8_t* codes_dev, int
     return MOTIFS_OK;
 }
 
+// Measurement hook: a7's dense contraction (warmup_X / update_X's conv(ZY, F, flipped=true), model.jl:214,251) on its own:
+// the syntax-layer analysis GEMM of n_groups mini-batches, rows = reads x l, columns = K, reduction = h * 2M.
+int motifs_model_time_syntax_conv(motifs_model* m, const uint8_t* codes_dev, int n_groups, int reps, float* ms_out) {
+    int r = check_model(m, "motifs_model_time_syntax_conv");
+    if (r) return r;
+    if (!codes_dev || !ms_out || n_groups < 1 || reps < 1 || (int64_t)n_groups * m->B > 65535) return MOTIFS_ERR_INVALID;
+    MOTIFS_HIP_CHECK(hipSetDevice(m->ctx->device));
+    Engine& e = m->eng;
+    e.st = m->ctx->stream;
+    e.reset();
+    e.recording = false;
+    e.keep_named = false;
+    Graph gr(m, n_groups);
+    gr.Sone = make_onehot(m, codes_dev, gr.S);
+    Tensor Draw = e.wrap(m->params, nullptr, m->nD, false), Fraw = e.wrap(m->params + m->nD, nullptr, m->nF, false);
+    Tensor Dp = e.norm4(e.lin(gr.sq(Draw), 1.0f, nullptr, 0.0f, 0.001f));
+    Tensor Fp = e.norml2(gr.sq(Fraw), m->h * m->twoM);
+    Graph::Bank bD = gr.bankD(Dp, 1), bF = gr.bankF(Fp, 1);
+    Tensor ZY = gr.anaD(gr.Sone, bD);                 // an image of the right shape and scale: [S][c][2M]
+    (void)gr.anaF(ZY, bF);                            // warm-up: the bank's fragment re-layout is built here
+    const size_t mark = e.arena.off;
+    hipEvent_t e0, e1;
+    MOTIFS_HIP_CHECK(hipEventCreate(&e0));
+    MOTIFS_HIP_CHECK(hipEventCreate(&e1));
+    MOTIFS_HIP_CHECK(hipEventRecord(e0, e.st));
+    for (int i = 0; i < reps; i++) {
+        e.arena.off = mark;
+        (void)gr.anaF(ZY, bF);
+    }
+    MOTIFS_HIP_CHECK(hipEventRecord(e1, e.st));
+    MOTIFS_HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0;
+    MOTIFS_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (e.failed) {
+        set_error("engine arena exhausted during motifs_model_time_syntax_conv");
+        return MOTIFS_ERR_UNSUPPORTED;
+    }
+    *ms_out = ms / (float)reps;
+    return MOTIFS_OK;
+}
+
 // Test hook: copy a named intermediate of the last motifs_model_loss_grad_dev(keep_intermediates=1) call.
 int motifs_model_dump(motifs_model* m, const char* name, float* out, int64_t cap, int64_t* n) {
     int r = check_model(m, "motifs_model_dump");

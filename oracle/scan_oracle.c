@@ -222,7 +222,8 @@ void oracle_scan_gather(const uint16_t* pwms, const int64_t* lens, int K, const 
  * The optimised CPU form of oracle_get_pos_scores_arr: what a careful CPU implementation of the SAME arithmetic
  * looks like (bench.py's cpu_baseline, kind "port"; the literal loop above stays as "port-literal").
  *   - gather form (one add per PWM position: the three w*0 = +-0 terms of :28-29 are exact no-ops);
- *   - 8 PWMs per AVX register, binary16 adds as binary32 add + VCVTPS2PH (round to nearest even) + VCVTPH2PS:
+ *   - 8 PWMs per AVX register, 5-8 registers (independent chains) in flight, binary16 adds as binary32 add + VCVTPS2PH
+ *     (round to nearest even) + VCVTPH2PS:
  *     the binary32 sum of two binary16 values rounded again to binary16 is the correctly rounded binary16 sum
  *     (24 >= 2*11 + 2), i.e. the same bits as h_add, in the same order (ind ascending);
  *   - no dense (K, nb, 4L) tensor: threads own ranges of start positions l of a batch and append their hits, the
@@ -231,6 +232,7 @@ void oracle_scan_gather(const uint16_t* pwms, const int64_t* lens, int K, const 
  * or -1 when the CPU lacks AVX2/F16C (the caller falls back to the literal form).
  */
 #include <immintrin.h>
+#define FAST_CHAINS 8
 
 typedef struct {
     oracle_hit* h;
@@ -258,22 +260,44 @@ __attribute__((target("avx2,f16c"))) static void scan_rows_f16c(const float* wt,
     for (int l = l_lo; l < l_hi; l++) {
         for (int64_t n = 0; n < nb; n++) {
             const uint8_t* s = codes + (n0 + n) * L;
-            for (int g0 = 0; g0 < ng; g0 += 4) {       /* four independent chains of 8 PWMs hide the add+convert latency */
-                __m256 acc[4];
-                const int gn = ng - g0 < 4 ? ng - g0 : 4;
-                for (int j = 0; j < 4; j++) acc[j] = _mm256_setzero_ps();
+            for (int g0 = 0, gn = 0; g0 < ng; g0 += gn) {
+                /* gn independent chains of 8 PWMs at a time: an add step is add + 2 converts (~15 cycles of latency), so 5-8
+                 * chains in flight keep the ports busy where 4 left them idle most of the time; the groups of a bank are dealt out
+                 * evenly (25 groups = 7 + 6 + 6 + 6) so that no block runs with a single chain */
+                const int nblk = (ng + FAST_CHAINS - 1) / FAST_CHAINS, left = nblk - g0 * nblk / ng;   /* blocks still to go */
+                gn = (ng - g0 + left - 1) / (left > 0 ? left : 1);
+                if (gn > FAST_CHAINS) gn = FAST_CHAINS;
+                if (gn > ng - g0) gn = ng - g0;
+                __m256 acc[FAST_CHAINS];
+                for (int j = 0; j < FAST_CHAINS; j++) acc[j] = _mm256_setzero_ps();
                 const int span = L - l < maxlen ? L - l : maxlen;   /* positions past the read are never added: l <= L - len is checked below */
-                for (int ind = 0; ind < span; ind++) {
-                    const int b = s[l + ind];
-                    if (b >= 4) continue;
-                    const float* w = wt + ((size_t)ind * 4 + b) * Kp + (size_t)g0 * 8;
-                    for (int j = 0; j < gn; j++) {
-                        const __m256 sum = _mm256_add_ps(acc[j], _mm256_loadu_ps(w + 8 * j));
-                        const __m256 r = _mm256_cvtph_ps(_mm256_cvtps_ph(sum, _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC));
-                        if (uniform) acc[j] = r;
-                        else acc[j] = _mm256_blendv_ps(acc[j], r, _mm256_loadu_ps(lenmask + (size_t)ind * Kp + (size_t)(g0 + j) * 8));
+#define CHAIN_BLOCK(N)                                                                                                   \
+    for (int ind = 0; ind < span; ind++) {                                                                               \
+        const int b = s[l + ind];                                                                                        \
+        if (b >= 4) continue;                                                                                            \
+        const float* w = wt + ((size_t)ind * 4 + b) * Kp + (size_t)g0 * 8;                                               \
+        _Pragma("GCC unroll 8") for (int j = 0; j < N; j++)                                                              \
+            acc[j] = _mm256_cvtph_ps(_mm256_cvtps_ph(_mm256_add_ps(acc[j], _mm256_loadu_ps(w + 8 * j)),                  \
+                                                      _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC));                  \
+    }
+                if (uniform && gn == 8) { CHAIN_BLOCK(8) }
+                else if (uniform && gn == 7) { CHAIN_BLOCK(7) }
+                else if (uniform && gn == 6) { CHAIN_BLOCK(6) }
+                else if (uniform && gn == 5) { CHAIN_BLOCK(5) }
+                else {
+                    for (int ind = 0; ind < span; ind++) {
+                        const int b = s[l + ind];
+                        if (b >= 4) continue;
+                        const float* w = wt + ((size_t)ind * 4 + b) * Kp + (size_t)g0 * 8;
+                        for (int j = 0; j < gn; j++) {
+                            const __m256 sum = _mm256_add_ps(acc[j], _mm256_loadu_ps(w + 8 * j));
+                            const __m256 r = _mm256_cvtph_ps(_mm256_cvtps_ph(sum, _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC));
+                            if (uniform) acc[j] = r;
+                            else acc[j] = _mm256_blendv_ps(acc[j], r, _mm256_loadu_ps(lenmask + (size_t)ind * Kp + (size_t)(g0 + j) * 8));
+                        }
                     }
                 }
+#undef CHAIN_BLOCK
                 for (int j = 0; j < gn; j++) {
                     const int pos = _mm256_movemask_ps(_mm256_cmp_ps(acc[j], _mm256_setzero_ps(), _CMP_GT_OQ));
                     if (!pos) continue;

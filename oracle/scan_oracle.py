@@ -125,6 +125,23 @@ def num_threads():
     return lib().oracle_num_threads()
 
 
+def physical_cores():
+    """Distinct physical cores among the CPUs this process may run on (two SMT siblings share one set of vector ports, so
+    the thread count overstates what the baseline had)."""
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        cpus = list(range(os.cpu_count() or 1))
+    seen = set()
+    for c in cpus:
+        try:
+            with open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list") as fh:
+                seen.add(fh.read().strip())
+        except OSError:
+            seen.add(str(c))
+    return len(seen)
+
+
 def greedy_search_numpy(pwms, lens, data16):
     """Pure-numpy restatement of greedy_search! (:18-36) with numpy's Float16
     arithmetic (correctly rounded per operation).  Small cases only."""

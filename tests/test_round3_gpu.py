@@ -308,3 +308,68 @@ def test_rccl_reducer_orders_an_operand_from_another_stream(torch_cuda, pkg):
         comm.close()
     finally:
         c.close()
+
+
+# ---- BASELINE configs[3] / configs[4] at the size of one rank's shard: properties that do not need the oracle at full size ----
+def _full_size_shard(torch, pkg, ctx, n, L, K, len_lo, len_hi, ws_limit, sample):
+    lib, sy = pkg._lib, pkg.synth
+    pwms, lens = sy.gen_pwm_bank(K, 4711 + K, len_lo=len_lo, len_hi=len_hi, alpha=0.3)
+    bank = sy.pad_bank(pwms, lens)
+    codes = sy.gen_codes(n, L, 4712 + K, n_plant=5, k=len_hi)
+    codes[7, 11] = 4
+    raw = torch.from_numpy(codes).cuda()
+    dcodes = torch.zeros(lib.Context.codes_bytes(n, L), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    ctx.encode_dev(raw.data_ptr(), lib.DATA_CODES_U8, n, L, dcodes.data_ptr())
+    del raw
+    ctx.set_workspace_limit(ws_limit)
+    try:
+        need = ctx.pwm_scan_hits_both_dev(bank, lens, dcodes.data_ptr(), n, L, None, None, 0)
+        cap = max(need)
+        hits = [torch.empty((cap, 3), dtype=torch.int32, device="cuda") for _ in range(2)]
+        hsc = [torch.empty(cap, dtype=torch.int16, device="cuda") for _ in range(2)]
+        cnt = torch.zeros((2, K), dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        got = ctx.pwm_scan_hits_both_dev(bank, lens, dcodes.data_ptr(), n, L, [h.data_ptr() for h in hits], [s.data_ptr() for s in hsc], cap,
+                                         counts_ptr=cnt.data_ptr())
+        ctx.synchronize()
+    finally:
+        ctx.set_workspace_limit(0)
+    assert got == need and min(got) > 100_000
+    B = lib.SCAN_BATCH
+    for rc in (0, 1):
+        f = hits[rc][: got[rc]].to(torch.int64)
+        m, nn, l = f[:, 0], f[:, 1], f[:, 2]
+        assert int(m.min()) >= 1 and int(m.max()) <= K and int(nn.min()) >= 1 and int(nn.max()) <= n and int(l.min()) >= 1
+        lens_t = torch.from_numpy(lens).cuda()
+        assert bool((l <= L - lens_t[m - 1] + 1).all())                               # every window lies inside its read
+        assert bool((hsc[rc][: got[rc]] > 0).all())                                   # binary16 bits of a positive score
+        key = (((nn - 1) // B * (L + 1) + l) * B + (nn - 1) % B) * (K + 1) + m        # (batch, l, n, m): findall's order per batch
+        assert bool((key[1:] > key[:-1]).all()), "records are not in the reference's order"
+        assert torch.equal(torch.bincount(m - 1, minlength=K), cnt[rc])               # the histogram is the records'
+        # sampled reads against the CPU port: every record of the read, scores included
+        hs = hsc[rc][: got[rc]]
+        for r0 in sample:
+            sel = (nn > r0) & (nn <= r0 + 3)
+            mine = torch.stack([m[sel], nn[sel], l[sel]], dim=1).cpu().numpy().astype(np.uint32)
+            mys = hs[sel].cpu().numpy().view(np.uint16)
+            oh, os_ = fast_oracle_hits(bank, lens, codes[r0:r0 + 3], bool(rc), B)
+            oh = oh.copy()
+            oh[:, 1] += r0
+            # the oracle saw these three reads as a batch of their own: same records, (l, n, m) order within it
+            order = np.lexsort((mine[:, 0], mine[:, 1], mine[:, 2]))
+            assert np.array_equal(mine[order], oh) and np.array_equal(mys[order], os_), (rc, r0)
+        del f, m, nn, l, key
+    return got
+
+
+def test_cfg3_shard_full_size_properties(torch_cuda, ctx, pkg):
+    """62 500 reads x 500 bp vs 512 PWMs of 20 positions: one rank's shard of BASELINE configs[3] (13 ordering batches, one launch)."""
+    _full_size_shard(torch_cuda, pkg, ctx, 62_500, 500, 512, 20, 20, 0, sample=(0, 4998, 31_249, 62_497))
+
+
+def test_cfg4_shard_full_size_properties(torch_cuda, ctx, pkg):
+    """25 000 reads x 1000 bp vs 2048 PWMs of 8-20 positions (a fifth of one rank's shard of BASELINE configs[4]) under a 4 GiB
+    workspace bound: each strand crosses three super-batch launches (2 + 2 + 1 ordering batches), the running total chained on
+    the device; samples sit on both sides of the launch edges."""
+    _full_size_shard(torch_cuda, pkg, ctx, 25_000, 1000, 2048, 8, 20, 4 << 30, sample=(0, 9_998, 10_000, 19_999, 24_997))
