@@ -322,6 +322,8 @@ static void scan_args(motifs_ctx* c, const BankSlot& bank, int K, const uint8_t*
     a.cinit = (const float*)bank.cinit.p;
     a.codes = codes;
     a.cells = (uint32_t*)c->cnt.p;
+    a.centries = nullptr;
+    f.centries = nullptr;
     a.lenp = bank.lenp;
     a.ntiles = bank.ntiles;
     a.uniform_eps = bank.uniform_eps;
@@ -382,6 +384,14 @@ static int scan_hits_mfma(motifs_ctx* c, const BankSlot& bank, int K, const uint
     const int64_t sb = nb_max * batch;
     const int64_t rows_max = nb_max * Lout * parts;
     MOTIFS_HIP_CHECK(c->cnt.reserve((size_t)nb_max * per_batch));
+    bool compact = c->compact_cells;
+    {   // compact entries (a quarter of the cells' bytes) when the candidate kernel of this launch shape can write them
+        CandArgs a0{};
+        FillArgs f0{};
+        scan_args(c, bank, K, codes_dev, std::min<int64_t>(sb, N), L, Lout, batch, rpr, a0, f0);
+        compact = compact && cand_compact_ok(a0) && (size_t)nb_max * per_batch / 8 < ((size_t)1 << 32);   // 32-bit entry indices in the kernels
+    }
+    if (compact) MOTIFS_HIP_CHECK(c->centries.reserve((size_t)nb_max * per_batch / 4));
     MOTIFS_HIP_CHECK(c->tilesum.reserve((size_t)rows_max * 4));
     MOTIFS_HIP_CHECK(c->off.reserve((size_t)((rows_max + 1023) / 1024) * 8));
     MOTIFS_HIP_CHECK(c->rowx.reserve((size_t)rows_max * 4));
@@ -401,6 +411,10 @@ static int scan_hits_mfma(motifs_ctx* c, const BankSlot& bank, int K, const uint
         CandArgs a{};
         FillArgs f{};
         scan_args(c, bank, K, codes_dev + (size_t)s0 * motifs_codes_pitch(L), ns, L, Lout, batch, rpr, a, f);
+        if (compact) {
+            a.centries = (uint16_t*)c->centries.p;
+            f.centries = (const uint16_t*)c->centries.p;
+        }
         f.row_sum = (uint32_t*)c->tilesum.p;
         f.blk_base = (unsigned long long*)c->off.p;
         f.staging = (uint32_t*)c->staging.p;
@@ -415,8 +429,10 @@ static int scan_hits_mfma(motifs_ctx* c, const BankSlot& bank, int K, const uint
         f.pwm_counts = per_pwm_counts_dev;   // zeroed by the caller of this function; only bins k < K are ever touched
         f.n0 = n0 + s0;
         f.hist_bins = (per_pwm_counts_dev && 2 * bank.KP <= FILL_HIST_MAX) ? 2 * bank.KP : 0;
-        if (ns < nb * batch)   // cells of reads the last batch does not have are never written by the scan
-            MOTIFS_HIP_CHECK(hipMemsetAsync((char*)c->cnt.p + (size_t)(nb - 1) * per_batch, 0, per_batch, c->stream));
+        if (ns < nb * batch) {   // cells of reads the last batch does not have are never written by the scan
+            if (compact) MOTIFS_HIP_CHECK(hipMemsetAsync((char*)c->centries.p + (size_t)(nb - 1) * (per_batch / 4), 0, per_batch / 4, c->stream));
+            else MOTIFS_HIP_CHECK(hipMemsetAsync((char*)c->cnt.p + (size_t)(nb - 1) * per_batch, 0, per_batch, c->stream));
+        }
         {
             KernelTimer t(c, KS_SCAN_COUNT, true);
             const hipError_t le = launch_cand(a, c->stream, t.e0, t.e1);
@@ -482,6 +498,7 @@ int motifs_ctx_create(int device, motifs_ctx** out) {
     MOTIFS_HIP_CHECK(hipHostMalloc(&c->pinned, 256, hipHostMallocDefault));
     const char* ev = getenv("MOTIFS_SCAN_VALU");
     c->scan_valu = ev && ev[0] == '1';
+    if (const char* nc = getenv("MOTIFS_DENSE_CELLS")) c->compact_cells = !(nc[0] == '1');   // A/B: the round-2 cell round trip
     if (const char* wl = getenv("MOTIFS_WS_LIMIT_MB")) {       // experiments: the default of motifs_ctx_set_workspace_limit
         const long long mb = atoll(wl);
         if (mb > 0) c->ws_limit = (size_t)mb << 20;
@@ -495,7 +512,7 @@ void motifs_ctx_destroy(motifs_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : {&c->tab, &c->lim, &c->cnt, &c->off, &c->tilesum, &c->small, &c->codes, &c->hits_tmp,
-                      &c->scores_tmp, &c->pwmcnt, &c->data_tmp, &c->afrag, &c->cinit, &c->staging, &c->rowx, &c->dp_scratch})
+                      &c->scores_tmp, &c->pwmcnt, &c->data_tmp, &c->afrag, &c->cinit, &c->staging, &c->rowx, &c->dp_scratch, &c->centries})
         b->release();
     for (BankSlot& bs : c->bank_slot)
         for (DevBuf* b : {&bs.tab, &bs.lim, &bs.afrag, &bs.cinit, &bs.tabk}) b->release();

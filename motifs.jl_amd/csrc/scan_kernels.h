@@ -45,6 +45,7 @@ struct FastDivHost {
 };
 
 struct FillArgs {
+    const uint16_t* centries; // compact entries of the cells (nullptr: the cells themselves are the candidates), 2 per cell
     const uint4* masks;       // [row = (batch, p)][cell = (n-in-batch, chunk)]
     int64_t nrows;            // batches * LoutP
     uint32_t row_cells;       // batch * nch
@@ -100,11 +101,13 @@ struct CandArgs {
     const float* cinit;       // [tiles][2][16] eps per PWM in accumulator order
     const uint8_t* codes;
     uint32_t* cells;          // [(batch, l, n-in-batch, chunk)] x 4 words, bit i of a cell = PWM 128*chunk + i
+    uint16_t* centries;       // compact form (nullptr: off): one 16-bit entry per half cell, see scan_mfma.hip "compact entries"
     CandDims d;
     int lenp, ntiles;         // padded PWM length (multiple of 4); tiles of 32 PWMs (multiple of 4: whole chunks)
     int uniform_eps;          // afrag holds the bank scaled so that the slack is 4.0 for every PWM (cinit unused)
 };
 int cand_tile_group(int lenp);
+bool cand_compact_ok(const CandArgs& a);   // this launch can write compact entries (four-reads-per-wave kernel, tile groups of 4)
 hipError_t launch_cand(const CandArgs& a, hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 int stage_row_reads(int nch);                                              // reads per row of cells
 int dense_row_reads(int nch);                                              // the same for the dense tensor (mode 2)

@@ -101,12 +101,27 @@ static __device__ __forceinline__ void cand_read(const f16x8 (&A)[PG][T], const 
     }
 }
 
+// the compact entry of a half cell (see scan_cand_kernel_q): count << 12 | (63 - last) << 6 | first, or 3 << 12 | popcount
+static __device__ __forceinline__ uint32_t half_cell_entry(uint32_t wa, uint32_t wb, uint32_t& cnt) {
+    // v_ffbl_b32 / v_ffbh_u32 answer -1 for an empty word, which `| 32` leaves at -1 and the unsigned minimum then ignores
+    uint32_t fa, fb, la, lb;
+    asm("v_ffbl_b32 %0, %1" : "=v"(fa) : "v"(wa));
+    asm("v_ffbl_b32 %0, %1" : "=v"(fb) : "v"(wb));
+    asm("v_ffbh_u32 %0, %1" : "=v"(la) : "v"(wb));
+    asm("v_ffbh_u32 %0, %1" : "=v"(lb) : "v"(wa));
+    cnt = (uint32_t)__builtin_popcount(wa) + (uint32_t)__builtin_popcount(wb);
+    const uint32_t first = min(fa, fb | 32u), lastp = min(la, lb | 32u);   // 0..63 whenever cnt >= 1
+    uint32_t e = cnt < 3u ? (cnt << 12) | (lastp << 6) | first : (3u << 12) | cnt;
+    if (cnt == 0u) e = 0u;
+    return e;
+}
+
 // UEPS: the bank was scaled by powers of two on the host so that the slack of tile g of a group is the inline constant
 // -4 / 2^g (C is then not a register operand and the wave needs 64 VGPRs fewer); otherwise C = -eps_k from cinit.
-template <int T, int PG, bool UEPS, int RPB, int TGB>
+template <int T, int PG, bool UEPS, int RPB, int TGB, bool COMPACT = false>
 static __device__ __forceinline__ void scan_cand_body(const uint4* __restrict__ afrag, const float* __restrict__ cinit,
                                                       const uint8_t* __restrict__ codes, uint32_t* __restrict__ cells,
-                                                      const CandDims& d) {
+                                                      const CandDims& d, uint16_t* __restrict__ centries = nullptr) {
     extern __shared__ uint2 oh_all[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int w = lane & 31, h = lane >> 5;
@@ -168,8 +183,19 @@ static __device__ __forceinline__ void scan_cand_body(const uint4* __restrict__ 
         // multiply per store cost two v_mad_u64_u32 per tile)
         uint32_t* cp = cells + cell0 * 4 + word0 + (size_t)w * lstride4 + (PG == 4 ? 2 * h : PG == 2 ? h : 0);
         const size_t tile_step = 32 * lstride4;
+        uint32_t ei = COMPACT ? (uint32_t)(cell0 * 2 + h + (size_t)w * (lstride4 / 2)) : 0u;     // compact entries: see scan_cand_kernel_q
+        const uint32_t ei_step = (uint32_t)(16 * lstride4);
+        if (COMPACT) __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): no load of this wave is pending inside the tile loop
         auto store_cells = [&](int l0, uint32_t wa, uint32_t wb) {
             const int l = l0 + w;
+            if (COMPACT && PG == 4) {
+                uint32_t cnt;
+                const uint32_t e = half_cell_entry(wa, wb, cnt);
+                if (l < d.Lout) centries[ei] = (uint16_t)e;
+                if (l < d.Lout && cnt >= 3u) *(uint2*)(cells + (size_t)ei * 2) = make_uint2(wa, wb);
+                ei += ei_step;
+                return;
+            }
             if (PG == 4) {
                 if (l < d.Lout && (ng > 2 || h == 0)) *(uint2*)cp = make_uint2(wa, wb);
             } else if (PG == 2) {
@@ -197,10 +223,10 @@ __global__ __launch_bounds__(512) void scan_cand_kernel(const uint4* __restrict_
     scan_cand_body<T, PG, false, 4, 2>(afrag, cinit, codes, cells, d);
 }
 // uniform slack: the wave fits 168 VGPRs, so three 4-wave blocks (2 reads x 2 tile groups, or 4 reads x 1) share a CU
-template <int T, int PG, int TGB>
+template <int T, int PG, int TGB, bool COMPACT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((T * PG <= 16 && PG > 1) ? 3 : 2, 4))) void scan_cand_kernel_u(
-    const uint4* __restrict__ afrag, const uint8_t* __restrict__ codes, uint32_t* __restrict__ cells, const CandDims d) {
-    scan_cand_body<T, PG, true, 4 / TGB, TGB>(afrag, nullptr, codes, cells, d);
+    const uint4* __restrict__ afrag, const uint8_t* __restrict__ codes, uint32_t* __restrict__ cells, uint16_t* __restrict__ centries, const CandDims d) {
+    scan_cand_body<T, PG, true, 4 / TGB, TGB, COMPACT>(afrag, nullptr, codes, cells, d, centries);
 }
 
 // Four reads per wave (uniform slack, short reads): the 32 columns of a tile are 8 consecutive windows of 4 consecutive
@@ -211,9 +237,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((T * PG <= 
 // B-operand reads of a half wave then cover the 64 banks exactly once.
 static __host__ __device__ inline int quad_pitch(int ohlen) { return ((((ohlen + 3) & ~3) - 8 + 31) & ~31) + 8; }
 
-template <int T, int PG, int TGB>
+// Compact entries (COMPACT, tile groups of 4 only): candidates are under 1 % of the (PWM, window) pairs, so a half cell - the 64
+// PWMs a lane holds after the exchange - is empty or holds one or two candidates 98.6 % of the time.  Instead of its 8 bytes of
+// bits the lane stores ONE 16-bit entry, count << 12 | (63 - last) << 6 | first, and only a half cell with three or more
+// candidates (entry 3 << 12 | popcount) also leaves its bits in the cell array, where the consumer fetches them.  The entries
+// keep the cells' order (batch, l, read, chunk, half), so the consumers' rows, offsets and record order do not change; what
+// changes is the traffic of the round trip: 151 MB + the rare cells instead of 605 MB written and read back per strand of
+// BASELINE configs[1].
+template <int T, int PG, int TGB, bool COMPACT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((T * PG <= 12) ? 4 : (T * PG <= 16 && PG > 1) ? 3 : 2, 4))) void scan_cand_kernel_q(
-    const uint4* __restrict__ afrag, const uint8_t* __restrict__ codes, uint32_t* __restrict__ cells, const CandDims d) {
+    const uint4* __restrict__ afrag, const uint8_t* __restrict__ codes, uint32_t* __restrict__ cells, uint16_t* __restrict__ centries, const CandDims d) {
     extern __shared__ __attribute__((aligned(16))) uint2 oh_all[];
     constexpr int QPB = 4 / TGB;                     // quads of reads per block
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -284,8 +317,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((T * PG <= 
         const size_t cell0 = ((size_t)bql * d.Lout * d.batch + (size_t)rl) * d.nch + chunk;
         uint32_t* cp = cells + cell0 * 4 + word0 + (size_t)wq * lstride4 + (PG == 4 ? 2 * h : PG == 2 ? h : 0);
         const size_t tile_step = 8 * lstride4;
+        // compact entries: a 32-bit running entry index (entries of a super-batch number < 2^32) instead of a second 64-bit pointer
+        uint32_t ei = COMPACT ? (uint32_t)(cell0 * 2 + h + (size_t)wq * (lstride4 / 2)) : 0u;
+        const uint32_t ei_step = (uint32_t)(4 * lstride4);
         auto store_cells = [&](int l0, uint32_t wa, uint32_t wb) {
             const bool live = rowl && l0 + wq < d.Lout;
+            if (COMPACT && PG == 4) {
+                uint32_t cnt;
+                const uint32_t e = half_cell_entry(wa, wb, cnt);
+                if (live) centries[ei] = (uint16_t)e;
+                if (live && cnt >= 3u) *(uint2*)(cells + (size_t)ei * 2) = make_uint2(wa, wb);
+                ei += ei_step;
+                return;
+            }
             if (PG == 4) {
                 if (live && (ng > 2 || h == 0)) *(uint2*)cp = make_uint2(wa, wb);
             } else if (PG == 2) {
@@ -295,6 +339,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((T * PG <= 
             }
             cp += tile_step;
         };
+        // Every load of this wave (PWM fragments, code words) has landed before the tile loop starts: without this the compiler
+        // guards the fragments' first uses with s_waitcnt vmcnt(n) INSIDE the loop, and since vmcnt counts in order those waits
+        // also drain the tile stores of the previous turn (seen in the ISA of the compact-entry build: vmcnt(8) ... vmcnt(0)
+        // between the twelve MFMAs of a tile).
+        if (COMPACT) __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0) only
         switch (ng) {
             case 1: cand_read<T, PG, 1, 1, 8>(A, C0, ohl, ntile, store_cells); break;
             case 2: cand_read<T, PG, (PG >= 2 ? 2 : PG), 1, 8>(A, C0, ohl, ntile, store_cells); break;
@@ -506,6 +555,7 @@ struct RowGeom {
     uint32_t row_cells;
     uint32_t nvalid;              // reads of the row that exist (the last batch may be short)
     const uint4* cells;
+    size_t cell0;                 // index of the row's first cell in the cell array (compact entries: 2 per cell)
     const uint8_t* codes;         // the row's first read, advanced to the dword that holds start l
 };
 static __device__ __forceinline__ RowGeom row_geom(const FillArgs& a, int64_t r) {
@@ -517,7 +567,8 @@ static __device__ __forceinline__ RowGeom row_geom(const FillArgs& a, int64_t r)
     const uint32_t n_lo = part * (uint32_t)a.rpr;
     const uint32_t nreads = (uint32_t)a.batch - n_lo < (uint32_t)a.rpr ? (uint32_t)a.batch - n_lo : (uint32_t)a.rpr;
     g.row_cells = nreads * (uint32_t)a.nch;
-    g.cells = a.masks + (((size_t)g.bq * a.Lout + g.l) * a.batch + n_lo) * a.nch;
+    g.cell0 = (((size_t)g.bq * a.Lout + g.l) * a.batch + n_lo) * a.nch;
+    g.cells = a.masks + g.cell0;
     g.nrow0 = g.bq * a.batch + n_lo;
     const int64_t left = a.N - g.nrow0;
     g.nvalid = left <= 0 ? 0u : (left < (int64_t)nreads ? (uint32_t)left : nreads);
@@ -554,6 +605,134 @@ static __device__ __forceinline__ void for_row_candidates(const RowGeom& g, uint
         const uint32_t inc = wave_incl_scan(pc);
         const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
         if (tot) push_and_drain<4 * CPL>(queue, qlen, wd, idx, inc - pc, tot, fn);
+    }
+    if (qlen) fn((uint32_t)queue[lane], (uint32_t)lane < qlen);      // the remainder (< 64)
+    wave_lds_sync();
+}
+
+// The same walk over COMPACT entries (scan_cand_kernel_q<.., COMPACT>): one dword per cell = {entry of half 0, entry of half 1},
+// entry = count << 12 | (63 - last) << 6 | first for up to two candidates among the half cell's 64 PWMs, 3 << 12 | popcount when
+// there are more (their bits then sit in the cell array).  A lane takes 8 consecutive cells per step - 512 cells, a whole row, per
+// step of the wave - so the candidates still come out in cell order; there is no per-bit loop: an entry yields its candidates with
+// two predicated LDS stores.  The rare half cells with three or more candidates (1.4 % at BASELINE configs[1]) are fetched from
+// the cell array: the loads of a lane's first two are issued before the other entries are written out, the rest on demand.
+template <typename F>
+static __device__ __forceinline__ void for_row_candidates_c(const FillArgs& a, const RowGeom& g, uint16_t* queue, F&& fn) {
+    const int lane = threadIdx.x & 63;
+    constexpr uint32_t CPLC = 8, STEP = 64 * CPLC;
+    uint32_t qlen = 0;                                                // wave-uniform
+    const uint32_t* ent = (const uint32_t*)a.centries + g.cell0;      // one dword per cell
+    for (uint32_t i0 = 0; i0 < g.row_cells; i0 += STEP) {             // wave-uniform trip count (1 for rows of <= 512 cells)
+        const uint32_t idx = i0 + lane * CPLC;
+        uint32_t done = 0, tot = 0;                                   // wave-uniform
+        // One turn unless the queue is short of room.  A turn starts from the entries in memory again (they come from L2 then), so
+        // that nothing but a few scalars lives across the scoring calls of the drain below.
+        do {
+            uint32_t e[CPLC];
+            if (idx + CPLC <= g.row_cells) {
+                const uint4 v0 = *(const uint4*)(ent + idx), v1 = *(const uint4*)(ent + idx + 4);
+                e[0] = v0.x, e[1] = v0.y, e[2] = v0.z, e[3] = v0.w, e[4] = v1.x, e[5] = v1.y, e[6] = v1.z, e[7] = v1.w;
+            } else {
+#pragma unroll
+                for (int c = 0; c < (int)CPLC; c++) e[c] = idx + c < g.row_cells ? ent[idx + c] : 0u;
+            }
+            // candidates of the lane: the two count fields of a dword are summed in packed form; a count of 3 stands for "popcount
+            // in the low 12 bits" and is put right below
+            uint32_t acc = 0, ovf = 0;                                // ovf: bit 2c + half set = that entry holds a popcount
+#pragma unroll
+            for (int c = 0; c < (int)CPLC; c++) {
+                const uint32_t t = (e[c] >> 12) & 0x00030003u;
+                acc += t;
+                const uint32_t both = t & (t >> 1) & 0x00010001u;      // field == 3
+                ovf |= ((both & 1u) | (both >> 15)) << (2 * c);
+            }
+            uint32_t pc = (acc & 0xffffu) + (acc >> 16);
+            // Half cells with three or more candidates (1.4 % of them): their bits are fetched from the cell array.  A lane issues
+            // the loads of its first two now (two cover 99.9 % of the lanes) and writes their candidates after everybody's ordinary
+            // entries, so that the round trip hides behind that work and the bit loops run once per step for all such lanes
+            // together instead of once per entry position.
+            uint2 m0 = make_uint2(0u, 0u), m1 = make_uint2(0u, 0u);
+            uint32_t j0 = 0, j1 = 0, g0 = 0, g1 = 0;
+            if (ovf) {                                                // rare lanes
+#pragma unroll
+                for (int j = 0; j < 2 * (int)CPLC; j++)
+                    if ((ovf >> j) & 1u) pc += ((e[j >> 1] >> (16 * (j & 1))) & 0xfffu) - 3u;
+                j0 = (uint32_t)__builtin_ctz(ovf);
+                m0 = ((const uint2*)(g.cells + idx + (j0 >> 1)))[j0 & 1];
+                const uint32_t o1 = ovf & (ovf - 1u);
+                if (o1) {
+                    j1 = (uint32_t)__builtin_ctz(o1);
+                    m1 = ((const uint2*)(g.cells + idx + (j1 >> 1)))[j1 & 1];
+                }
+            }
+            const uint32_t inc = wave_incl_scan(pc);
+            tot = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+            if (!tot) break;
+            const uint32_t room = QN - qlen;
+            const uint32_t take = tot - done < room ? tot - done : room;
+            uint16_t* qb = queue + qlen;
+            uint32_t gp = inc - pc - done;                            // the lane's next candidate's place in this turn's window (may wrap: unsigned)
+#pragma unroll
+            for (int j = 0; j < 2 * (int)CPLC; j++) {
+                const uint32_t f = (e[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+                const uint32_t cnt = f >> 12;
+                const uint32_t base = ((idx + (uint32_t)(j >> 1)) << 7) | ((uint32_t)(j & 1) << 6);
+                if (cnt >= 1u && cnt < 3u) {
+                    if (gp < take) qb[gp] = (uint16_t)(base | (f & 63u));
+                }
+                if (cnt == 2u) {
+                    if (gp + 1u < take) qb[gp + 1u] = (uint16_t)(base | (63u - ((f >> 6) & 63u)));
+                }
+                if (cnt == 3u) {                                      // its candidates go in later: remember where
+                    if ((uint32_t)j == j0) g0 = gp;
+                    if ((uint32_t)j == j1) g1 = gp;
+                    gp += f & 0xfffu;
+                } else {
+                    gp += cnt;
+                }
+            }
+            if (__ballot(ovf != 0)) {
+                auto spill = [&](uint2 mk, uint32_t j, uint32_t gq) {
+                    uint64_t x = (uint64_t)mk.x | ((uint64_t)mk.y << 32);
+                    const uint32_t base = ((idx + (j >> 1)) << 7) | ((j & 1u) << 6);
+                    while (x) {
+                        if (gq < take) qb[gq] = (uint16_t)(base | (uint32_t)__builtin_ctzll(x));
+                        x &= x - 1;
+                        gq++;
+                    }
+                };
+                if (ovf) spill(m0, j0, g0);
+                const uint32_t o1 = ovf & (ovf - 1u);
+                if (__ballot(o1 != 0)) {
+                    if (o1) spill(m1, j1, g1);
+                    uint32_t o2 = o1 & (o1 - 1u);
+                    if (__ballot(o2 != 0)) {                          // a lane with three or more such half cells: one by one
+                        while (o2) {
+                            const uint32_t j = (uint32_t)__builtin_ctz(o2);
+                            o2 &= o2 - 1u;
+                            uint32_t gq = inc - pc - done;            // the entries before j
+                            for (uint32_t i = 0; i < j; i++) {
+                                const uint32_t f = (ent[idx + (i >> 1)] >> (16 * (i & 1))) & 0xffffu;
+                                gq += (f >> 12) == 3u ? (f & 0xfffu) : (f >> 12);
+                            }
+                            spill(((const uint2*)(g.cells + idx + (j >> 1)))[j & 1], j, gq);
+                        }
+                    }
+                }
+            }
+            qlen += take;
+            done += take;
+            wave_lds_sync();
+            uint32_t at = 0;
+            for (; at + 64 <= qlen; at += 64) fn((uint32_t)queue[at + lane], true);
+            if (at) {                                                 // the remainder to the front
+                const uint16_t v = at + lane < (uint32_t)QN ? queue[at + lane] : (uint16_t)0;
+                wave_lds_sync();
+                qlen -= at;
+                if ((uint32_t)lane < qlen) queue[lane] = v;
+            }
+            wave_lds_sync();
+        } while (done < tot);
     }
     if (qlen) fn((uint32_t)queue[lane], (uint32_t)lane < qlen);      // the remainder (< 64)
     wave_lds_sync();
@@ -634,7 +813,7 @@ __global__ __launch_bounds__(VF_THREADS) __attribute__((amdgpu_waves_per_eu((LEN
             dirty = false;
             win_lo += DWIN;
         };
-        for_row_candidates<(MODE == 2 ? 1 : 2)>(g, queue, [&](const uint32_t cw, const bool live) {
+        auto on_cand = [&](const uint32_t cw, const bool live) {
             uint32_t k, nin;
             uint16_t sc;
             bool hit = score_candidate<LEN>(a, g, tb, cw, live, k, nin, sc);
@@ -659,7 +838,9 @@ __global__ __launch_bounds__(VF_THREADS) __attribute__((amdgpu_waves_per_eu((LEN
                     flush();
                 }
             }
-        });
+        };
+        if (MODE != 2 && a.centries) for_row_candidates_c(a, g, queue, on_cand);
+        else for_row_candidates<(MODE == 2 ? 1 : 2)>(g, queue, on_cand);
         if (MODE == 2)
             while (win_lo < seg_len) flush();                         // the rest of the run
         if (MODE != 2 && lane == 0) a.row_sum[r] = nhit;
@@ -779,14 +960,16 @@ __global__ __launch_bounds__(VF_THREADS) void emit_records(FillArgs a) {
             }
         } else {
             uint32_t nhit = 0;
-            for_row_candidates<2>(g, queue, [&](const uint32_t cw, const bool live) {
+            auto on_cand = [&](const uint32_t cw, const bool live) {
                 uint32_t k, nin;
                 uint16_t sc;
                 const bool hit = score_candidate<LEN>(a, g, tb, cw, live, k, nin, sc);
                 const unsigned long long hb = __ballot(hit);
                 if (hit) put(row_at + nhit + (uint32_t)__builtin_popcountll(hb & ((1ull << lane) - 1ull)), k, nin, sc);
                 nhit += (uint32_t)__builtin_popcountll(hb);
-            });
+            };
+            if (a.centries) for_row_candidates_c(a, g, queue, on_cand);
+            else for_row_candidates<2>(g, queue, on_cand);
         }
     }
 }
@@ -800,26 +983,41 @@ static hipError_t launch_cand_tp(const CandArgs& a, hipStream_t st, hipEvent_t e
     constexpr int wpe = (T * PG <= 12) ? 4 : (T * PG <= 16 && PG > 1) ? 3 : 2;
     if (a.uniform_eps && lds_q <= std::min<size_t>(64 * 1024, 160 * 1024 / wpe)) {
         CandDims d = a.d;
+        const bool compact = PG == 4 && a.centries != nullptr;
         // quads per wave: many small blocks balance the CUs best (N = 100k: 1 or 2 per wave 0.337 ms, 3: 0.354, 8: 0.390)
         d.spw = (int)std::max<int64_t>(1, std::min<int64_t>(8, a.d.N / (16 * 8192)));
         const int64_t per_block = (int64_t)(4 / tgb) * 4 * d.spw;
         dim3 grid((unsigned)((d.N + per_block - 1) / per_block), (unsigned)((ntg + tgb - 1) / tgb), 1);
-        if (tgb == 1) hipExtLaunchKernelGGL((scan_cand_kernel_q<T, PG, 1>), grid, dim3(256), (uint32_t)lds_q, st, ev0, ev1, 0, a.afrag, a.codes, a.cells, d);
-        else hipExtLaunchKernelGGL((scan_cand_kernel_q<T, PG, 2>), grid, dim3(256), (uint32_t)lds_q, st, ev0, ev1, 0, a.afrag, a.codes, a.cells, d);
+        if (compact) {
+            if constexpr (PG == 4) {
+                if (tgb == 1) hipExtLaunchKernelGGL((scan_cand_kernel_q<T, PG, 1, true>), grid, dim3(256), (uint32_t)lds_q, st, ev0, ev1, 0, a.afrag, a.codes, a.cells, a.centries, d);
+                else hipExtLaunchKernelGGL((scan_cand_kernel_q<T, PG, 2, true>), grid, dim3(256), (uint32_t)lds_q, st, ev0, ev1, 0, a.afrag, a.codes, a.cells, a.centries, d);
+            }
+        } else if (tgb == 1) hipExtLaunchKernelGGL((scan_cand_kernel_q<T, PG, 1, false>), grid, dim3(256), (uint32_t)lds_q, st, ev0, ev1, 0, a.afrag, a.codes, a.cells, (uint16_t*)nullptr, d);
+        else hipExtLaunchKernelGGL((scan_cand_kernel_q<T, PG, 2, false>), grid, dim3(256), (uint32_t)lds_q, st, ev0, ev1, 0, a.afrag, a.codes, a.cells, (uint16_t*)nullptr, d);
         return hipGetLastError();
     }
     const int rpb = a.uniform_eps ? 4 / tgb : 4;
     const int64_t per_block = (int64_t)rpb * a.d.spw;
     dim3 grid((unsigned)((a.d.N + per_block - 1) / per_block), (unsigned)((ntg + tgb - 1) / tgb), 1);
     const size_t lds = (size_t)tgb * rpb * ((a.d.ohlen + 3) & ~3) * 8;
-    if (a.uniform_eps && tgb == 1) hipExtLaunchKernelGGL((scan_cand_kernel_u<T, PG, 1>), grid, dim3(256), (uint32_t)lds, st, ev0, ev1, 0, a.afrag, a.codes, a.cells, a.d);
-    else if (a.uniform_eps) hipExtLaunchKernelGGL((scan_cand_kernel_u<T, PG, 2>), grid, dim3(256), (uint32_t)lds, st, ev0, ev1, 0, a.afrag, a.codes, a.cells, a.d);
+    if (a.centries && !(a.uniform_eps && PG == 4)) return hipErrorInvalidValue;      // the caller asked cand_compact_ok() first
+    if (a.uniform_eps && a.centries) {
+        if constexpr (PG == 4) {
+            if (tgb == 1) hipExtLaunchKernelGGL((scan_cand_kernel_u<T, PG, 1, true>), grid, dim3(256), (uint32_t)lds, st, ev0, ev1, 0, a.afrag, a.codes, a.cells, a.centries, a.d);
+            else hipExtLaunchKernelGGL((scan_cand_kernel_u<T, PG, 2, true>), grid, dim3(256), (uint32_t)lds, st, ev0, ev1, 0, a.afrag, a.codes, a.cells, a.centries, a.d);
+        }
+    } else if (a.uniform_eps && tgb == 1) hipExtLaunchKernelGGL((scan_cand_kernel_u<T, PG, 1, false>), grid, dim3(256), (uint32_t)lds, st, ev0, ev1, 0, a.afrag, a.codes, a.cells, (uint16_t*)nullptr, a.d);
+    else if (a.uniform_eps) hipExtLaunchKernelGGL((scan_cand_kernel_u<T, PG, 2, false>), grid, dim3(256), (uint32_t)lds, st, ev0, ev1, 0, a.afrag, a.codes, a.cells, (uint16_t*)nullptr, a.d);
     else hipExtLaunchKernelGGL((scan_cand_kernel<T, PG>), grid, dim3(512), (uint32_t)lds, st, ev0, ev1, 0, a.afrag, a.cinit, a.codes, a.cells, a.d);
     return hipGetLastError();
 }
 
 // tiles of 32 PWMs a wave carries: its A fragments are PG * lenp / 4 registers x 4
 int cand_tile_group(int lenp) { return lenp <= 20 ? 4 : lenp <= 32 ? 2 : 1; }
+
+// compact entries are written by the kernels for banks scaled to one slack, with tile groups of 4 (PWMs of up to 20 positions)
+bool cand_compact_ok(const CandArgs& a) { return a.uniform_eps && a.lenp <= 20; }
 
 // ev0 / ev1 (optional): events that take the kernel's own start and stop time stamps (hipExtLaunchKernelGGL): timing the
 // dominant kernel then puts no extra packets on the stream (an event recorded before and after cost ~5 us each per launch)
