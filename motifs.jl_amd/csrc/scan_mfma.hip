@@ -110,10 +110,9 @@ static __device__ __forceinline__ uint32_t half_cell_entry(uint32_t wa, uint32_t
     asm("v_ffbh_u32 %0, %1" : "=v"(la) : "v"(wb));
     asm("v_ffbh_u32 %0, %1" : "=v"(lb) : "v"(wa));
     cnt = (uint32_t)__builtin_popcount(wa) + (uint32_t)__builtin_popcount(wb);
-    const uint32_t first = min(fa, fb | 32u), lastp = min(la, lb | 32u);   // 0..63 whenever cnt >= 1
-    uint32_t e = cnt < 3u ? (cnt << 12) | (lastp << 6) | first : (3u << 12) | cnt;
-    if (cnt == 0u) e = 0u;
-    return e;
+    const uint32_t first = min(fa, fb | 32u), lastp = min(la, lb | 32u);   // 0..63 whenever cnt >= 1 (garbage for an empty half cell)
+    const uint32_t low = cnt < 3u ? ((lastp << 6) | (first & 63u)) & 0xfffu : cnt;    // selects, not branches: this sits between MFMAs
+    return (min(cnt, 3u) << 12) | low;                                        // count 0: the low bits are ignored by the consumers
 }
 
 // UEPS: the bank was scaled by powers of two on the host so that the slack of tile g of a group is the inline constant
@@ -318,15 +317,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((T * PG <= 
         uint32_t* cp = cells + cell0 * 4 + word0 + (size_t)wq * lstride4 + (PG == 4 ? 2 * h : PG == 2 ? h : 0);
         const size_t tile_step = 8 * lstride4;
         // compact entries: a 32-bit running entry index (entries of a super-batch number < 2^32) instead of a second 64-bit pointer
-        uint32_t ei = COMPACT ? (uint32_t)(cell0 * 2 + h + (size_t)wq * (lstride4 / 2)) : 0u;
-        const uint32_t ei_step = (uint32_t)(4 * lstride4);
+        uint32_t ei = COMPACT ? (uint32_t)(cell0 * 2 + h + (size_t)wq * (lstride4 / 2)) * 2u : 0u;   // BYTE offset of the lane's entry (< 2^32)
+        const uint32_t ei_step = (uint32_t)(4 * lstride4) * 2u;
         auto store_cells = [&](int l0, uint32_t wa, uint32_t wb) {
             const bool live = rowl && l0 + wq < d.Lout;
             if (COMPACT && PG == 4) {
                 uint32_t cnt;
                 const uint32_t e = half_cell_entry(wa, wb, cnt);
-                if (live) centries[ei] = (uint16_t)e;
-                if (live && cnt >= 3u) *(uint2*)(cells + (size_t)ei * 2) = make_uint2(wa, wb);
+                if (live) *(uint16_t*)((char*)centries + ei) = (uint16_t)e;                     // scalar base + 32-bit lane offset
+                if (live && cnt >= 3u) *(uint2*)((char*)cells + (size_t)ei * 4) = make_uint2(wa, wb);
                 ei += ei_step;
                 return;
             }

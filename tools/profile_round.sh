@@ -2,7 +2,7 @@
 # usage: bash tools/profile_round.sh <tag>     (outputs under gpurun_out/<tag>_*; fold them with tools/summarize_*.py afterwards)
 # Counters go in their own passes (--pmc with --kernel-trace only), as the pool requires.
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${TAG}_stats -o out --output-format csv -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu --train-steps 2 > $R/gpurun_out/${TAG}_bench_under_rocprof.log 2>&1
