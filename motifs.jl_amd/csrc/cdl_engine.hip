@@ -2385,7 +2385,7 @@ Tensor Engine::toep(Tensor A, Tensor Bm, const ToepGeom& gm) {
                 float* dB = grad(Bm);
                 if (!dB) return;
                 const int G = gm.S / gm.B;
-                if (gm.ldb != 0) {
+                if (gm.ldb != 0 || G == 1) {      // one mini-batch (the reference's schedule): its partial IS the sum over groups
                     launch_wgrad(*this, A->v, out->g, dB, gm, 1);
                 } else {   // shared filter: per-group partials, then a sum over groups
                     const size_t per = (size_t)gm.Q * gm.N;
@@ -2902,7 +2902,7 @@ Tensor Engine::sp_syn(Tensor T, Tensor FAf, Tensor Fk, const SpDims& d) {
                 float* dF = grad(FAf);
                 const int G = d.S / d.B;
                 if (!dF) return;
-                if (d.ldf != 0) {
+                if (d.ldf != 0 || G == 1) {
                     hipLaunchKernelGGL(k_sp_wgrad_syn, dim3((d.W + 127) / 128, d.h, G), dim3(128), (size_t)d.K * 128 * 4, st, nz, out->g, dF, d);
                 } else {
                     const size_t per = (size_t)d.h * d.K * d.W;
@@ -2939,7 +2939,7 @@ Tensor Engine::ana_sp(Tensor img, Tensor FA, Tensor FAf, const SpDims& d, const 
                 float* dB = grad(FA);
                 const int G = d.S / d.B;
                 if (!dB) return;
-                if (d.ldf != 0) {
+                if (d.ldf != 0 || G == 1) {
                     hipLaunchKernelGGL(k_sp_wgrad_ana, dim3((d.W + 127) / 128, d.h, G), dim3(128), (size_t)128 * (d.K + 1) * 4, st, img->v, gz, dB, d, 1);
                 } else {
                     const size_t per = (size_t)d.h * d.W * d.K;
