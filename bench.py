@@ -558,16 +558,17 @@ def main():
     # 8d, GEMM form): 2 * 4*len * K flop per window, N * (L - len + 1) windows per strand launch.
     # The whole pass is also quoted against HBM on the fused-hits contract (N*L codes in, 14 B per hit out).
     hits_per_pass = nhits / 2.0
-    n_pass = max(kms["count"][1], 1)
-    cand_ms = kms["count"][0] / n_pass
-    pass_ms = (kms["count"][0] + kms["offsets"][0] + kms["fill"][0]) / n_pass
+    n_launch = max(kms["count"][1], 1)
+    strands_per_launch = 2.0 * args.steps / n_launch           # 2: one candidate launch takes both strands' banks (gpu_scan); 1: one per strand
+    cand_ms = kms["count"][0] / n_launch
+    pass_ms = (kms["count"][0] + kms["offsets"][0] + kms["fill"][0]) / (2.0 * args.steps)    # one strand's share of a step's kernels
     alg_bytes = N * L + hits_per_pass * 14 + K * 8
     pass_gbs = alg_bytes / (pass_ms * 1e-3) / 1e9
-    cand_flops = 2.0 * 4 * PL * K * float(N) * Lout
+    cand_flops = 2.0 * 4 * PL * K * float(N) * Lout * strands_per_launch
     cand_tflops = cand_flops / (cand_ms * 1e-3) / 1e12
     traffic, traffic_src = None, None
     # the PMC entry of the launch that was timed: same kernel, same grid (blocks of 8 reads, tools/summarize_traffic.py keys by shape)
-    cand_blocks = (N + 7) // 8
+    cand_blocks = (N + 7) // 8                                  # (the PMC driver tools/prof_scan.py scans one strand per call)
     for tf in TRAFFIC_FILES:
         if traffic is None and os.path.exists(tf) and (N, L, K, PL) == (100_000, 200, 200, 12):
             with open(tf) as fh:
@@ -600,7 +601,9 @@ def main():
             "untimed_preheat_steps": PREHEAT,
         },
         "roofline": {
-            "kernel": "scan_cand_kernel_q<3,4,2> (v_mfma_f32_32x32x16_f16 candidate filter, four reads per wave, one strand of the shard per launch)",
+            "kernel": "scan_cand_kernel_q<3,4,2,compact> (v_mfma_f32_32x32x16_f16 candidate filter, four reads per wave; "
+                      f"{strands_per_launch:.0f} strand(s) of the shard per launch)",
+            "strands_per_launch": strands_per_launch,
             "bound": "mfma",
             "achieved": cand_tflops,
             "peak": MFMA_F16_PEAK_TFLOPS,

@@ -79,6 +79,8 @@ struct motifs_ctx {
     motifs::DevBuf dp_scratch;      // host-buffer data-parallel step: flat gradient + losses
     motifs::DevBuf centries;        // matrix-core scan: compact 16-bit entries of the candidate cells (scan_mfma.hip)
     bool compact_cells = true;      // MOTIFS_DENSE_CELLS=1 turns them off (the round-2 round trip through the 128-bit cells)
+    motifs::DevBuf cnt2, centries2; // the reverse strand's cells / entries when one candidate launch serves both strands of gpu_scan
+    bool fuse_strands = true;       // MOTIFS_NO_STRAND_FUSION=1: one candidate launch per strand
     motifs::BankSlot bank_slot[2];  // [rc]
     void* pinned = nullptr;  // small pinned host block for totals / flags
     // pinned staging of the host-buffer entries (motifs_pwm_scan*): code rows on the way up, record chunks on the way down

@@ -314,15 +314,19 @@ static int cached_bank(motifs_ctx* c, const uint16_t* pwms, const int64_t* lens,
 
 // The arguments the candidate kernel and the row kernels share, for `ns` reads starting at `codes` (cells in c->cnt).
 static void scan_args(motifs_ctx* c, const BankSlot& bank, int K, const uint8_t* codes, int64_t ns, int L, int Lout, int batch,
-                      int rpr, CandArgs& a, FillArgs& f) {
+                      int rpr, CandArgs& a, FillArgs& f, void* cells = nullptr) {
+    if (!cells) cells = c->cnt.p;
     const int PG = cand_tile_group(bank.lenp);
     const int parts = (batch + rpr - 1) / rpr;
     const int64_t nb = (ns + batch - 1) / batch;
     a.afrag = (const uint4*)bank.afrag.p;
     a.cinit = (const float*)bank.cinit.p;
     a.codes = codes;
-    a.cells = (uint32_t*)c->cnt.p;
+    a.cells = (uint32_t*)cells;
     a.centries = nullptr;
+    a.afrag2 = nullptr;
+    a.cells2 = nullptr;
+    a.centries2 = nullptr;
     f.centries = nullptr;
     a.lenp = bank.lenp;
     a.ntiles = bank.ntiles;
@@ -339,7 +343,7 @@ static void scan_args(motifs_ctx* c, const BankSlot& bank, int K, const uint8_t*
         int64_t spw = ns * (bank.ntiles / PG) / 16384;
         a.d.spw = (int)std::max<int64_t>(1, std::min<int64_t>(spw, 8));   // measured: 4-8 reads per wave best, 16 is 12 % slower
     }
-    f.masks = (const uint4*)c->cnt.p;
+    f.masks = (const uint4*)cells;
     f.parts = parts;
     f.rpr = rpr;
     f.nrows = nb * Lout * parts;
@@ -366,11 +370,26 @@ static void scan_args(motifs_ctx* c, const BankSlot& bank, int K, const uint8_t*
     f.div_nch.m = d == 1 ? 0u : (uint32_t)((((uint64_t)1 << 32) * (((uint64_t)1 << sh) - d)) / d + 1);
 }
 
+// reads one launch of the matrix-core path takes under the workspace bound (whole ordering batches)
+static int64_t reads_per_launch(const motifs_ctx* c, const BankSlot& bank, int Lout, int batch, bool emit, int64_t N) {
+    const int rpr = stage_row_reads(bank.nch);
+    const int parts = (batch + rpr - 1) / rpr;
+    const int row_slots = 2 * rpr * bank.nch;
+    const size_t per_batch = (size_t)Lout * batch * bank.nch * 16;
+    const size_t stage_per_batch = emit ? (size_t)Lout * parts * row_slots * 4 : 0;
+    int64_t nb_max = (int64_t)(c->ws_limit / (per_batch + stage_per_batch));
+    nb_max = std::max<int64_t>(1, std::min<int64_t>(nb_max, (N + batch - 1) / batch));
+    return nb_max * batch;
+}
+
 // Hit records through the matrix cores: candidates (scan_cand_kernel) -> exact verification, staged hits and
 // row counts (stage_hits) -> scan -> records (emit_records); no host round trip in between.  The bank has already been uploaded (tab, lim).
 static int scan_hits_mfma(motifs_ctx* c, const BankSlot& bank, int K, const uint8_t* codes_dev, int64_t N, int L, int Lout, int64_t n0,
                           int batch, motifs_hit* hits_dev, uint16_t* hit_scores_dev, int64_t cap, int64_t* n_out,
-                          int64_t* per_pwm_counts_dev, int slot = 0, bool finish = true) {
+                          int64_t* per_pwm_counts_dev, int slot = 0, bool finish = true, int cand_mode = 0, const BankSlot* bank2 = nullptr) {
+    // cand_mode (gpu_scan's two strands through ONE candidate launch, single super-batch only): 1 = this is the forward strand and the
+    // launch also takes bank2, the reverse strand's bank, writing its entries / cells into the second buffer set; 2 = this is the
+    // reverse strand: its candidates are already in the second buffer set, no launch
     // slot: which pair of running totals in c->small this strand uses; finish = false: everything is enqueued, the
     // total stays on the device at totals_of(slot) and the caller reads it after its own synchronisation
     const bool emit = hits_dev != nullptr && cap > 0;
@@ -391,7 +410,17 @@ static int scan_hits_mfma(motifs_ctx* c, const BankSlot& bank, int K, const uint
         scan_args(c, bank, K, codes_dev, std::min<int64_t>(sb, N), L, Lout, batch, rpr, a0, f0);
         compact = compact && cand_compact_ok(a0) && (size_t)nb_max * per_batch / 8 < ((size_t)1 << 32);   // 32-bit entry indices in the kernels
     }
+    if (cand_mode != 0 && (!compact || sb < N)) {
+        set_error("internal: a two-strand candidate launch needs compact entries and a single super-batch");
+        return MOTIFS_ERR_INVALID;
+    }
     if (compact) MOTIFS_HIP_CHECK(c->centries.reserve((size_t)nb_max * per_batch / 4));
+    if (cand_mode == 1) {
+        MOTIFS_HIP_CHECK(c->cnt2.reserve((size_t)nb_max * per_batch));
+        MOTIFS_HIP_CHECK(c->centries2.reserve((size_t)nb_max * per_batch / 4));
+    }
+    void* const cells_buf = cand_mode == 2 ? c->cnt2.p : c->cnt.p;
+    void* const entries_buf = cand_mode == 2 ? c->centries2.p : c->centries.p;
     MOTIFS_HIP_CHECK(c->tilesum.reserve((size_t)rows_max * 4));
     MOTIFS_HIP_CHECK(c->off.reserve((size_t)((rows_max + 1023) / 1024) * 8));
     MOTIFS_HIP_CHECK(c->rowx.reserve((size_t)rows_max * 4));
@@ -410,10 +439,15 @@ static int scan_hits_mfma(motifs_ctx* c, const BankSlot& bank, int K, const uint
         const int64_t nb = (ns + batch - 1) / batch;
         CandArgs a{};
         FillArgs f{};
-        scan_args(c, bank, K, codes_dev + (size_t)s0 * motifs_codes_pitch(L), ns, L, Lout, batch, rpr, a, f);
+        scan_args(c, bank, K, codes_dev + (size_t)s0 * motifs_codes_pitch(L), ns, L, Lout, batch, rpr, a, f, cells_buf);
         if (compact) {
-            a.centries = (uint16_t*)c->centries.p;
-            f.centries = (const uint16_t*)c->centries.p;
+            a.centries = (uint16_t*)entries_buf;
+            f.centries = (const uint16_t*)entries_buf;
+        }
+        if (cand_mode == 1) {
+            a.afrag2 = (const uint4*)bank2->afrag.p;
+            a.cells2 = (uint32_t*)c->cnt2.p;
+            a.centries2 = (uint16_t*)c->centries2.p;
         }
         f.row_sum = (uint32_t*)c->tilesum.p;
         f.blk_base = (unsigned long long*)c->off.p;
@@ -429,11 +463,12 @@ static int scan_hits_mfma(motifs_ctx* c, const BankSlot& bank, int K, const uint
         f.pwm_counts = per_pwm_counts_dev;   // zeroed by the caller of this function; only bins k < K are ever touched
         f.n0 = n0 + s0;
         f.hist_bins = (per_pwm_counts_dev && 2 * bank.KP <= FILL_HIST_MAX) ? 2 * bank.KP : 0;
-        if (ns < nb * batch) {   // cells of reads the last batch does not have are never written by the scan
+        if (ns < nb * batch && cand_mode != 2) {   // cells of reads the last batch does not have are never written by the scan
             if (compact) MOTIFS_HIP_CHECK(hipMemsetAsync((char*)c->centries.p + (size_t)(nb - 1) * (per_batch / 4), 0, per_batch / 4, c->stream));
             else MOTIFS_HIP_CHECK(hipMemsetAsync((char*)c->cnt.p + (size_t)(nb - 1) * per_batch, 0, per_batch, c->stream));
+            if (cand_mode == 1) MOTIFS_HIP_CHECK(hipMemsetAsync((char*)c->centries2.p + (size_t)(nb - 1) * (per_batch / 4), 0, per_batch / 4, c->stream));
         }
-        {
+        if (cand_mode != 2) {
             KernelTimer t(c, KS_SCAN_COUNT, true);
             const hipError_t le = launch_cand(a, c->stream, t.e0, t.e1);
             t.stamped = le == hipSuccess;            // events of a failed launch are never stamped: do not queue them
@@ -499,6 +534,7 @@ int motifs_ctx_create(int device, motifs_ctx** out) {
     const char* ev = getenv("MOTIFS_SCAN_VALU");
     c->scan_valu = ev && ev[0] == '1';
     if (const char* nc = getenv("MOTIFS_DENSE_CELLS")) c->compact_cells = !(nc[0] == '1');   // A/B: the round-2 cell round trip
+    if (const char* nf = getenv("MOTIFS_NO_STRAND_FUSION")) c->fuse_strands = !(nf[0] == '1');  // A/B: one candidate launch per strand
     if (const char* wl = getenv("MOTIFS_WS_LIMIT_MB")) {       // experiments: the default of motifs_ctx_set_workspace_limit
         const long long mb = atoll(wl);
         if (mb > 0) c->ws_limit = (size_t)mb << 20;
@@ -512,7 +548,7 @@ void motifs_ctx_destroy(motifs_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : {&c->tab, &c->lim, &c->cnt, &c->off, &c->tilesum, &c->small, &c->codes, &c->hits_tmp,
-                      &c->scores_tmp, &c->pwmcnt, &c->data_tmp, &c->afrag, &c->cinit, &c->staging, &c->rowx, &c->dp_scratch, &c->centries})
+                      &c->scores_tmp, &c->pwmcnt, &c->data_tmp, &c->afrag, &c->cinit, &c->staging, &c->rowx, &c->dp_scratch, &c->centries, &c->cnt2, &c->centries2})
         b->release();
     for (BankSlot& bs : c->bank_slot)
         for (DevBuf* b : {&bs.tab, &bs.lim, &bs.afrag, &bs.cinit, &bs.tabk}) b->release();
@@ -884,11 +920,27 @@ int motifs_pwm_scan_hits_both_dev(motifs_ctx* c, const uint16_t* pwms_fp16, cons
     }
     MOTIFS_HIP_CHECK(hipSetDevice(c->device));
     if (per_pwm_counts2_dev) MOTIFS_HIP_CHECK(hipMemsetAsync(per_pwm_counts2_dev, 0, (size_t)2 * K * 8, c->stream));
+    // One candidate launch for both strands when the four-reads kernel with compact entries serves both banks and the shard is one
+    // super-batch: the reverse bank then goes over the reads the forward bank's waves have already staged (scan_mfma.hip).
+    bool fuse = c->compact_cells && c->fuse_strands;
+    {
+        const int Lout0 = L - bs[0]->minlen + 1;
+        CandArgs a0{}, a1{};
+        FillArgs f0{};
+        const int rpr0 = stage_row_reads(bs[0]->nch);
+        scan_args(c, *bs[0], K, codes_dev, N, L, Lout0, batch, rpr0, a0, f0);
+        scan_args(c, *bs[1], K, codes_dev, N, L, Lout0, batch, rpr0, a1, f0);
+        const bool emit = hits[0] != nullptr && cap > 0;
+        fuse = fuse && cand_two_strands_ok(a0) && cand_two_strands_ok(a1) && bs[0]->lenp == bs[1]->lenp && bs[0]->nch == bs[1]->nch &&
+               reads_per_launch(c, *bs[0], Lout0, batch, emit, N) >= N &&
+               (size_t)((N + batch - 1) / batch) * ((size_t)Lout0 * batch * bs[0]->nch * 16) / 8 < ((size_t)1 << 32);
+    }
     for (int rc = 0; rc < 2; rc++) {
         const int Lout = L - bs[rc]->minlen + 1;
         int64_t dummy = 0;
         const int rcode = scan_hits_mfma(c, *bs[rc], K, codes_dev, N, L, Lout, n0, batch, hits[rc], scores[rc], cap, &dummy,
-                                         per_pwm_counts2_dev ? per_pwm_counts2_dev + (size_t)rc * K : nullptr, rc, false);
+                                         per_pwm_counts2_dev ? per_pwm_counts2_dev + (size_t)rc * K : nullptr, rc, false,
+                                         fuse ? rc + 1 : 0, fuse ? bs[1] : nullptr);
         if (rcode) return rcode;
     }
     MOTIFS_HIP_CHECK(hipStreamSynchronize(c->stream));

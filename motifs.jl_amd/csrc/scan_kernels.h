@@ -102,12 +102,16 @@ struct CandArgs {
     const uint8_t* codes;
     uint32_t* cells;          // [(batch, l, n-in-batch, chunk)] x 4 words, bit i of a cell = PWM 128*chunk + i
     uint16_t* centries;       // compact form (nullptr: off): one 16-bit entry per half cell, see scan_mfma.hip "compact entries"
+    const uint4* afrag2;      // the other strand's bank in the same launch (nullptr: one strand), with its own cells2 / centries2
+    uint32_t* cells2;
+    uint16_t* centries2;
     CandDims d;
     int lenp, ntiles;         // padded PWM length (multiple of 4); tiles of 32 PWMs (multiple of 4: whole chunks)
     int uniform_eps;          // afrag holds the bank scaled so that the slack is 4.0 for every PWM (cinit unused)
 };
 int cand_tile_group(int lenp);
-bool cand_compact_ok(const CandArgs& a);   // this launch can write compact entries (four-reads-per-wave kernel, tile groups of 4)
+bool cand_compact_ok(const CandArgs& a);
+bool cand_two_strands_ok(const CandArgs& a);   // ... and take both strands' banks in one launch   // this launch can write compact entries (four-reads-per-wave kernel, tile groups of 4)
 hipError_t launch_cand(const CandArgs& a, hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 int stage_row_reads(int nch);                                              // reads per row of cells
 int dense_row_reads(int nch);                                              // the same for the dense tensor (mode 2)

@@ -245,7 +245,12 @@ static __host__ __device__ inline int quad_pitch(int ohlen) { return ((((ohlen +
 // BASELINE configs[1].
 template <int T, int PG, int TGB, bool COMPACT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((T * PG <= 12) ? 4 : (T * PG <= 16 && PG > 1) ? 3 : 2, 4))) void scan_cand_kernel_q(
-    const uint4* __restrict__ afrag, const uint8_t* __restrict__ codes, uint32_t* __restrict__ cells, uint16_t* __restrict__ centries, const CandDims d) {
+    const uint4* __restrict__ afrag, const uint8_t* __restrict__ codes, uint32_t* __restrict__ cells, uint16_t* __restrict__ centries, const CandDims d,
+    const uint4* __restrict__ afrag2, uint32_t* __restrict__ cells2, uint16_t* __restrict__ centries2) {
+    // afrag2 != nullptr (COMPACT only): the reverse strand's bank goes over the SAME staged reads right after the forward one's -
+    // gpu_scan (_h3_1_alignment.jl:89-99) scans every read with both banks, and what a wave does before its first tile (code loads,
+    // four one-hot images, the cell address) and after its last is 9 % of a one-strand pass (measured by running the tile loop
+    // twice: 1.128 ms for two passes' worth against 2 x 0.591).  The second bank's fragments replace the first's in the same registers.
     extern __shared__ __attribute__((aligned(16))) uint2 oh_all[];
     constexpr int QPB = 4 / TGB;                     // quads of reads per block
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -263,10 +268,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((T * PG <= 
     f32x16 C0[1];
 #pragma unroll
     for (int r = 0; r < 16; r++) C0[0][r] = 0.f;     // unused: cand_read takes the inline constants
+    const int nstrand = (COMPACT && afrag2) ? 2 : 1;
+    auto load_bank = [&](const uint4* af) {
 #pragma unroll
-    for (int g = 0; g < PG; g++)
+        for (int g = 0; g < PG; g++)
 #pragma unroll
-        for (int t = 0; t < T; t++) A[g][t] = __builtin_bit_cast(f16x8, afrag[((size_t)(tile0 + g) * T + t) * 64 + lane]);
+            for (int t = 0; t < T; t++) A[g][t] = __builtin_bit_cast(f16x8, af[((size_t)(tile0 + g) * T + t) * 64 + lane]);
+    };
+    load_bank(afrag);
 
     const unsigned lb = xcd_swz(blockIdx.x, gridDim.x);
     const int ntile = (d.Lout + 7) / 8;
@@ -317,37 +326,43 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((T * PG <= 
         uint32_t* cp = cells + cell0 * 4 + word0 + (size_t)wq * lstride4 + (PG == 4 ? 2 * h : PG == 2 ? h : 0);
         const size_t tile_step = 8 * lstride4;
         // compact entries: a 32-bit running entry index (entries of a super-batch number < 2^32) instead of a second 64-bit pointer
-        uint32_t ei = COMPACT ? (uint32_t)(cell0 * 2 + h + (size_t)wq * (lstride4 / 2)) * 2u : 0u;   // BYTE offset of the lane's entry (< 2^32)
+        const uint32_t ei0 = COMPACT ? (uint32_t)(cell0 * 2 + h + (size_t)wq * (lstride4 / 2)) * 2u : 0u;   // BYTE offset of the lane's entry (< 2^32)
         const uint32_t ei_step = (uint32_t)(4 * lstride4) * 2u;
-        auto store_cells = [&](int l0, uint32_t wa, uint32_t wb) {
-            const bool live = rowl && l0 + wq < d.Lout;
-            if (COMPACT && PG == 4) {
-                uint32_t cnt;
-                const uint32_t e = half_cell_entry(wa, wb, cnt);
-                if (live) *(uint16_t*)((char*)centries + ei) = (uint16_t)e;                     // scalar base + 32-bit lane offset
-                if (live && cnt >= 3u) *(uint2*)((char*)cells + (size_t)ei * 4) = make_uint2(wa, wb);
-                ei += ei_step;
-                return;
+        for (int strand = 0; strand < nstrand; strand++) {        // wave-uniform
+            uint32_t* const cells_s = strand ? cells2 : cells;
+            uint16_t* const centries_s = strand ? centries2 : centries;
+            if (nstrand == 2 && (strand || s)) load_bank(strand ? afrag2 : afrag);  // (the first quad's forward bank is already in the registers)
+            uint32_t ei = ei0;
+            auto store_cells = [&](int l0, uint32_t wa, uint32_t wb) {
+                const bool live = rowl && l0 + wq < d.Lout;
+                if (COMPACT && PG == 4) {
+                    uint32_t cnt;
+                    const uint32_t e = half_cell_entry(wa, wb, cnt);
+                    if (live) *(uint16_t*)((char*)centries_s + ei) = (uint16_t)e;                     // scalar base + 32-bit lane offset
+                    if (live && cnt >= 3u) *(uint2*)((char*)cells_s + (size_t)ei * 4) = make_uint2(wa, wb);
+                    ei += ei_step;
+                    return;
+                }
+                if (PG == 4) {
+                    if (live && (ng > 2 || h == 0)) *(uint2*)cp = make_uint2(wa, wb);
+                } else if (PG == 2) {
+                    if (live) *cp = wa;
+                } else {
+                    if (live && h == 0) *cp = wa;
+                }
+                cp += tile_step;
+            };
+            // Every load of this wave (PWM fragments, code words) has landed before the tile loop starts: without this the compiler
+            // guards the fragments' first uses with s_waitcnt vmcnt(n) INSIDE the loop, and since vmcnt counts in order those waits
+            // also drain the tile stores of the previous turn (seen in the ISA of the compact-entry build: vmcnt(8) ... vmcnt(0)
+            // between the twelve MFMAs of a tile).
+            if (COMPACT) __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0) only
+            switch (ng) {
+                case 1: cand_read<T, PG, 1, 1, 8>(A, C0, ohl, ntile, store_cells); break;
+                case 2: cand_read<T, PG, (PG >= 2 ? 2 : PG), 1, 8>(A, C0, ohl, ntile, store_cells); break;
+                case 3: cand_read<T, PG, (PG >= 3 ? 3 : PG), 1, 8>(A, C0, ohl, ntile, store_cells); break;
+                default: cand_read<T, PG, PG, 1, 8>(A, C0, ohl, ntile, store_cells); break;
             }
-            if (PG == 4) {
-                if (live && (ng > 2 || h == 0)) *(uint2*)cp = make_uint2(wa, wb);
-            } else if (PG == 2) {
-                if (live) *cp = wa;
-            } else {
-                if (live && h == 0) *cp = wa;
-            }
-            cp += tile_step;
-        };
-        // Every load of this wave (PWM fragments, code words) has landed before the tile loop starts: without this the compiler
-        // guards the fragments' first uses with s_waitcnt vmcnt(n) INSIDE the loop, and since vmcnt counts in order those waits
-        // also drain the tile stores of the previous turn (seen in the ISA of the compact-entry build: vmcnt(8) ... vmcnt(0)
-        // between the twelve MFMAs of a tile).
-        if (COMPACT) __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0) only
-        switch (ng) {
-            case 1: cand_read<T, PG, 1, 1, 8>(A, C0, ohl, ntile, store_cells); break;
-            case 2: cand_read<T, PG, (PG >= 2 ? 2 : PG), 1, 8>(A, C0, ohl, ntile, store_cells); break;
-            case 3: cand_read<T, PG, (PG >= 3 ? 3 : PG), 1, 8>(A, C0, ohl, ntile, store_cells); break;
-            default: cand_read<T, PG, PG, 1, 8>(A, C0, ohl, ntile, store_cells); break;
         }
         __builtin_amdgcn_wave_barrier();
         r0 += 4 * QPB;
@@ -991,17 +1006,18 @@ static hipError_t launch_cand_tp(const CandArgs& a, hipStream_t st, hipEvent_t e
         dim3 grid((unsigned)((d.N + per_block - 1) / per_block), (unsigned)((ntg + tgb - 1) / tgb), 1);
         if (compact) {
             if constexpr (PG == 4) {
-                if (tgb == 1) hipExtLaunchKernelGGL((scan_cand_kernel_q<T, PG, 1, true>), grid, dim3(256), (uint32_t)lds_q, st, ev0, ev1, 0, a.afrag, a.codes, a.cells, a.centries, d);
-                else hipExtLaunchKernelGGL((scan_cand_kernel_q<T, PG, 2, true>), grid, dim3(256), (uint32_t)lds_q, st, ev0, ev1, 0, a.afrag, a.codes, a.cells, a.centries, d);
+                if (tgb == 1) hipExtLaunchKernelGGL((scan_cand_kernel_q<T, PG, 1, true>), grid, dim3(256), (uint32_t)lds_q, st, ev0, ev1, 0, a.afrag, a.codes, a.cells, a.centries, d, a.afrag2, a.cells2, a.centries2);
+                else hipExtLaunchKernelGGL((scan_cand_kernel_q<T, PG, 2, true>), grid, dim3(256), (uint32_t)lds_q, st, ev0, ev1, 0, a.afrag, a.codes, a.cells, a.centries, d, a.afrag2, a.cells2, a.centries2);
             }
-        } else if (tgb == 1) hipExtLaunchKernelGGL((scan_cand_kernel_q<T, PG, 1, false>), grid, dim3(256), (uint32_t)lds_q, st, ev0, ev1, 0, a.afrag, a.codes, a.cells, (uint16_t*)nullptr, d);
-        else hipExtLaunchKernelGGL((scan_cand_kernel_q<T, PG, 2, false>), grid, dim3(256), (uint32_t)lds_q, st, ev0, ev1, 0, a.afrag, a.codes, a.cells, (uint16_t*)nullptr, d);
+        } else if (tgb == 1) hipExtLaunchKernelGGL((scan_cand_kernel_q<T, PG, 1, false>), grid, dim3(256), (uint32_t)lds_q, st, ev0, ev1, 0, a.afrag, a.codes, a.cells, (uint16_t*)nullptr, d, (const uint4*)nullptr, (uint32_t*)nullptr, (uint16_t*)nullptr);
+        else hipExtLaunchKernelGGL((scan_cand_kernel_q<T, PG, 2, false>), grid, dim3(256), (uint32_t)lds_q, st, ev0, ev1, 0, a.afrag, a.codes, a.cells, (uint16_t*)nullptr, d, (const uint4*)nullptr, (uint32_t*)nullptr, (uint16_t*)nullptr);
         return hipGetLastError();
     }
     const int rpb = a.uniform_eps ? 4 / tgb : 4;
     const int64_t per_block = (int64_t)rpb * a.d.spw;
     dim3 grid((unsigned)((a.d.N + per_block - 1) / per_block), (unsigned)((ntg + tgb - 1) / tgb), 1);
     const size_t lds = (size_t)tgb * rpb * ((a.d.ohlen + 3) & ~3) * 8;
+    if (a.afrag2) return hipErrorInvalidValue;                                       // two strands per launch: the four-reads kernel only (cand_two_strands_ok)
     if (a.centries && !(a.uniform_eps && PG == 4)) return hipErrorInvalidValue;      // the caller asked cand_compact_ok() first
     if (a.uniform_eps && a.centries) {
         if constexpr (PG == 4) {
@@ -1019,6 +1035,14 @@ int cand_tile_group(int lenp) { return lenp <= 20 ? 4 : lenp <= 32 ? 2 : 1; }
 
 // compact entries are written by the kernels for banks scaled to one slack, with tile groups of 4 (PWMs of up to 20 positions)
 bool cand_compact_ok(const CandArgs& a) { return a.uniform_eps && a.lenp <= 20; }
+// both strands of gpu_scan in one launch: the four-reads-per-wave kernel with compact entries (the condition of launch_cand_tp)
+bool cand_two_strands_ok(const CandArgs& a) {
+    if (!cand_compact_ok(a)) return false;
+    const int T = a.lenp / 4;
+    const int wpe = (T * 4 <= 12) ? 4 : (T * 4 <= 16) ? 3 : 2;
+    const size_t lds_q = (size_t)4 * 4 * quad_pitch(a.d.ohlen) * 8;
+    return lds_q <= std::min<size_t>(64 * 1024, 160 * 1024 / wpe);
+}
 
 // ev0 / ev1 (optional): events that take the kernel's own start and stop time stamps (hipExtLaunchKernelGGL): timing the
 // dominant kernel then puts no extra packets on the stream (an event recorded before and after cost ~5 us each per launch)
