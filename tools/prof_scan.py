@@ -22,11 +22,13 @@ raw = torch.from_numpy(codes).cuda()
 dcodes = torch.zeros(lib.Context.codes_bytes(N, L), dtype=torch.uint8, device="cuda")
 torch.cuda.synchronize()
 ctx.encode_dev(raw.data_ptr(), lib.DATA_CODES_U8, N, L, dcodes.data_ptr())
-n = ctx.pwm_scan_hits_dev(bank, lens, dcodes.data_ptr(), N, L, 0, None, None, 0)
-hits = torch.empty((n + 16, 3), dtype=torch.int32, device="cuda")
-sc = torch.empty(n + 16, dtype=torch.int16, device="cuda")
+# the hit-record path exactly as bench.py drives it: gpu_scan, both strands in one call (one candidate launch for the two banks)
+need = ctx.pwm_scan_hits_both_dev(bank, lens, dcodes.data_ptr(), N, L, None, None, 0)
+n = max(need)
+hits = [torch.empty((n + 16, 3), dtype=torch.int32, device="cuda") for _ in range(2)]
+sc = [torch.empty(n + 16, dtype=torch.int16, device="cuda") for _ in range(2)]
 for _ in range(reps):
-    ctx.pwm_scan_hits_dev(bank, lens, dcodes.data_ptr(), N, L, 0, hits.data_ptr(), sc.data_ptr(), n + 16)
+    ctx.pwm_scan_hits_both_dev(bank, lens, dcodes.data_ptr(), N, L, [h.data_ptr() for h in hits], [s.data_ptr() for s in sc], n + 16)
 nb = min(N, 20000)
 Lout = L - PL + 1
 dense = torch.empty((Lout, nb, K), dtype=torch.int16, device="cuda")

@@ -24,7 +24,7 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
 res = {"commit": commit,
        "command": f"bash tools/profile_round.sh {tag}  (on the GPU box: rocprofv3 --pmc FETCH_SIZE --kernel-trace ... -- python3 "
                   f"tools/prof_scan.py; the same with WRITE_SIZE), then python tools/summarize_traffic.py {tag} <out> <commit>",
-       "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over tools/prof_scan.py at BASELINE configs[1] (100k reads x "
+       "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over tools/prof_scan.py at BASELINE configs[1] (gpu_scan: both strands per call, as bench.py drives it; 100k reads x "
                "200 bp, 200 PWMs len 12; dense launches: 20k reads).  One entry per (kernel, grid size in threads): the average over the "
                "launches of THAT shape.  hbm_bytes_per_launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 read-side correction).",
        "launches": []}
