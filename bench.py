@@ -517,7 +517,8 @@ def main():
             "seqs_per_s_g1": hp.batch_size * world * g1_steps / g1dt,
             "g1_note": "reference schedule (train.jl:40-46): one AdaBelief step per mini-batch of 6 reads per GPU; launch-bound",
             "filter_scan_a4": {
-                "kernel": "k_toep_wide (warmup_ZY's conv(S,D) pair as one Toeplitz GEMM on v_mfma_f32_32x32x2_f32; model.jl:171-173)",
+                "kernel": "k_onehot_bank_scan (warmup_ZY's conv(S,D) pair, model.jl:171-173: S is one-hot, so each output is fl bank rows picked by base "
+                          "code from LDS and added in the GEMM's order; MOTIFS_NO_ONEHOT_SCAN=1: k_toep_wide, the Toeplitz GEMM on the f32 image)",
                 "bound": "hbm", "achieved": a4_bytes / (a4_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": a4_bytes / (a4_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_launch_ms": a4_ms, "algorithmic_bytes": a4_bytes,
                 "reads_per_launch": St, "bases_per_s": St * L / (a4_ms * 1e-3),

@@ -84,6 +84,9 @@ struct SpDims {
     int64_t ldf;   // filter elements per group (h*W*K), 0 = shared
 };
 
+void dev_zero(hipStream_t st, float* p, size_t n);                    // n floats of zero, as a kernel
+void dev_copy(hipStream_t st, float* dst, const float* src, size_t n);   // n floats device to device, as a kernel
+
 struct Engine {
     hipStream_t st = nullptr;
     Arena arena;
@@ -91,6 +94,7 @@ struct Engine {
     std::vector<TNode*> nodes;
     bool recording = true;
     bool failed = false;           // arena exhausted
+    bool onehot_attr_set = false;  // k_onehot_bank_scan's dynamic-LDS attribute has been set on this engine's device
     // re-laid-out copies of filter banks (fragment order, flipped, transposed), keyed by source and kind: a bank serves
     // many calls of a pass and its contents are final when the first of them runs
     struct RelayoutKey {
@@ -149,6 +153,9 @@ struct Engine {
     // coef * sum_group (x + b*[y >= thr[group]]*y)^2 without writing the residual
     Tensor resid_sumsq_groups(Tensor x, Tensor y, float b, const float* thr, float coef, int groups);
     Tensor toep(Tensor A, Tensor Bm, const ToepGeom& gm);                 // Toeplitz GEMM
+    // the same product when A is the one-hot image of `codes` (rows of `pitch` bytes, 0..3, 4 = all-zero column) and the windows
+    // advance by whole positions (gm.sa == 4): the forward is fl gathered bank rows per output row, no GEMM; the backward is toep's
+    Tensor toep_onehot(Tensor A, const uint8_t* codes, int pitch, Tensor Bm, const ToepGeom& gm);
     Tensor wgrad(Tensor A, Tensor C, const ToepGeom& gm);                 // [G][Q][N] = sum_{s,p} Aw * C
     // syntax layer with sparse codes (X keeps ~q entries per read; gradients into it are masked):
     Tensor sp_syn(Tensor T, Tensor FAf, Tensor Fk, const SpDims& d);      // FX = sum(conv(X,F,pad,groups=K),dims=3)

@@ -14,6 +14,29 @@ static inline unsigned nblocks(size_t n, int per = 256, size_t cap = 256 * 32) {
     return (unsigned)std::min(b, cap);
 }
 
+// Fills and device-to-device copies of the step as plain kernels (no hipMemsetAsync / hipMemcpyAsync): one kind of node for
+// the stream and for a captured step alike.  All buffers of the engine are float arrays.
+__global__ __launch_bounds__(256) void k_zero4(uint4* __restrict__ p, size_t n16, float* __restrict__ tail, int ntail) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride) p[i] = make_uint4(0, 0, 0, 0);
+    if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = 0.0f;
+}
+__global__ __launch_bounds__(256) void k_copy1(const float* __restrict__ src, float* __restrict__ dst, size_t n) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+}
+void dev_zero(hipStream_t st, float* p, size_t n) {
+    if (!n) return;
+    size_t head = (((uintptr_t)p + 15) & ~(uintptr_t)15) - (uintptr_t)p;      // bytes up to 16-byte alignment
+    head = std::min(head / 4, n);
+    if (head) hipLaunchKernelGGL(k_zero4, dim3(1), dim3(256), 0, st, (uint4*)nullptr, (size_t)0, p, (int)head);
+    const size_t rest = n - head, n16 = rest / 4;
+    hipLaunchKernelGGL(k_zero4, dim3(nblocks(n16, 256 * 4, 2048)), dim3(256), 0, st, (uint4*)(p + head), n16, p + head + n16 * 4, (int)(rest & 3));
+}
+void dev_copy(hipStream_t st, float* dst, const float* src, size_t n) {
+    if (n) hipLaunchKernelGGL(k_copy1, dim3(nblocks(n, 256 * 4, 2048)), dim3(256), 0, st, src, dst, n);
+}
+
 // ---------------------------------------------------------------------------------------------
 // engine bookkeeping
 // ---------------------------------------------------------------------------------------------
@@ -59,7 +82,7 @@ float* Engine::zeros(size_t n) {
             failed = true;
             return nullptr;
         }
-        (void)hipMemsetAsync(p, 0, n * 4, st);
+        dev_zero(st, p, n);
         return p;
     }
     const size_t need = (n + 63) & ~(size_t)63;    // keep 256-byte alignment
@@ -70,7 +93,7 @@ float* Engine::zeros(size_t n) {
             zleft = 0;
             return nullptr;
         }
-        (void)hipMemsetAsync(zpool, 0, CHUNK * 4, st);
+        dev_zero(st, zpool, CHUNK);
         zleft = CHUNK;
     }
     float* p = zpool;
@@ -897,7 +920,7 @@ Tensor Engine::resid_sumsq_groups(Tensor x, Tensor y, float b, const float* thr,
     Tensor out = make(groups, x->needs_grad || y->needs_grad);
     if (failed) return out;
     const size_t per = x->n / groups;
-    (void)hipMemsetAsync(out->v, 0, (size_t)groups * 4, st);
+    dev_zero(st, out->v, (size_t)groups);
     hipLaunchKernelGGL(k_resid_sumsq, dim3(nblocks(per, 256, 64), groups), dim3(256), 0, st, x->v, y->v, thr, b, per, coef, out->v);
     if (recording && out->needs_grad)
         tape.push_back([this, out, x, y, b, thr, per, coef, groups]() {
@@ -916,7 +939,7 @@ Tensor Engine::sumsq_groups(Tensor x, float coef, int groups) {
     Tensor out = make(groups, x->needs_grad);
     if (failed) return out;
     const size_t per = x->n / groups;
-    (void)hipMemsetAsync(out->v, 0, (size_t)groups * 4, st);
+    dev_zero(st, out->v, (size_t)groups);
     hipLaunchKernelGGL(k_sumsq_groups, dim3(nblocks(per, 256, 64), groups), dim3(256), 0, st, x->v, per, coef, out->v);
     if (recording && out->needs_grad)
         tape.push_back([this, out, x, per, coef]() {
@@ -2367,6 +2390,125 @@ static bool toep_adjoint_a(Engine& e, const float* dC, const float* Bm, float* d
     return true;
 }
 
+// a4 (warmup_ZY's conv(S, D, flipped=true) | conv(S, D), model.jl:171-173) on base codes.  S is one-hot, so the Toeplitz GEMM
+// out[s][p][n] = sum_q S[s][4p + q] Bm[q][n] collapses to fl gathered rows of the bank per output row:
+// out[s][p][:] = sum_{k < fl} Bm[4k + code[s][p + k]][:] ("fl gathered adds").  The pass is then bound by writing the
+// codes image (2 c M floats per read: 302 KB at configs[1]), not by a contraction: the bank sits in LDS (one extra zero row for
+// an all-zero column), a block streams one read's rows, every lane adds its four columns of fl rows and stores 16 bytes.
+constexpr int OH_TPB = 1024;   // sixteen waves share one copy of the bank: LDS round trips of different rows overlap
+// The launch is a fixed number of blocks (two per CU); block b takes the b-th equal share of ALL output rows of the launch, S * P of
+// them in (read, position) order - a share may straddle reads - and stages the bank once.  (One block per read left a third of
+// the chip idle in the second round at 384 reads: 38.7 us against 55.6 with 256-thread blocks, and against 46 for the GEMM form.)
+template <int FL>       // filter length; 0 = run-time
+__global__ __launch_bounds__(OH_TPB) void k_onehot_bank_scan(const uint8_t* __restrict__ codes, int pitch, const float* __restrict__ Bm,
+                                                          float* __restrict__ out, ToepGeom gm, int fl_rt, int L) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int fl = FL ? FL : fl_rt;
+    const int N4 = gm.N >> 2, Q = gm.Q;
+    float4* bank = (float4*)lds;                           // [Q + 1][N4]; the shared bank (gm.ldb == 0)
+    const int tid = threadIdx.x;
+    const float4* B4 = (const float4*)Bm;
+    for (int i = tid; i < Q * N4; i += OH_TPB) bank[i] = B4[i];
+    for (int i = tid; i < N4; i += OH_TPB) bank[(size_t)Q * N4 + i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    const int rows_par = OH_TPB / N4;                     // rows in flight per block (10 at N = 400)
+    const int rs = tid / N4, cg = tid - rs * N4;
+    if (rs >= rows_par) return;
+    const int64_t total = (int64_t)gm.S * gm.P;
+    const int64_t per = (total + gridDim.x - 1) / gridDim.x;
+    const int64_t r_lo = (int64_t)blockIdx.x * per, r_hi = r_lo + per < total ? r_lo + per : total;
+    for (int64_t r = r_lo + rs; r < r_hi; r += rows_par) {
+        const int sq = (int)(r / gm.P), p = (int)(r - (int64_t)sq * gm.P);
+        const uint8_t* cd = codes + (size_t)sq * pitch + p;        // the row's fl codes: the same bytes for every lane of the row (L1 / scalar-like)
+        float4* o4 = (float4*)(out + (size_t)sq * gm.ldc) + (size_t)p * N4 + cg;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (FL) {
+            // all FL code bytes, then all FL bank rows, in flight before the adds: two round trips per output row, not 2 FL
+            int c[FL ? FL : 1];
+            {   // the row's FL code bytes as aligned dwords + a funnel shift (the rows carry >= 4 bytes of padding and the matrix a
+                // guard behind its last row, so the dword past the window's end is readable): FL/4 + 1 loads instead of FL
+                const uintptr_t ad = (uintptr_t)cd;
+                const uint32_t* wp = (const uint32_t*)(ad & ~(uintptr_t)3);
+                const uint32_t sh = (uint32_t)(ad & 3);
+                uint32_t wds[FL / 4 + 2];
+#pragma unroll
+                for (int j = 0; j < FL / 4 + 2; j++) wds[j] = wp[j];
+#pragma unroll
+                for (int k = 0; k < FL; k++) {
+                    const uint32_t al = __builtin_amdgcn_alignbyte(wds[k / 4 + 1], wds[k / 4], sh);
+                    const int cc = (int)((al >> (8 * (k % 4))) & 0xffu);
+                    c[k] = p + k < L ? cc : 4;
+                }
+            }
+            float4 w[FL ? FL : 1];
+#pragma unroll
+            for (int k = 0; k < FL; k++) w[k] = bank[(size_t)(c[k] < 4 ? 4 * k + c[k] : Q) * N4 + cg];
+#pragma unroll
+            for (int k = 0; k < FL; k++) acc.x += w[k].x, acc.y += w[k].y, acc.z += w[k].z, acc.w += w[k].w;
+        } else {
+            for (int k = 0; k < fl; k++) {
+                const int c = p + k < L ? cd[k] : 4;
+                const float4 w = bank[(size_t)(c < 4 ? 4 * k + c : Q) * N4 + cg];
+                acc.x += w.x, acc.y += w.y, acc.z += w.z, acc.w += w.w;
+            }
+        }
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        __builtin_nontemporal_store(f32x4{acc.x, acc.y, acc.z, acc.w}, (f32x4*)o4);      // written once, read by the next kernel from HBM anyway
+    }
+}
+
+Tensor Engine::toep_onehot(Tensor A, const uint8_t* codes, int pitch, Tensor Bm, const ToepGeom& gm) {
+    const int fl = gm.Q / 4, L = (int)(gm.lda / 4);
+    const size_t lds = ((size_t)(gm.Q + 1) * gm.N * 4 + 15) & ~(size_t)15;
+    // few reads (the reference's 6-read step) leave most CUs without a block, and a bank past the LDS has no fast path here: the GEMM form
+    static const bool off = getenv("MOTIFS_NO_ONEHOT_SCAN") != nullptr;      // A/B: the GEMM form for every launch
+    if (off || !codes || gm.sa != 4 || gm.a0 != 0 || (gm.N & 3) || gm.N > 1024 || gm.Q != 4 * fl || gm.S < 96 || lds > 80 * 1024 || gm.ldb != 0 ||
+        gm.P + fl - 1 > L)
+        return toep(A, Bm, gm);
+    Tensor out = make((size_t)gm.S * gm.ldc, A->needs_grad || Bm->needs_grad);
+    if (failed) return out;
+    auto go = [&](auto kern) {
+        if (!onehot_attr_set) {      // once per engine (an engine lives on one device): the call costs more than the kernel's launch
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            onehot_attr_set = true;
+        }
+        hipLaunchKernelGGL(kern, dim3(512), dim3(OH_TPB), lds, st, codes, pitch, Bm->v, out->v, gm, fl, L);    // two blocks per CU
+    };
+    if (fl == 8) go(k_onehot_bank_scan<8>);
+    else if (fl == 12) go(k_onehot_bank_scan<12>);
+    else if (fl == 16) go(k_onehot_bank_scan<16>);
+    else if (fl == 20) go(k_onehot_bank_scan<20>);
+    else go(k_onehot_bank_scan<0>);
+    if (recording && out->needs_grad)
+        tape.push_back([this, out, A, Bm, gm]() {          // the adjoints of toep(): the image A holds the same one-hot values
+            if (!out->g) return;
+            if (A->needs_grad) {
+                int a = 1;
+                const bool whole = gm.amax == gm.lda && gm.amax % gm.sa == 0;
+                float* dA = whole ? grad_first(A, a) : grad(A);
+                if (dA) toep_adjoint_a(*this, out->g, Bm->v, dA, gm, a);
+            }
+            if (Bm->needs_grad) {
+                float* dB = grad(Bm);
+                if (!dB) return;
+                const int G = gm.S / gm.B;
+                if (gm.ldb != 0 || G == 1) {
+                    launch_wgrad(*this, A->v, out->g, dB, gm, 1);
+                } else {
+                    const size_t per = (size_t)gm.Q * gm.N;
+                    float* tmp = arena.alloc(per * G);
+                    if (!tmp) {
+                        failed = true;
+                        return;
+                    }
+                    launch_wgrad(*this, A->v, out->g, tmp, gm, 0);
+                    hipLaunchKernelGGL(k_sum_groups, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, st, tmp, per, G, dB);
+                }
+            }
+        });
+    return out;
+}
+
 Tensor Engine::toep(Tensor A, Tensor Bm, const ToepGeom& gm) {
     Tensor out = make((size_t)gm.S * gm.ldc, A->needs_grad || Bm->needs_grad);
     if (failed) return out;
@@ -2911,7 +3053,7 @@ Tensor Engine::sp_syn(Tensor T, Tensor FAf, Tensor Fk, const SpDims& d) {
                         failed = true;
                         return;
                     }
-                    (void)hipMemsetAsync(tmp, 0, per * G * 4, st);
+                    dev_zero(st, tmp, per * G);
                     hipLaunchKernelGGL(k_sp_wgrad_syn, dim3((d.W + 127) / 128, d.h, G), dim3(128), (size_t)d.K * 128 * 4, st, nz, out->g, tmp, d);
                     hipLaunchKernelGGL(k_sum_groups, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, st, tmp, per, G, dF);
                 }

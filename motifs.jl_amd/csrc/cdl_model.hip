@@ -64,6 +64,7 @@ struct Graph {
     int G, S;
     ToepGeom gD1, gD2, gF1, gF2;
     Tensor Sone;
+    const uint8_t* codes = nullptr;   // the base codes Sone was made from (rows of motifs_codes_pitch(L) bytes): a4 reads them directly
     Tensor pre_of = nullptr;          // codes written by a step kernel that filled pass 0 of their median select, and its workspace
     float* pre_ws = nullptr;
     float* med_ws() { return e.zeros(median_workspace_bytes(G) / 4 + 64); }
@@ -130,7 +131,10 @@ struct Graph {
         return Bank{FA, e.flipT(FA, g, m->h, m->twoM, m->K), F, g};
     }
     Tensor synD(Tensor ZY, const Bank& b) { return e.toep(ZY, b.syn, with(gD2, b.g)); }     // sum_m conv(Z,D)+conv(Y,D,flipped)
-    Tensor anaD(Tensor sig, const Bank& b) { return e.toep(sig, b.an, with(gD1, b.g)); }    // [conv(.,D,flipped) | conv(.,D)] rows 1:4:end
+    Tensor anaD(Tensor sig, const Bank& b) {      // [conv(.,D,flipped) | conv(.,D)] rows 1:4:end
+        if (sig == Sone && codes) return e.toep_onehot(sig, codes, motifs_codes_pitch(m->L), b.an, with(gD1, b.g));   // a4: the reads themselves
+        return e.toep(sig, b.an, with(gD1, b.g));
+    }
     // syntax layer: X keeps ~q entries per read, so synthesis and every adjoint run per non-zero
     Tensor synF(Tensor X, const Bank& b) { return e.sp_syn(X, b.syn, b.raw, spd(b.g)); }    // sum(conv(X,F,pad,groups=K),dims=3)
     Tensor anaF(Tensor img, const Bank& b) { return e.ana_sp(img, b.an, b.syn, spd(b.g), with(gF1, b.g)); }   // conv(img,F,flipped)
@@ -361,9 +365,10 @@ static int enqueue_loss_grad(motifs_model* m, hipStream_t st, const uint8_t* cod
     e.reset();
     e.recording = grad_flat_dev != nullptr;
     e.keep_named = keep_intermediates != 0;
-    MOTIFS_HIP_CHECK(hipMemsetAsync(m->grads, 0, m->nP * 4, e.st));
+    dev_zero(e.st, m->grads, m->nP);
     Graph gr(m, n_groups);
     gr.Sone = make_onehot(m, codes_dev, gr.S);
+    gr.codes = codes_dev;
     Tensor Lv = forward_loss(m, gr, e.recording);
     if (!e.failed && e.recording) {
         float* g = e.grad(Lv);
@@ -375,8 +380,8 @@ static int enqueue_loss_grad(motifs_model* m, hipStream_t st, const uint8_t* cod
                   m->arena_bytes);
         return MOTIFS_ERR_UNSUPPORTED;
     }
-    if (loss_dev) MOTIFS_HIP_CHECK(hipMemcpyAsync(loss_dev, Lv->v, (size_t)n_groups * 4, hipMemcpyDeviceToDevice, e.st));
-    if (grad_flat_dev) MOTIFS_HIP_CHECK(hipMemcpyAsync(grad_flat_dev, m->grads, m->nP * 4, hipMemcpyDeviceToDevice, e.st));
+    if (loss_dev) dev_copy(e.st, loss_dev, Lv->v, (size_t)n_groups);
+    if (grad_flat_dev) dev_copy(e.st, grad_flat_dev, m->grads, m->nP);
     MOTIFS_HIP_CHECK(hipGetLastError());
     return MOTIFS_OK;
 }
@@ -542,12 +547,12 @@ int motifs_model_loss_grad_dev(motifs_model* m, const uint8_t* codes_dev, int n_
     }
     MOTIFS_HIP_CHECK(hipSetDevice(m->ctx->device));
     KernelTimer tm(m->ctx, KS_TRAIN_STEP);
-    // Replays only on the context's own private stream.  On a caller's stream (motifs_ctx_set_stream; HIP's legacy null stream
-    // in particular) a replayed step came back with gradients of ~1e28 on ROCm 7.0 / 7.2 - also with the replay fenced off on a
-    // side stream and with the device idle around it, so it is the captured graph, not its ordering, that goes wrong there
-    // (tests/test_round3_gpu.py::test_step_graph_on_the_null_stream; found in round 3).  The replay is worth 1.5 % of a
-    // 6-read step: such contexts stay eager.
-    if (!m->use_graphs || !m->ctx->own_stream || keep_intermediates || n_groups > m->graph_max_groups)
+    // Every node of the captured step is a kernel: dev_zero / dev_copy instead of hipMemsetAsync / hipMemcpyAsync.  With memset
+    // and memcpy nodes in it (rounds 2 and 3, ROCm 7.0 / 7.2) a replay was not ordered with its neighbours: on the context's
+    // own stream later replays returned the loss of a half-updated buffer whenever the reads behind the same pointers had
+    // changed, and on HIP's legacy null stream gradients of ~1e28 (tests/test_model_gpu.py::
+    // test_replayed_steps_follow_the_reads, tests/test_round3_gpu.py::test_step_graph_on_the_null_stream).
+    if (!m->use_graphs || keep_intermediates || n_groups > m->graph_max_groups)
         return enqueue_loss_grad(m, m->ctx->stream, codes_dev, n_groups, loss_dev, grad_flat_dev, keep_intermediates);
     motifs_model::StepGraph* sg = nullptr;
     for (auto& g : m->step_graphs)
@@ -905,6 +910,7 @@ int motifs_model_retrieve_codes(motifs_model* m, const void* data, int kind, int
         e.keep_named = false;
         Graph gr(m, G);
         gr.Sone = make_onehot(m, (const uint8_t*)c->codes.p, (int)S);
+        gr.codes = (const uint8_t*)c->codes.p;
         Tensor Draw = e.wrap(m->params, nullptr, m->nD, false), Fraw = e.wrap(m->params + m->nD, nullptr, m->nF, false);
         Scalars sc = prep_scalars(m, gr, false);
         Tensor Dp = e.norm4(e.lin(gr.sq(Draw), 1.0f, nullptr, 0.0f, 0.001f));
@@ -969,6 +975,7 @@ int motifs_model_time_filter_scan(motifs_model* m, const uint8_t* codes_dev, int
     e.keep_named = false;
     Graph gr(m, n_groups);
     gr.Sone = make_onehot(m, codes_dev, gr.S);
+    gr.codes = codes_dev;
     Tensor Draw = e.wrap(m->params, nullptr, m->nD, false);
     Tensor Dp = e.norm4(e.lin(gr.sq(Draw), 1.0f, nullptr, 0.0f, 0.001f));
     Graph::Bank bD = gr.bankD(Dp, 1);
@@ -1010,6 +1017,7 @@ int motifs_model_time_syntax_conv(motifs_model* m, const uint8_t* codes_dev, int
     e.keep_named = false;
     Graph gr(m, n_groups);
     gr.Sone = make_onehot(m, codes_dev, gr.S);
+    gr.codes = codes_dev;
     Tensor Draw = e.wrap(m->params, nullptr, m->nD, false), Fraw = e.wrap(m->params + m->nD, nullptr, m->nF, false);
     Tensor Dp = e.norm4(e.lin(gr.sq(Draw), 1.0f, nullptr, 0.0f, 0.001f));
     Tensor Fp = e.norml2(gr.sq(Fraw), m->h * m->twoM);

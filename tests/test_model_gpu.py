@@ -293,6 +293,28 @@ def test_groups_are_independent(ctx, pkg):
     assert rel_inf(flat, acc) <= 1e-5
 
 
+def test_filter_bank_scan_on_base_codes_equals_the_gemm_form(ctx, pkg):
+    """a4 (warmup_ZY's conv pair) reads the base codes and gathers fl bank rows per output row once a launch has >= 96 reads
+    (k_onehot_bank_scan); below that it is the Toeplitz GEMM on the one-hot image.  The same 32 mini-batches (96 reads, one with an
+    all-zero column) in one launch and in four launches of 8 give the same losses and the same summed gradient."""
+    G, B, Lbp = 32, 3, 40
+    hp = mo.Hyperparam(filter_len=8, M=6, h=3, K=4, q=6, batch_size=B, num_pass_xyz=2, num_pass_df=2)     # 2M = 12 columns: four per lane
+    rng = np.random.default_rng(21)
+    codes = rng.integers(0, 4, size=(G * B, Lbp)).astype(np.uint8)
+    cdl_o = mo.UCDL(hp, rng).to(torch.float64)
+    codes[5, 7] = 4
+    codes[95, Lbp - 1] = 4
+    B = hp.batch_size
+    cdl = to_model(pkg, ctx, hp, codes.shape[1], cdl_o)
+    loss, flat = gpu_loss_grad(pkg, ctx, cdl, codes, 32)
+    acc = np.zeros_like(flat, dtype=np.float64)
+    for g0 in range(0, 32, 8):
+        l8, f8 = gpu_loss_grad(pkg, ctx, cdl, codes[g0 * B:(g0 + 8) * B], 8)
+        assert np.allclose(l8, loss[g0:g0 + 8], rtol=2e-6, atol=0)
+        acc += f8
+    assert rel_inf(flat, acc) <= 1e-5
+
+
 def test_train_ucdl_runs_and_code_retrieval_format(ctx, pkg):
     md = pkg.model
     hp = md.Hyperparam(filter_len=4, M=6, h=3, K=4, q=5, batch_size=3)
@@ -327,6 +349,48 @@ def test_cfg4_shape_runs(ctx, pkg):
         acc += f1
     assert rel_inf(flat, acc) <= 1e-4
     cdl.model.close()
+
+
+@pytest.mark.parametrize("null_stream", [False, True])
+def test_replayed_steps_follow_the_reads(pkg, null_stream):
+    """The reference's schedule (train.jl:40-46): one mini-batch per step, every step other reads behind the same pointers.
+    From the third step on the launches are replayed from a hipGraph; each replay must give the loss and the gradient of ITS
+    reads.  With hipMemsetAsync / hipMemcpyAsync nodes in the captured step (round 2) later replays did not (group 3 of 32
+    came back as 35.8199 for 35.7228): twelve one-mini-batch steps against one eager step of twelve (> 8: never captured)."""
+    md, sy, lib = pkg.model, pkg.synth, pkg._lib
+    c = lib.Context(0)
+    if null_stream:
+        c.set_stream(0)
+    try:
+        hp = md.Hyperparam(filter_len=8, M=6, K=4, q=6, h=3, batch_size=3, num_pass_xyz=2, num_pass_df=2)
+        L, G = 40, 12
+        cdl = md.ucdl(hp, L, ctx=c, seed=5, arena_bytes=1 << 30)
+        codes = np.random.default_rng(21).integers(0, 4, size=(G * hp.batch_size, L)).astype(np.uint8)
+        nP = cdl.model.nP
+
+        def run(rows, n, dcodes, loss, grad):
+            raw = torch.from_numpy(np.ascontiguousarray(rows)).cuda()
+            torch.cuda.synchronize()
+            c.encode_dev(raw.data_ptr(), lib.DATA_CODES_U8, rows.shape[0], L, dcodes.data_ptr())
+            cdl.model.loss_grad_dev(dcodes.data_ptr(), n, loss.data_ptr(), grad.data_ptr())
+            c.synchronize()
+            return loss.cpu().numpy().copy(), grad.cpu().numpy().copy()
+
+        big = [torch.zeros(lib.Context.codes_bytes(G * hp.batch_size, L), dtype=torch.uint8, device="cuda"),
+               torch.zeros(G, dtype=torch.float32, device="cuda"), torch.zeros(nP, dtype=torch.float32, device="cuda")]
+        l_all, g_all = run(codes, G, *big)
+        one = [torch.zeros(lib.Context.codes_bytes(hp.batch_size, L), dtype=torch.uint8, device="cuda"),
+               torch.zeros(1, dtype=torch.float32, device="cuda"), torch.zeros(nP, dtype=torch.float32, device="cuda")]
+        l_one, g_sum = [], np.zeros(nP, dtype=np.float64)
+        for g in range(G):
+            l, gr = run(codes[g * hp.batch_size:(g + 1) * hp.batch_size], 1, *one)
+            l_one.append(l[0])
+            g_sum += gr
+        assert np.allclose(np.array(l_one), l_all, rtol=2e-6), (l_one, l_all)
+        assert np.allclose(g_sum, g_all, rtol=0, atol=1e-5 * np.abs(g_all).max())
+        cdl.model.close()
+    finally:
+        c.close()
 
 
 def test_step_graph_replay_equals_eager(ctx, pkg):

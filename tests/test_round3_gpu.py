@@ -158,10 +158,11 @@ def test_grouped_step_reduces_before_it_updates(torch_cuda, pkg):
 
 @pytest.mark.parametrize("null_stream", [False, True])
 def test_step_graph_on_the_null_stream(torch_cuda, pkg, null_stream):
-    """Found in round 3 by the test above: from its third call on a step of <= 8 mini-batches was replayed from a captured
+    """Found in round 3 by the test above: from its third call on a step of <= 8 mini-batches is replayed from a captured
     hipGraph, and with the context on HIP's legacy null stream (motifs_ctx_set_stream(ctx, NULL): torch's default stream)
-    replays returned gradients of ~1e28.  Steps are now replayed only on the context's own private stream and stay eager on a
-    caller's.  Six steps of two default models against an always-eager one, nothing synchronised in between, on either."""
+    replays returned gradients of ~1e28.  The cause was the hipMemsetAsync / hipMemcpyAsync nodes of the captured step; it
+    is all kernels now (dev_zero / dev_copy) and is replayed on any stream.  Six steps of two default models against an
+    always-eager one, nothing synchronised in between, on either stream."""
     import os
 
     torch = torch_cuda
