@@ -94,6 +94,7 @@ struct Engine {
     std::vector<TNode*> nodes;
     bool recording = true;
     bool failed = false;           // arena exhausted
+    bool wgrad_reads_attr_set = false;   // the dynamic-LDS attribute of k_sp_wgrad_*_reads
     bool onehot_attr_set = false;  // k_onehot_bank_scan's dynamic-LDS attribute has been set on this engine's device
     // re-laid-out copies of filter banks (fragment order, flipped, transposed), keyed by source and kind: a bank serves
     // many calls of a pass and its contents are final when the first of them runs

@@ -2180,12 +2180,14 @@ __global__ void k_windows(const float* __restrict__ A, ToepGeom gm, float* __res
         Wn[i] = (e >= 0 && e < gm.amax) ? A[s * gm.lda + e] : 0.0f;
     }
 }
-// dB[g][q][n] (+)= sum_{b < B} part[g B + b][n][q], Q <= 48.  One block per (32 columns n, group): the partial banks
-// are read as contiguous [32][Q] spans, the sums turn in LDS and leave as 128-byte row pieces.
+// dB[g][q][n] (+)= sum_{b < B} part[g B + b][n][q], Q <= 48.  One block per (NT columns n, group): the partial banks
+// are read as contiguous [NT][Q] spans, the sums turn in LDS and leave as row pieces of NT floats.  NT = 32 when there are
+// groups enough to fill the chip; 4 for the reference's one-mini-batch steps (13 blocks of 32 columns took 21 us there).
+template <int NT>
 __global__ __launch_bounds__(256) void k_sum_segments_T(const float* __restrict__ part, int Q, int N, int B, float* __restrict__ dB, int acc) {
-    __shared__ float t[48][33];
-    const int n0 = blockIdx.x * 32, g = blockIdx.y, tid = threadIdx.x;
-    const int nn_max = min(32, N - n0), cnt = nn_max * Q;
+    __shared__ float t[48][NT + 1];
+    const int n0 = blockIdx.x * NT, g = blockIdx.y, tid = threadIdx.x;
+    const int nn_max = min(NT, N - n0), cnt = nn_max * Q;
     const size_t per = (size_t)Q * N;
     for (int idx = tid; idx < cnt; idx += 256) {
         const float* src = part + (size_t)g * B * per + (size_t)n0 * Q + idx;
@@ -2199,8 +2201,8 @@ __global__ __launch_bounds__(256) void k_sum_segments_T(const float* __restrict_
         t[idx % Q][idx / Q] = (a0 + a1) + (a2 + a3);
     }
     __syncthreads();
-    for (int idx = tid; idx < Q * 32; idx += 256) {
-        const int q = idx >> 5, nn = idx & 31;
+    for (int idx = tid; idx < Q * NT; idx += 256) {
+        const int q = idx / NT, nn = idx % NT;
         if (nn < nn_max) {
             float* o = dB + (size_t)g * per + (size_t)q * N + n0 + nn;
             *o = acc ? *o + t[q][nn] : t[q][nn];
@@ -2261,7 +2263,10 @@ static void launch_wgrad(Engine& e, const float* A, const float* C, float* dB, c
         }
         hipLaunchKernelGGL(k_windows, dim3(nblocks((size_t)gm.S * gm.P * gm.Q)), dim3(256), 0, st, A, gm, Wn);
         if (launch_rowwgrad_lds(e, C, Wn, part, rg)) {
-            hipLaunchKernelGGL(k_sum_segments_T, dim3((gm.N + 31) / 32, G), dim3(256), 0, st, part, gm.Q, gm.N, gm.B * rowwgrad_split(rg), dB, acc);
+            if (G * ((gm.N + 31) / 32) >= 128)
+                hipLaunchKernelGGL(k_sum_segments_T<32>, dim3((gm.N + 31) / 32, G), dim3(256), 0, st, part, gm.Q, gm.N, gm.B * rowwgrad_split(rg), dB, acc);
+            else
+                hipLaunchKernelGGL(k_sum_segments_T<4>, dim3((gm.N + 3) / 4, G), dim3(256), 0, st, part, gm.Q, gm.N, gm.B * rowwgrad_split(rg), dB, acc);
             return;
         }
     }
@@ -2702,14 +2707,15 @@ Tensor Engine::flipT(Tensor Bm, int g, int H, int W, int N) {
 // Non-zeros are taken in memory order (deterministic sums).
 // ---------------------------------------------------------------------------------------------
 // Non-zero list of a [S][n] tensor: one block per read, entries in memory order (deterministic sums).
-__global__ __launch_bounds__(256) void k_build_nz(const float* __restrict__ x, int n, int* __restrict__ cnt,
-                                                  uint2* __restrict__ ent) {
-    // every wave owns a contiguous quarter of the read: count, meet once, then write in ascending order
-    __shared__ int wcnt[4];
-    const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+__global__ __launch_bounds__(1024) void k_build_nz(const float* __restrict__ x, int n, int* __restrict__ cnt,
+                                                   uint2* __restrict__ ent) {
+    // every wave owns a contiguous slice of the read: count, meet once, then write in ascending order
+    // (4 waves per read when the reads fill the chip, 16 for the few reads of a small step)
+    __shared__ int wcnt[16];
+    const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nw = blockDim.x >> 6;
     const float* xs = x + (size_t)s * n;
     uint2* es = ent + (size_t)s * n;
-    const int q = (((n + 3) / 4) + 63) & ~63, lo = wv * q, hi = min(n, lo + q);
+    const int q = (((n + nw - 1) / nw) + 63) & ~63, lo = min(n, wv * q), hi = min(n, lo + q);
     int c = 0;
     for (int e0 = lo; e0 < hi; e0 += 64) {
         const int e = e0 + lane;
@@ -2728,7 +2734,11 @@ __global__ __launch_bounds__(256) void k_build_nz(const float* __restrict__ x, i
         if (hit) es[base + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = make_uint2((unsigned)e, __float_as_uint(v));
         base += __builtin_popcountll(m);
     }
-    if (tid == 0) cnt[s] = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    if (tid == 0) {
+        int t = 0;
+        for (int w = 0; w < nw; w++) t += wcnt[w];
+        cnt[s] = t;
+    }
 }
 
 // floor(e / K) for the flat code indices e = p*K + k (e < 2^32 / K): one multiply-high instead of a division.  The entry
@@ -2869,6 +2879,91 @@ __global__ __launch_bounds__(128) void k_sp_wgrad_ana(const float* __restrict__ 
     }
 }
 
+// S2 / S3 for steps of few mini-batches (the reference's schedule: G = 1, 48 blocks on 256 CUs, each walking the entries
+// of all B reads one after the other: 26 us).  Here a block has B wave pairs, pair b walks read b's entries into its own LDS
+// accumulators, and the B partial banks are added in read order on the way out.
+__global__ __launch_bounds__(1024) void k_sp_wgrad_syn_reads(NzView nz, const float* __restrict__ dOut, float* __restrict__ dF, SpDims d) {
+    extern __shared__ float accs[];                      // [B][K][128]
+    const int g = blockIdx.z, ip = blockIdx.y, tx = threadIdx.x & 127, b = threadIdx.x >> 7, j0 = blockIdx.x * 128;
+    const int jc = min(j0 + tx, d.W - 1);
+    float* mine = accs + (size_t)b * d.K * 128;
+    for (int k = 0; k < d.K; k++) mine[k * 128 + tx] = 0.0f;
+    {
+        const int s = g * d.B + b;
+        const float* ds = dOut + (size_t)s * d.c * d.W + (size_t)(d.h - 1 - ip) * d.W + jc;
+        const int cnt = nz.cnt[s];
+        const uint2* es = nz.ent + (size_t)s * nz.cap;
+        for (int z = 0; z < cnt; z++) {                  // wave-uniform
+            const uint2 en = es[z];
+            const int p = (int)__umulhi(en.x, kmagic(d.K)), k = (int)(en.x - (unsigned)p * d.K);
+            mine[k * 128 + tx] = fmaf(__uint_as_float(en.y), ds[(size_t)p * d.W], mine[k * 128 + tx]);
+        }
+    }
+    __syncthreads();
+    float* dFg = dF + (size_t)g * d.h * d.K * d.W + (size_t)ip * d.K * d.W + j0;
+    const int nj = min(128, d.W - j0);
+    for (int idx = threadIdx.x; idx < d.K * 128; idx += blockDim.x) {
+        const int k = idx >> 7, jj = idx & 127;
+        float v = 0.0f;
+        for (int bb = 0; bb < d.B; bb++) v += accs[(size_t)bb * d.K * 128 + idx];
+        if (jj < nj) dFg[(size_t)k * d.W + jj] += v;
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_sp_wgrad_ana_reads(const float* __restrict__ img, NzView nz, float* __restrict__ dB, SpDims d, int acc) {
+    extern __shared__ float accs[];                      // [B][128][K + 1]
+    const int g = blockIdx.z, i = blockIdx.y, tx = threadIdx.x & 127, b = threadIdx.x >> 7, j0 = blockIdx.x * 128;
+    const int jc = min(j0 + tx, d.W - 1);
+    const int per = 128 * (d.K + 1);
+    float* my = accs + (size_t)b * per + (size_t)tx * (d.K + 1);
+    for (int k = 0; k < d.K; k++) my[k] = 0.0f;
+    {
+        const int s = g * d.B + b;
+        const float* is = img + (size_t)s * d.c * d.W + (size_t)i * d.W + jc;
+        const int cnt = nz.cnt[s];
+        const uint2* es = nz.ent + (size_t)s * nz.cap;
+        for (int z = 0; z < cnt; z++) {
+            const uint2 en = es[z];
+            const int p = (int)__umulhi(en.x, kmagic(d.K)), k = (int)(en.x - (unsigned)p * d.K);
+            my[k] = fmaf(__uint_as_float(en.y), is[(size_t)p * d.W], my[k]);
+        }
+    }
+    __syncthreads();
+    const int nj = min(128, d.W - j0);
+    float* span = dB + (size_t)g * d.h * d.W * d.K + ((size_t)i * d.W + j0) * d.K;
+    for (int idx = threadIdx.x; idx < nj * d.K; idx += blockDim.x) {
+        const int jj = idx / d.K, k = idx - jj * d.K;
+        float v = 0.0f;
+        for (int bb = 0; bb < d.B; bb++) v += accs[(size_t)bb * per + jj * (d.K + 1) + k];
+        span[idx] = acc ? span[idx] + v : v;
+    }
+}
+
+// few mini-batches: the per-read form; many: a block per (columns, row, mini-batch) fills the chip by itself
+static bool sp_wgrad_by_reads(Engine& e, const SpDims& d, int G, size_t lds) {
+    if (G > 8 || d.B < 2 || d.B > 8 || lds > (size_t)150 << 10) return false;
+    if (!e.wgrad_reads_attr_set) {
+        (void)hipFuncSetAttribute((const void*)k_sp_wgrad_syn_reads, hipFuncAttributeMaxDynamicSharedMemorySize, 150 << 10);
+        (void)hipFuncSetAttribute((const void*)k_sp_wgrad_ana_reads, hipFuncAttributeMaxDynamicSharedMemorySize, 150 << 10);
+        e.wgrad_reads_attr_set = true;
+    }
+    return true;
+}
+static void launch_sp_wgrad_syn(Engine& e, NzView nz, const float* dOut, float* dF, const SpDims& d, int G) {
+    const size_t lds = (size_t)d.B * d.K * 128 * 4;
+    if (sp_wgrad_by_reads(e, d, G, lds))
+        hipLaunchKernelGGL(k_sp_wgrad_syn_reads, dim3((d.W + 127) / 128, d.h, G), dim3(128 * d.B), lds, e.st, nz, dOut, dF, d);
+    else
+        hipLaunchKernelGGL(k_sp_wgrad_syn, dim3((d.W + 127) / 128, d.h, G), dim3(128), (size_t)d.K * 128 * 4, e.st, nz, dOut, dF, d);
+}
+static void launch_sp_wgrad_ana(Engine& e, const float* img, NzView nz, float* dB, const SpDims& d, int G, int acc) {
+    const size_t lds = (size_t)d.B * 128 * (d.K + 1) * 4;
+    if (sp_wgrad_by_reads(e, d, G, lds))
+        hipLaunchKernelGGL(k_sp_wgrad_ana_reads, dim3((d.W + 127) / 128, d.h, G), dim3(128 * d.B), lds, e.st, img, nz, dB, d, acc);
+    else
+        hipLaunchKernelGGL(k_sp_wgrad_ana, dim3((d.W + 127) / 128, d.h, G), dim3(128), (size_t)128 * (d.K + 1) * 4, e.st, img, nz, dB, d, acc);
+}
+
 // S4: out[s][p][k] += sum_{i,j} img[s][p+i][j] * Fk[g][k][j][i]   only at the listed (masked) entries
 // (one wave per entry; Fk is the reference layout F (h,2M,1,K): i fastest)
 __global__ __launch_bounds__(256) void k_sp_ana_masked(const float* __restrict__ img, const float* __restrict__ Fk,
@@ -2910,7 +3005,7 @@ NzView Engine::nz_build(const float* data, int S, int n_per) {
         failed = true;
         return v;
     }
-    hipLaunchKernelGGL(k_build_nz, dim3(S), dim3(256), 0, st, data, n_per, cnt, ent);
+    hipLaunchKernelGGL(k_build_nz, dim3(S), dim3(S >= 256 ? 256 : 1024), 0, st, data, n_per, cnt, ent);
     v.cnt = cnt;
     v.ent = ent;
     return v;
@@ -2952,25 +3047,36 @@ __global__ __launch_bounds__(256) void k_sp_syn_rows(NzView nz, const float* __r
     __shared__ int lo[RB], hi[RB];
     __shared__ int ep[EC], ek[EC];
     __shared__ float ev[EC];
+    __shared__ unsigned ex[EC];
     const int s = blockIdx.y, r0 = blockIdx.x * RB, tid = threadIdx.x;
-    const int cnt = nz.cnt[s];
     const uint2* es = nz.ent + (size_t)s * nz.cap;
+    // The usual read has a few dozen entries: the whole list comes to LDS in one round of loads issued beside the load of
+    // its length, and the bisections run there (six dependent trips to memory per row before).
+    uint2 mine = make_uint2(0, 0);
+    if (tid < EC && tid < nz.cap) mine = es[tid];
+    const int cnt = nz.cnt[s];
+    const bool all = cnt <= EC;
+    if (all && tid < cnt) {
+        const int p = (int)__umulhi(mine.x, kmagic(d.K));
+        ex[tid] = mine.x, ep[tid] = p, ek[tid] = (int)(mine.x - (unsigned)p * d.K), ev[tid] = __uint_as_float(mine.y);
+    }
+    if (all) __syncthreads();
     if (tid < 2 * RB) {                            // first entry with p >= r - h + 1 (lo) / p >= r + 1 (hi)
         const int r = r0 + (tid % RB);
         const long key = ((long)(tid < RB ? r - d.h + 1 : r + 1)) * d.K;
         int a = 0, b = cnt;
         while (a < b) {
             const int m = (a + b) >> 1;
-            if ((long)es[m].x < key) a = m + 1;
+            if ((long)(all ? ex[m] : es[m].x) < key) a = m + 1;
             else b = m;
         }
         (tid < RB ? lo : hi)[tid % RB] = a;
     }
     __syncthreads();
     const int nrow = min(RB, d.c - r0);
-    const int zb = lo[0], ne = hi[nrow - 1] - zb;
-    const bool cached = ne <= EC;
-    if (cached) {
+    const int zb = all ? 0 : lo[0], ne = hi[nrow - 1] - zb;
+    const bool cached = all || ne <= EC;
+    if (!all && cached) {
         for (int i = tid; i < ne; i += 256) {
             const uint2 en = es[zb + i];
             const int p = (int)__umulhi(en.x, kmagic(d.K));
@@ -3045,7 +3151,7 @@ Tensor Engine::sp_syn(Tensor T, Tensor FAf, Tensor Fk, const SpDims& d) {
                 const int G = d.S / d.B;
                 if (!dF) return;
                 if (d.ldf != 0 || G == 1) {
-                    hipLaunchKernelGGL(k_sp_wgrad_syn, dim3((d.W + 127) / 128, d.h, G), dim3(128), (size_t)d.K * 128 * 4, st, nz, out->g, dF, d);
+                    launch_sp_wgrad_syn(*this, nz, out->g, dF, d, G);
                 } else {
                     const size_t per = (size_t)d.h * d.K * d.W;
                     float* tmp = arena.alloc(per * G);
@@ -3054,7 +3160,7 @@ Tensor Engine::sp_syn(Tensor T, Tensor FAf, Tensor Fk, const SpDims& d) {
                         return;
                     }
                     dev_zero(st, tmp, per * G);
-                    hipLaunchKernelGGL(k_sp_wgrad_syn, dim3((d.W + 127) / 128, d.h, G), dim3(128), (size_t)d.K * 128 * 4, st, nz, out->g, tmp, d);
+                    launch_sp_wgrad_syn(*this, nz, out->g, tmp, d, G);
                     hipLaunchKernelGGL(k_sum_groups, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, st, tmp, per, G, dF);
                 }
             }
@@ -3082,7 +3188,7 @@ Tensor Engine::ana_sp(Tensor img, Tensor FA, Tensor FAf, const SpDims& d, const 
                 const int G = d.S / d.B;
                 if (!dB) return;
                 if (d.ldf != 0 || G == 1) {
-                    hipLaunchKernelGGL(k_sp_wgrad_ana, dim3((d.W + 127) / 128, d.h, G), dim3(128), (size_t)128 * (d.K + 1) * 4, st, img->v, gz, dB, d, 1);
+                    launch_sp_wgrad_ana(*this, img->v, gz, dB, d, G, 1);
                 } else {
                     const size_t per = (size_t)d.h * d.W * d.K;
                     float* tmp = arena.alloc(per * G);
@@ -3090,7 +3196,7 @@ Tensor Engine::ana_sp(Tensor img, Tensor FA, Tensor FAf, const SpDims& d, const 
                         failed = true;
                         return;
                     }
-                    hipLaunchKernelGGL(k_sp_wgrad_ana, dim3((d.W + 127) / 128, d.h, G), dim3(128), (size_t)128 * (d.K + 1) * 4, st, img->v, gz, tmp, d, 0);
+                    launch_sp_wgrad_ana(*this, img->v, gz, tmp, d, G, 0);
                     hipLaunchKernelGGL(k_sum_groups, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, st, tmp, per, G, dB);
                 }
             }
@@ -3104,7 +3210,7 @@ Tensor Engine::wgrad_sp(Tensor img, Tensor T, const SpDims& d) {
     if (failed) return out;
     NzView nz = nz_of(T, d.S);
     if (failed) return out;
-    hipLaunchKernelGGL(k_sp_wgrad_ana, dim3((d.W + 127) / 128, d.h, G), dim3(128), (size_t)128 * (d.K + 1) * 4, st, img->v, nz, out->v, d, 0);
+    launch_sp_wgrad_ana(*this, img->v, nz, out->v, d, G, 0);
     if (recording && out->needs_grad)
         tape.push_back([this, out, img, T, d, G, nz]() {
             if (!out->g) return;
@@ -3209,7 +3315,7 @@ static __device__ __forceinline__ float unkey(uint32_t k) {
 }
 
 // generate_bitmat (model.jl:181-187): per sequence, q-th largest of its l*K values; bitmat = X >= that value
-__global__ __launch_bounds__(256) void k_topq_mask(const float* X, float* bitmat, int n, int q) {
+__global__ __launch_bounds__(1024) void k_topq_mask(const float* X, float* bitmat, int n, int q) {
     __shared__ uint32_t hist[256];
     __shared__ uint32_t sh[2];
     const float* xs = X + (size_t)blockIdx.x * n;
@@ -3218,7 +3324,7 @@ __global__ __launch_bounds__(256) void k_topq_mask(const float* X, float* bitmat
     for (int i = threadIdx.x; i < n; i += blockDim.x) bitmat[(size_t)blockIdx.x * n + i] = xs[i] >= thr ? 1.0f : 0.0f;
 }
 void topq_mask(hipStream_t st, const float* X, float* bitmat, int S, int n_per_seq, int q) {
-    hipLaunchKernelGGL(k_topq_mask, dim3(S), dim3(256), 0, st, X, bitmat, n_per_seq, q);
+    hipLaunchKernelGGL(k_topq_mask, dim3(S), dim3(S >= 256 ? 256 : 1024), 0, st, X, bitmat, n_per_seq, q);   // few reads: more waves per read
 }
 
 // create_ZY_mask (model.jl:194-204): median of the strictly positive entries of the whole mini-batch
