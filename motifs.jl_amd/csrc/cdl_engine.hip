@@ -402,6 +402,9 @@ static __device__ __forceinline__ void zh_end(uint32_t* zh, uint32_t* hist0) {
     }
 }
 // (one grid row per group of `per` elements; hist0 optional)
+// Blocks per group: every block ends with one atomic per occupied bin on its group's histogram - a few dozen addresses -
+// so with the 1772 blocks a single mini-batch used to get, the step took 23 us for 1.8 MB; 256 blocks per group at most.
+static size_t zy_blocks_cap(int G, bool hist) { return std::max<size_t>(std::min<size_t>(256 * 32 / G, hist ? 256 : 256 * 32), 1); }
 __global__ void k_zy_step(const float* ZY, const float* g1, const float* FX, const float* ab, const float* pen, const float* lst,
                           const float* ls, size_t per, float* out, uint32_t* hist0) {
     __shared__ uint32_t zh[ZH_BINS];
@@ -711,7 +714,7 @@ Tensor Engine::zy_step(Tensor ZY, Tensor g1, Tensor FX, Tensor ab, Tensor pen, T
     {
         const int G = hist0 ? groups : 1;
         const size_t per = ZY->n / G;
-        hipLaunchKernelGGL(k_zy_step, dim3(nblocks(per, 256, std::max<size_t>(256 * 32 / G, 1)), G), dim3(256), 0, st, ZY->v, g1->v, FX->v,
+        hipLaunchKernelGGL(k_zy_step, dim3(nblocks(per, 256, zy_blocks_cap(G, hist0 != nullptr)), G), dim3(256), 0, st, ZY->v, g1->v, FX->v,
                            ab ? ab->v : nullptr, pen->v, lst->v, ls->v, per, out->v, hist0);
     }
     if (recording && out->needs_grad)
@@ -801,7 +804,7 @@ std::pair<Tensor, Tensor> Engine::zy_step2(Tensor ZY, Tensor g1, Tensor FX, Tens
     {
         const int G = hist0 ? groups : 1;
         const size_t per = ZY->n / G;
-        hipLaunchKernelGGL(k_zy_step2, dim3(nblocks(per, 256, std::max<size_t>(256 * 32 / G, 1)), G), dim3(256), 0, st, ZY->v, g1->v, FX->v,
+        hipLaunchKernelGGL(k_zy_step2, dim3(nblocks(per, 256, zy_blocks_cap(G, hist0 != nullptr)), G), dim3(256), 0, st, ZY->v, g1->v, FX->v,
                            abp ? abp->v : nullptr, pen->v, lst->v, ls->v, per, out->v, abn->v, hist0);
     }
     if (recording && ng)
@@ -3039,8 +3042,7 @@ static void launch_sp_ana_masked(hipStream_t st, const float* img, const float* 
 // reach row r are the (position-sorted) run with p in (r - h, r], found once per row by bisection.  The image is
 // written (or accumulated) once with 16-byte accesses, the contributions of a row meet in registers in entry order -
 // the same sums as the ring of k_sp_syn, without its serial walk over the entries.
-// RB rows per block: 32 when there are reads enough to fill the chip, 8 for the reference's 6-read steps (each thread then
-// walks a quarter of the dependent filter loads)
+// RB rows per block: 32 when there are reads enough to fill the chip, 2 for the reference's 6-read steps (one output per thread)
 template <int RB>
 __global__ __launch_bounds__(256) void k_sp_syn_rows(NzView nz, const float* __restrict__ FAf, float* __restrict__ out, SpDims d, int acc) {
     constexpr int EC = 256;                        // decoded entries kept in LDS (more: decoded on the fly)
@@ -3092,17 +3094,27 @@ __global__ __launch_bounds__(256) void k_sp_syn_rows(NzView nz, const float* __r
     for (int idx = tid; idx < nrow * W4; idx += 256) {
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
         const int r = r0 + row;
-        for (int z = lo[row]; z < hi[row]; z++) {
-            int p, k;
-            float v;
-            if (cached) {
-                p = ep[z - zb], k = ek[z - zb], v = ev[z - zb];
-            } else {
-                const uint2 en = es[z];
-                p = (int)__umulhi(en.x, kmagic(d.K)), k = (int)(en.x - (unsigned)p * d.K), v = __uint_as_float(en.y);
+        const int zhi = hi[row];
+        for (int z = lo[row]; z < zhi; z += 4) {   // four filter rows in flight: the loop is a chain of dependent trips to memory otherwise
+            float4 f[4];
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                v[u] = 0.0f, f[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (z + u < zhi) {
+                    int p, k;
+                    if (cached) {
+                        p = ep[z + u - zb], k = ek[z + u - zb], v[u] = ev[z + u - zb];
+                    } else {
+                        const uint2 en = es[z + u];
+                        p = (int)__umulhi(en.x, kmagic(d.K)), k = (int)(en.x - (unsigned)p * d.K), v[u] = __uint_as_float(en.y);
+                    }
+                    f[u] = F4[((size_t)(d.h - 1 - (r - p)) * d.K + k) * W4 + c4];
+                }
             }
-            const float4 f = F4[((size_t)(d.h - 1 - (r - p)) * d.K + k) * W4 + c4];
-            a.x = fmaf(v, f.x, a.x), a.y = fmaf(v, f.y, a.y), a.z = fmaf(v, f.z, a.z), a.w = fmaf(v, f.w, a.w);
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (z + u < zhi) a.x = fmaf(v[u], f[u].x, a.x), a.y = fmaf(v[u], f[u].y, a.y), a.z = fmaf(v[u], f[u].z, a.z), a.w = fmaf(v[u], f[u].w, a.w);
         }
         if (acc) {
             const float4 t = o4[idx];
@@ -3118,7 +3130,7 @@ static void launch_sp_syn(hipStream_t st, const NzView& nz, const float* FAf, fl
     static const bool legacy = getenv("MOTIFS_TOEP_LEGACY") != nullptr;
     if (!legacy && (d.W & 3) == 0 && d.W <= 1024 && (d.ldf & 3) == 0 && ((((uintptr_t)FAf) | ((uintptr_t)out)) & 15) == 0) {
         if (d.S >= 48) hipLaunchKernelGGL(k_sp_syn_rows<32>, dim3((d.c + 31) / 32, d.S), dim3(256), 0, st, nz, FAf, out, d, acc);
-        else hipLaunchKernelGGL(k_sp_syn_rows<8>, dim3((d.c + 7) / 8, d.S), dim3(256), 0, st, nz, FAf, out, d, acc);
+        else hipLaunchKernelGGL(k_sp_syn_rows<2>, dim3((d.c + 1) / 2, d.S), dim3(256), 0, st, nz, FAf, out, d, acc);
         return;
     }
     if (d.h == 12) hipLaunchKernelGGL(k_sp_syn<12>, dim3((d.W + 127) / 128, d.S), dim3(128), 0, st, nz, FAf, out, d, acc);
@@ -3335,14 +3347,14 @@ void topq_mask(hipStream_t st, const float* X, float* bitmat, int S, int n_per_s
 // tracked side by side.
 struct MedState {
     uint32_t cnt, pref[2], k[2];
+    uint32_t ticket;       // blocks of the running histogram pass that have delivered (the last one makes the digit choice)
 };
 constexpr int MED_BINS = 2048;
 static __host__ __device__ __forceinline__ int med_shift(int pass) { return pass == 0 ? 21 : pass == 1 ? 10 : 0; }
 static __host__ __device__ __forceinline__ int med_bits(int pass) { return pass == 2 ? 10 : 11; }
 
-__global__ __launch_bounds__(256) void k_med_hist(const float* __restrict__ x, int n, const MedState* __restrict__ state,
-                                                  uint32_t* __restrict__ hist, int pass) {
-    __shared__ uint32_t h[2][MED_BINS];
+static __device__ __forceinline__ void med_hist_block(const float* __restrict__ x, int n, const MedState* state, uint32_t* hist, int pass,
+                                                      uint32_t (*h)[MED_BINS]) {
     const int g = blockIdx.y;
     for (int i = threadIdx.x; i < 2 * MED_BINS; i += 256) (&h[0][0])[i] = 0;
     __syncthreads();
@@ -3384,11 +3396,11 @@ __global__ __launch_bounds__(256) void k_med_hist(const float* __restrict__ x, i
     }
 }
 
-// digit choice: the first bin whose running count exceeds k (the last bin if none does); 256 threads x 8 bins
-__global__ __launch_bounds__(256) void k_med_select(MedState* state, uint32_t* hist, int pass) {
-    __shared__ uint32_t part[256];
-    __shared__ MedState sst;
-    const int g = blockIdx.x, tid = threadIdx.x, shift = med_shift(pass);
+// digit choice: the first bin whose running count exceeds k (the last bin if none does); 256 threads x 8 bins.
+// COHERENT: the histogram was filled by other blocks of the same launch (read past the caches, agent scope).
+template <bool COHERENT>
+static __device__ void med_select_block(MedState* state, uint32_t* hist, int pass, int g, float* thr, uint32_t* part, MedState& sst) {
+    const int tid = threadIdx.x, shift = med_shift(pass);
     uint32_t* h = hist + (size_t)g * 2 * MED_BINS;
     if (tid == 0) sst = state[g];
     __syncthreads();
@@ -3396,7 +3408,10 @@ __global__ __launch_bounds__(256) void k_med_select(MedState* state, uint32_t* h
         const uint32_t* hh = h + (pass == 0 ? 0 : sel * MED_BINS);
         uint32_t loc[8], sum = 0;
 #pragma unroll
-        for (int j = 0; j < 8; j++) loc[j] = hh[tid * 8 + j], sum += loc[j];
+        for (int j = 0; j < 8; j++) {
+            loc[j] = COHERENT ? __hip_atomic_load(&hh[tid * 8 + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : hh[tid * 8 + j];
+            sum += loc[j];
+        }
         part[tid] = sum;
         __syncthreads();
         for (int d = 1; d < 256; d <<= 1) {        // inclusive scan
@@ -3430,20 +3445,50 @@ __global__ __launch_bounds__(256) void k_med_select(MedState* state, uint32_t* h
         }
         __syncthreads();
     }
-    if (tid == 0) state[g] = sst;
+    if (tid == 0) {
+        sst.ticket = 0;
+        state[g] = sst;
+        if (thr) {                                     // after the last pass: the median itself
+            float med = -INFINITY;                     // no positive entry: everything passes
+            if (sst.cnt) {
+                const float lo = __uint_as_float(sst.pref[0]), hi = __uint_as_float(sst.pref[1]);
+                med = (sst.cnt & 1u) ? lo : lo / 2 + hi / 2;
+            }
+            thr[g] = med;
+        }
+    }
     for (int i = tid; i < 2 * MED_BINS; i += 256) h[i] = 0;   // ready for the next pass
 }
+__global__ __launch_bounds__(256) void k_med_select(MedState* state, uint32_t* hist, int pass, float* thr) {
+    __shared__ uint32_t part[256];
+    __shared__ MedState sst;
+    med_select_block<false>(state, hist, pass, blockIdx.x, thr, part, sst);
+}
 
-__global__ void k_med_thr(const MedState* __restrict__ state, int G, float* __restrict__ thr) {
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= G) return;
-    const MedState st = state[g];
-    float med = -INFINITY;                         // no positive entry: everything passes
-    if (st.cnt) {
-        const float lo = __uint_as_float(st.pref[0]), hi = __uint_as_float(st.pref[1]);
-        med = (st.cnt & 1u) ? lo : lo / 2 + hi / 2;
-    }
-    thr[g] = med;
+__global__ __launch_bounds__(256) void k_med_hist(const float* __restrict__ x, int n, const MedState* state, uint32_t* hist, int pass) {
+    __shared__ uint32_t h[2][MED_BINS];
+    med_hist_block(x, n, state, hist, pass, h);
+}
+
+// One pass of the select in one launch: every block adds its digits to the group's histogram and takes a ticket; the block that
+// draws the last one finds all counts delivered and makes the digit choice (three launches per median instead of six or seven
+// - the reference's one-mini-batch steps are made of launches of ~5 us).  Only for steps of few mini-batches: the fence in
+// front of the ticket is an L2 write-back per block, and with the 4096 blocks of a 64-mini-batch step a pass took 420 us
+// against 33 + 6 us for the two launches.
+__global__ __launch_bounds__(256) void k_med_pass(const float* __restrict__ x, int n, MedState* state, uint32_t* hist, int pass, float* thr) {
+    __shared__ uint32_t h[2][MED_BINS];
+    __shared__ uint32_t part[256];
+    __shared__ MedState sst;
+    __shared__ uint32_t drawn;
+    const int g = blockIdx.y;
+    med_hist_block(x, n, state, hist, pass, h);
+    __threadfence();                                   // this block's counts are visible to the device before its ticket is
+    __syncthreads();
+    if (threadIdx.x == 0) drawn = atomicAdd(&state[g].ticket, 1u);
+    __syncthreads();
+    if (drawn != gridDim.x - 1) return;
+    __threadfence();
+    med_select_block<true>(state, hist, pass, g, thr, part, sst);
 }
 
 static_assert(MED_BINS == ZH_BINS, "the fused first pass (zy_step kernels) fills the same histogram");
@@ -3455,11 +3500,16 @@ void median_threshold(hipStream_t st, const float* ZY, float* thr, int G, int n_
     uint32_t* hist = median_hist_ptr(workspace, G);
     const unsigned nb = (unsigned)std::min<size_t>((n_per_group + 256 * 16 - 1) / (256 * 16), 64);
     for (int pass = 0; pass < 3; pass++) {            // the workspace arrives zeroed (Engine::zeros)
-        if (!(pass == 0 && have_pass0))               // the kernel that wrote the codes may have counted the top digits already
+        float* out = pass == 2 ? thr : nullptr;
+        if (pass == 0 && have_pass0) {                // the kernel that wrote the codes has counted the top digits already
+            hipLaunchKernelGGL(k_med_select, dim3(G), dim3(256), 0, st, state, hist, pass, out);
+        } else if ((size_t)nb * G <= 256) {
+            hipLaunchKernelGGL(k_med_pass, dim3(nb, G), dim3(256), 0, st, ZY, n_per_group, state, hist, pass, out);
+        } else {
             hipLaunchKernelGGL(k_med_hist, dim3(nb, G), dim3(256), 0, st, ZY, n_per_group, state, hist, pass);
-        hipLaunchKernelGGL(k_med_select, dim3(G), dim3(256), 0, st, state, hist, pass);
+            hipLaunchKernelGGL(k_med_select, dim3(G), dim3(256), 0, st, state, hist, pass, out);
+        }
     }
-    hipLaunchKernelGGL(k_med_thr, dim3((G + 63) / 64), dim3(64), 0, st, state, G, thr);
 }
 size_t median_workspace_bytes(int G) { return (((size_t)G * sizeof(MedState) + 255) & ~(size_t)255) + (size_t)G * 2 * MED_BINS * 4; }
 
