@@ -1589,8 +1589,10 @@ __global__ void k_tall_bt_T(const float* __restrict__ dBt, int g, int H, int W, 
         dBm[i] = acc ? dBm[i] + v : v;
     }
 }
+// (y, yb): an image of C's layout added on the way out, C = gather + yb * y - the "- S" / "+ S" that follows every D-layer
+// synthesis (model.jl:238, :276, :313), which was a launch of its own
 __global__ void k_tall_gather(const float* __restrict__ Wt, float* __restrict__ C, int S, int P, int H, int N, int R, int off,
-                              int64_t ldc, int acc) {
+                              int64_t ldc, int acc, const float* __restrict__ y, float yb) {
     const size_t total = (size_t)S * P * N;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int n = (int)(i % N), r = (int)((i / N) % P), s = (int)(i / ((size_t)N * P));
@@ -1599,8 +1601,9 @@ __global__ void k_tall_gather(const float* __restrict__ Wt, float* __restrict__ 
             const int rho = r + ip + off;
             if (rho >= 0 && rho < R) a += Wt[(((size_t)s * R + rho) * H + ip) * N + n];
         }
-        float* o = &C[(size_t)s * ldc + (size_t)r * N + n];
-        *o = acc ? *o + a : a;
+        const size_t oi = (size_t)s * ldc + (size_t)r * N + n;
+        if (y) a += yb * y[oi];
+        C[oi] = acc ? C[oi] + a : a;
     }
 }
 // dW[s][rho][i'][n] = dC[s][rho - i' - off][n]
@@ -1907,7 +1910,7 @@ static ToepGeom tall_row_geom(const ToepGeom& gm) {
     return r;
 }
 
-static void launch_toep(Engine& e, const float* A, const float* Bm, float* C, const ToepGeom& gm, int acc) {
+static void launch_toep(Engine& e, const float* A, const float* Bm, float* C, const ToepGeom& gm, int acc, const float* y = nullptr, float yb = 0.0f) {
     hipStream_t st = e.st;
     if (is_tall(gm)) {
         const int H = gm.Q / gm.sa, R = gm.amax / gm.sa;
@@ -1929,7 +1932,7 @@ static void launch_toep(Engine& e, const float* A, const float* Bm, float* C, co
                                dim3(512), 0, st, A, Bt, Wt, rg, 0);
         }
         hipLaunchKernelGGL(k_tall_gather, dim3(nblocks((size_t)gm.S * gm.P * gm.N)), dim3(256), 0, st, Wt, C, gm.S, gm.P, H, gm.N, R,
-                           gm.a0 / gm.sa, gm.ldc, acc);
+                           gm.a0 / gm.sa, gm.ldc, acc, y, yb);
         return;
     }
     static const bool legacy = getenv("MOTIFS_TOEP_LEGACY") != nullptr;   // debugging aid: the pre-LDS kernels
@@ -2517,10 +2520,18 @@ Tensor Engine::toep_onehot(Tensor A, const uint8_t* codes, int pitch, Tensor Bm,
     return out;
 }
 
-Tensor Engine::toep(Tensor A, Tensor Bm, const ToepGeom& gm) {
+// toep(A, Bm) + b * y with a constant image y of the output's layout: folded into the tall form's gather (its VJP is toep's)
+Tensor Engine::toep_plus(Tensor A, Tensor Bm, const ToepGeom& gm, Tensor y, float b) {
+    static const bool off = getenv("MOTIFS_NO_TOEP_PLUS") != nullptr;
+    if (off || !is_tall(gm) || y->needs_grad || y->n != (size_t)gm.S * gm.ldc || gm.ldc != (int64_t)gm.P * gm.N)
+        return lin(toep(A, Bm, gm), 1.0f, y, b, 0.0f);
+    return toep(A, Bm, gm, y->v, b);
+}
+
+Tensor Engine::toep(Tensor A, Tensor Bm, const ToepGeom& gm, const float* y, float yb) {
     Tensor out = make((size_t)gm.S * gm.ldc, A->needs_grad || Bm->needs_grad);
     if (failed) return out;
-    launch_toep(*this, A->v, Bm->v, out->v, gm, 0);
+    launch_toep(*this, A->v, Bm->v, out->v, gm, 0, y, yb);
     if (recording && out->needs_grad)
         tape.push_back([this, out, A, Bm, gm]() {
             if (!out->g) return;
@@ -3339,6 +3350,126 @@ void topq_mask(hipStream_t st, const float* X, float* bitmat, int S, int n_per_s
     hipLaunchKernelGGL(k_topq_mask, dim3(S), dim3(S >= 256 ? 256 : 1024), 0, st, X, bitmat, n_per_seq, q);   // few reads: more waves per read
 }
 
+// update_X's tail in one launch (model.jl:253 then project_X, :181-192): the gradient step Xu = X - ost * xg (xg == null: Xu = X,
+// the warm-up's projection), the q-th largest of each read, bitmat = Xu >= that value, the projected codes bitmat .* Xu, and the
+// two entry lists every sparse kernel behind them walks - of the codes (values) and of the mask (ones) - which were launches of
+// their own (k_x_step, k_topq_mask, k_maskmul, k_build_nz twice).  One block per read, Xu staged in LDS.
+__global__ __launch_bounds__(1024) void k_x_project(const float* __restrict__ X, const float* __restrict__ xg, const float* __restrict__ ost, int n,
+                                                    int q, float* __restrict__ out, float* __restrict__ bit, int* __restrict__ cnt,
+                                                    uint2* __restrict__ ent, int* __restrict__ mcnt, uint2* __restrict__ ment) {
+    extern __shared__ float xs[];                  // [n]
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t sh[2];
+    __shared__ int wc[2][16];
+    const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nw = blockDim.x >> 6;
+    const size_t base = (size_t)s * n;
+    const float o = xg ? *ost : 0.0f;
+    for (int i = tid; i < n; i += blockDim.x) xs[i] = xg ? X[base + i] - xg[base + i] * o : X[base + i];
+    __syncthreads();
+    const uint32_t key = block_radix_select(xs, n, (uint32_t)(n - q), [](float) { return true; }, hist, sh);
+    const float thr = unkey(key);
+    // every wave owns a contiguous slice of the read: values out and counts, meet once, then the entries in ascending order
+    const int per = (((n + nw - 1) / nw) + 63) & ~63, lo = min(n, wv * per), hi = min(n, lo + per);
+    int c = 0, cm = 0;
+    for (int e0 = lo; e0 < hi; e0 += 64) {
+        const int e = e0 + lane;
+        float v = 0.0f, m = 0.0f;
+        if (e < hi) {
+            m = xs[e] >= thr ? 1.0f : 0.0f;
+            v = m * xs[e];
+            out[base + e] = v;
+            bit[base + e] = m;
+        }
+        c += __builtin_popcountll(__builtin_amdgcn_ballot_w64(v != 0.0f));
+        cm += __builtin_popcountll(__builtin_amdgcn_ballot_w64(m != 0.0f));
+    }
+    if (lane == 0) wc[0][wv] = c, wc[1][wv] = cm;
+    __syncthreads();
+    int b0 = 0, b1 = 0;
+    for (int w = 0; w < wv; w++) b0 += wc[0][w], b1 += wc[1][w];
+    uint2* es = ent + base;
+    uint2* ms = ment + base;
+    for (int e0 = lo; e0 < hi; e0 += 64) {
+        const int e = e0 + lane;
+        float v = 0.0f, m = 0.0f;
+        if (e < hi) {
+            m = xs[e] >= thr ? 1.0f : 0.0f;
+            v = m * xs[e];
+        }
+        const uint64_t hv = __builtin_amdgcn_ballot_w64(v != 0.0f), hm = __builtin_amdgcn_ballot_w64(m != 0.0f);
+        const uint64_t below = (1ull << lane) - 1ull;
+        if (v != 0.0f) es[b0 + __builtin_popcountll(hv & below)] = make_uint2((unsigned)e, __float_as_uint(v));
+        if (m != 0.0f) ms[b1 + __builtin_popcountll(hm & below)] = make_uint2((unsigned)e, __float_as_uint(m));
+        b0 += __builtin_popcountll(hv);
+        b1 += __builtin_popcountll(hm);
+    }
+    if (tid == 0) {
+        int t0 = 0, t1 = 0;
+        for (int w = 0; w < nw; w++) t0 += wc[0][w], t1 += wc[1][w];
+        cnt[s] = t0;
+        mcnt[s] = t1;
+    }
+}
+// VJP: g = bitmat .* d out;  dX (+)= g;  d xg (+)= -ost * g;  d ost += -sum(g .* xg)
+__global__ void k_x_project_bwd(const float* go, const float* bit, const float* xg, const float* ost, size_t n, float* dX, int aX, float* dxg,
+                                int axg, float* dost) {
+    const float o = ost ? *ost : 0.0f;
+    double so = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float g = bit[i] * go[i];
+        if (dX) dX[i] = (aX ? dX[i] : 0.0f) + g;
+        if (dxg) dxg[i] = (axg ? dxg[i] : 0.0f) - o * g;
+        if (xg) so -= (double)g * (double)xg[i];
+    }
+    if (!dost) return;
+    for (int d = 32; d >= 1; d >>= 1) so += __shfl_xor(so, d);
+    __shared__ double red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = so;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(dost, (float)(red[0] + red[1] + red[2] + red[3]));
+}
+
+Tensor Engine::x_project(Tensor X, Tensor xg, Tensor ost, int S, int q) {
+    const int n = (int)(X->n / S);
+    static const bool off = getenv("MOTIFS_NO_X_PROJECT") != nullptr;
+    if (off || (size_t)n * 4 > ((size_t)48 << 10)) {          // the separate launches
+        Tensor Xu = xg ? x_step(X, xg, ost) : X;
+        Tensor bitm = make(Xu->n, false);
+        if (failed) return Xu;
+        topq_mask(st, Xu->v, bitm->v, S, n, q);
+        Tensor P = maskmul(Xu, bitm->v, 1.0f);
+        P->gmask = bitm->v;
+        return P;
+    }
+    Tensor out = make(X->n, X->needs_grad || (xg && (xg->needs_grad || ost->needs_grad)));
+    Tensor bitm = make(X->n, false);
+    int* c = (int*)arena.alloc(2 * ((size_t)S + 64));
+    uint2* en = (uint2*)arena.alloc((size_t)S * n * 4);
+    if (failed || !c || !en) {
+        failed = true;
+        return out;
+    }
+    int* mc = c + S + 64;
+    uint2* men = en + (size_t)S * n;
+    hipLaunchKernelGGL(k_x_project, dim3(S), dim3(S >= 256 ? 256 : 1024), (size_t)n * 4, st, X->v, xg ? xg->v : nullptr, xg ? ost->v : nullptr, n, q,
+                       out->v, bitm->v, c, en, mc, men);
+    out->gmask = bitm->v;          // every gradient into the projected codes passes this mask on its way back
+    out->nz_cnt = c, out->nz_ent = en;
+    out->gm_cnt = mc, out->gm_ent = men;
+    if (recording && out->needs_grad)
+        tape.push_back([this, out, X, xg, ost, bitm]() {
+            if (!out->g) return;
+            int a0 = 1, a1 = 1;
+            float* d0 = X->needs_grad ? grad_first(X, a0) : nullptr;
+            float* d1 = xg && xg->needs_grad ? grad_first(xg, a1) : nullptr;
+            float* dq = xg && ost->needs_grad ? grad(ost) : nullptr;
+            if (failed) return;
+            hipLaunchKernelGGL(k_x_project_bwd, dim3(nblocks(out->n, 256, 1024)), dim3(256), 0, st, out->g, bitm->v, xg ? xg->v : nullptr,
+                               xg ? ost->v : nullptr, out->n, d0, a0, d1, a1, dq);
+        });
+    return out;
+}
+
 // create_ZY_mask (model.jl:194-204): median of the strictly positive entries of the whole mini-batch
 // (mean of the two middle values for an even count: Statistics.middle(a, b) = a/2 + b/2); mask = ZY >= median.
 // No positive entry -> the reference skips the mask (:209); that is mask == 1 here.
@@ -3347,7 +3478,6 @@ void topq_mask(hipStream_t st, const float* X, float* bitmat, int S, int n_per_s
 // tracked side by side.
 struct MedState {
     uint32_t cnt, pref[2], k[2];
-    uint32_t ticket;       // blocks of the running histogram pass that have delivered (the last one makes the digit choice)
 };
 constexpr int MED_BINS = 2048;
 static __host__ __device__ __forceinline__ int med_shift(int pass) { return pass == 0 ? 21 : pass == 1 ? 10 : 0; }
@@ -3397,8 +3527,7 @@ static __device__ __forceinline__ void med_hist_block(const float* __restrict__ 
 }
 
 // digit choice: the first bin whose running count exceeds k (the last bin if none does); 256 threads x 8 bins.
-// COHERENT: the histogram was filled by other blocks of the same launch (read past the caches, agent scope).
-template <bool COHERENT>
+// After the last pass (thr != null) also the median itself.
 static __device__ void med_select_block(MedState* state, uint32_t* hist, int pass, int g, float* thr, uint32_t* part, MedState& sst) {
     const int tid = threadIdx.x, shift = med_shift(pass);
     uint32_t* h = hist + (size_t)g * 2 * MED_BINS;
@@ -3409,7 +3538,7 @@ static __device__ void med_select_block(MedState* state, uint32_t* hist, int pas
         uint32_t loc[8], sum = 0;
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-            loc[j] = COHERENT ? __hip_atomic_load(&hh[tid * 8 + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : hh[tid * 8 + j];
+            loc[j] = hh[tid * 8 + j];
             sum += loc[j];
         }
         part[tid] = sum;
@@ -3446,7 +3575,6 @@ static __device__ void med_select_block(MedState* state, uint32_t* hist, int pas
         __syncthreads();
     }
     if (tid == 0) {
-        sst.ticket = 0;
         state[g] = sst;
         if (thr) {                                     // after the last pass: the median itself
             float med = -INFINITY;                     // no positive entry: everything passes
@@ -3462,7 +3590,7 @@ static __device__ void med_select_block(MedState* state, uint32_t* hist, int pas
 __global__ __launch_bounds__(256) void k_med_select(MedState* state, uint32_t* hist, int pass, float* thr) {
     __shared__ uint32_t part[256];
     __shared__ MedState sst;
-    med_select_block<false>(state, hist, pass, blockIdx.x, thr, part, sst);
+    med_select_block(state, hist, pass, blockIdx.x, thr, part, sst);
 }
 
 __global__ __launch_bounds__(256) void k_med_hist(const float* __restrict__ x, int n, const MedState* state, uint32_t* hist, int pass) {
@@ -3470,26 +3598,9 @@ __global__ __launch_bounds__(256) void k_med_hist(const float* __restrict__ x, i
     med_hist_block(x, n, state, hist, pass, h);
 }
 
-// One pass of the select in one launch: every block adds its digits to the group's histogram and takes a ticket; the block that
-// draws the last one finds all counts delivered and makes the digit choice (three launches per median instead of six or seven
-// - the reference's one-mini-batch steps are made of launches of ~5 us).  Only for steps of few mini-batches: the fence in
-// front of the ticket is an L2 write-back per block, and with the 4096 blocks of a 64-mini-batch step a pass took 420 us
-// against 33 + 6 us for the two launches.
-__global__ __launch_bounds__(256) void k_med_pass(const float* __restrict__ x, int n, MedState* state, uint32_t* hist, int pass, float* thr) {
-    __shared__ uint32_t h[2][MED_BINS];
-    __shared__ uint32_t part[256];
-    __shared__ MedState sst;
-    __shared__ uint32_t drawn;
-    const int g = blockIdx.y;
-    med_hist_block(x, n, state, hist, pass, h);
-    __threadfence();                                   // this block's counts are visible to the device before its ticket is
-    __syncthreads();
-    if (threadIdx.x == 0) drawn = atomicAdd(&state[g].ticket, 1u);
-    __syncthreads();
-    if (drawn != gridDim.x - 1) return;
-    __threadfence();
-    med_select_block<true>(state, hist, pass, g, thr, part, sst);
-}
+// (A pass as ONE launch - every block takes a ticket after its atomics and the block that draws the last one makes the digit
+// choice - was measured and lost: the fence in front of the ticket is an L2 write-back per block; 17.5 us per pass against
+// 7 + 5 for the two launches at one mini-batch, 420 us against 39 at 64.)
 
 static_assert(MED_BINS == ZH_BINS, "the fused first pass (zy_step kernels) fills the same histogram");
 uint32_t* median_hist_ptr(void* workspace, int G) {
@@ -3503,8 +3614,6 @@ void median_threshold(hipStream_t st, const float* ZY, float* thr, int G, int n_
         float* out = pass == 2 ? thr : nullptr;
         if (pass == 0 && have_pass0) {                // the kernel that wrote the codes has counted the top digits already
             hipLaunchKernelGGL(k_med_select, dim3(G), dim3(256), 0, st, state, hist, pass, out);
-        } else if ((size_t)nb * G <= 256) {
-            hipLaunchKernelGGL(k_med_pass, dim3(nb, G), dim3(256), 0, st, ZY, n_per_group, state, hist, pass, out);
         } else {
             hipLaunchKernelGGL(k_med_hist, dim3(nb, G), dim3(256), 0, st, ZY, n_per_group, state, hist, pass);
             hipLaunchKernelGGL(k_med_select, dim3(G), dim3(256), 0, st, state, hist, pass, out);

@@ -106,14 +106,9 @@ struct Graph {
         return thr->v;
     }
     // project_X (model.jl:181-192): keep the entries >= the q-th largest of each sequence
-    Tensor project_X(Tensor Xu) {
-        Tensor bit = e.make(Xu->n, false);
-        if (e.failed) return Xu;
-        topq_mask(e.st, Xu->v, bit->v, S, m->l * m->K, m->q);
-        Tensor X = e.maskmul(Xu, bit->v, 1.0f);
-        X->gmask = bit->v;            // every gradient into X passes this mask on its way to Xu
-        return X;
-    }
+    Tensor project_X(Tensor Xu) { return e.x_project(Xu, nullptr, nullptr, S, m->q); }
+    // update_X's step and projection in one (:253-254)
+    Tensor step_project_X(Tensor X, Tensor xg, Tensor ost) { return e.x_project(X, xg, ost, S, m->q); }
     // the two filter banks in GEMM layout, analysis and (flipped) synthesis form
     struct Bank {
         Tensor an, syn, raw;   // analysis layout, flipped synthesis layout, the reference layout it came from
@@ -131,6 +126,7 @@ struct Graph {
         return Bank{FA, e.flipT(FA, g, m->h, m->twoM, m->K), F, g};
     }
     Tensor synD(Tensor ZY, const Bank& b) { return e.toep(ZY, b.syn, with(gD2, b.g)); }     // sum_m conv(Z,D)+conv(Y,D,flipped)
+    Tensor synD_plus(Tensor ZY, const Bank& b, float sgn) { return e.toep_plus(ZY, b.syn, with(gD2, b.g), Sone, sgn); }   // ... + sgn * S in the same pass
     Tensor anaD(Tensor sig, const Bank& b) {      // [conv(.,D,flipped) | conv(.,D)] rows 1:4:end
         if (sig == Sone && codes) return e.toep_onehot(sig, codes, motifs_codes_pitch(m->L), b.an, with(gD1, b.g));   // a4: the reads themselves
         return e.toep(sig, b.an, with(gD1, b.g));
@@ -185,7 +181,7 @@ static void admm_xyz(motifs_model* m, Graph& gr, const Scalars& sc, const Graph:
     e.note("X0", X);
     for (int t = 0; t < m->hp.num_pass_xyz; t++) {
         // update_ZY (:237-245)
-        Tensor diff = e.lin(gr.synD(ZY, bD), 1.0f, gr.Sone, -1.0f, 0.0f);
+        Tensor diff = gr.synD_plus(ZY, bD, -1.0f);
         Tensor g1 = gr.anaD(diff, bD);
         float* mws = gr.med_ws();                                         // the median select of the new codes starts in the step kernel
         uint32_t* h0 = mws ? median_hist_ptr(mws, gr.G) : nullptr;
@@ -206,7 +202,7 @@ static void admm_xyz(motifs_model* m, Graph& gr, const Scalars& sc, const Graph:
         Tensor img = t == 0 ? e.lin3(FX, 1.0f, ZY, -m->hp.magnifying_factor, ab, 1.0f, zt, gr.G)
                             : e.lin3_zy(FX, ZY, -m->hp.magnifying_factor, ab, zt, gr.G);
         Tensor xg = gr.anaF(img, bF);
-        X = gr.project_X(e.x_step(X, xg, sc.ost[t]));
+        X = gr.step_project_X(X, xg, sc.ost[t]);
         FX = gr.synF(X, bF);                                              // the duals advance at the top of the next pass
     }
     e.note("ZY", ZY);
@@ -252,7 +248,7 @@ static Tensor forward_loss(motifs_model* m, Graph& gr, bool train) {
     std::vector<Tensor> thetas;                                            // theta_0 ..
     for (int t = 0; t < P; t++) {
         // update_D (:275-290): D_grad = Z'(sumZD + sumYRD + S) + reverse(Y'(...)), only the f_len needed lags
-        Tensor sig = e.lin(gr.synD(ZY, bDc), 1.0f, gr.Sone, 1.0f, 0.0f);
+        Tensor sig = gr.synD_plus(ZY, bDc, 1.0f);
         Tensor Dgrad = e.collapseD(e.wgrad(sig, ZY, gr.gD1), G, m->M, m->fl);
         Tensor ex = e.expo(e.mul(Dgrad, e.lin(sc.mu[t], -1.0f, nullptr, 0.0f, 0.0f)));
         Dc = e.norm4(e.mul(ex, Dc));
@@ -287,7 +283,7 @@ static Tensor forward_loss(motifs_model* m, Graph& gr, bool train) {
     e.note("Ffinal", Fc);
     // loss (:310-325)
     const float nf = 1.0f / (float)m->B;
-    Tensor r1 = e.lin(gr.synD(ZY, bDc), 1.0f, gr.Sone, -1.0f, 0.0f);
+    Tensor r1 = gr.synD_plus(ZY, bDc, -1.0f);
     Tensor Lv = e.lin(e.sumsq_groups(r1, nf, G), 1.0f, e.resid_sumsq_groups(FXcur, ZY, zmf, zmt, nf, G), 1.0f, 0.0f);
     (void)gD;
     (void)gF;
