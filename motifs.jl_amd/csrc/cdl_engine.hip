@@ -729,7 +729,7 @@ Tensor Engine::zy_step(Tensor ZY, Tensor g1, Tensor FX, Tensor ab, Tensor pen, T
             float* ds = lst->needs_grad ? grad(lst) : nullptr;
             float* dl = ls->needs_grad ? grad(ls) : nullptr;
             if (failed) return;
-            hipLaunchKernelGGL(k_zy_step_bwd, dim3(nblocks(out->n, 256, 2048)), dim3(256), 0, st, out->g, out->v, ZY->v, g1->v, FX->v,
+            hipLaunchKernelGGL(k_zy_step_bwd, dim3(nblocks(out->n, 256 * 8, 2048)), dim3(256), 0, st, out->g, out->v, ZY->v, g1->v, FX->v,
                                ab ? ab->v : nullptr, pen->v, lst->v, ls->v, out->n, d0, a0, d1, a1, d2, a2, d3, a3, dp, ds, dl);
         });
     return out;
@@ -911,10 +911,10 @@ Tensor Engine::norml2(Tensor x, int seg) {
     Tensor nrm = make(x->n / seg, false);
     if (failed) return out;
     const unsigned nseg = (unsigned)(x->n / seg);
-    hipLaunchKernelGGL(k_norml2, dim3(nseg), dim3(256), 0, st, x->v, seg, out->v, nrm->v);
+    hipLaunchKernelGGL(k_norml2, dim3(nseg), dim3(nseg >= 256 ? 256 : 1024), 0, st, x->v, seg, out->v, nrm->v);   // few segments: more waves on each
     if (recording && out->needs_grad)
         tape.push_back([this, out, x, nrm, seg, nseg]() {
-            if (out->g) hipLaunchKernelGGL(k_norml2_bwd, dim3(nseg), dim3(256), 0, st, out->g, out->v, nrm->v, seg, grad(x));
+            if (out->g) hipLaunchKernelGGL(k_norml2_bwd, dim3(nseg), dim3(nseg >= 256 ? 256 : 1024), 0, st, out->g, out->v, nrm->v, seg, grad(x));
         });
     return out;
 }
@@ -1277,6 +1277,15 @@ __global__ __launch_bounds__(512) void k_toep_mfma(const float* __restrict__ A, 
     }
 }
 
+// out[i] (+)= part[0][i] + part[1][i] + ... (k partial images of n floats, added in order)
+__global__ void k_sum_parts(const float* __restrict__ part, size_t n, int k, float* __restrict__ out, int acc) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float a = part[i];
+        for (int j = 1; j < k; j++) a += part[(size_t)j * n + i];
+        out[i] = acc ? out[i] + a : a;
+    }
+}
+
 // The syntax-layer analysis (model.jl:251, conv(img, F, flipped)) with the image resident in LDS.  The Toeplitz
 // rows of one sequence overlap by (H-1)/H, so a block keeps the 32 + H - 1 image rows of its 32 output rows in
 // LDS (CC channels at a time, double buffered) and feeds the matrix cores from there: one ds_read per MFMA for
@@ -1296,13 +1305,18 @@ __global__ void k_frag_b(const float* __restrict__ Bm, int G, int Q, int N, floa
     }
 }
 template <int H, int CC>
+// nsplit > 1 (steps of few reads: 36 blocks on 256 CUs otherwise): the channel chunks are dealt to nsplit blocks per job, each
+// leaves its partial tile at C + split * cstride and k_sum_parts adds them.
 __global__ __launch_bounds__(256) void k_ana_lds(const float* __restrict__ A, const float* __restrict__ Bf, float* __restrict__ C,
-                                                 ToepGeom gm, int acc, int tps, int64_t ldbf) {
+                                                 ToepGeom gm, int acc, int tps, int64_t ldbf, int nsplit, size_t cstride) {
     constexpr int ST = CC + 1, ROWS = 32 + H, JW = H / 4, C4 = CC / 4, NV = (ROWS * C4 + 255) / 256;   // one spare row
     extern __shared__ float lds[];                 // 2 x [ROWS][ST]; at the end 4 x [32][32]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int s = blockIdx.x / tps, p0 = (blockIdx.x - s * tps) * 32;
+    const int job = blockIdx.x / nsplit, split = blockIdx.x - job * nsplit;
+    const int s = job / tps, p0 = (job - s * tps) * 32;
     const int W = gm.sa, NCH = W / CC, N = gm.N;
+    const int ch0 = split * NCH / nsplit, ch1 = (split + 1) * NCH / nsplit;      // this block's chunks
+    C += (size_t)split * cstride;
     const float* img = A + (size_t)s * gm.lda + gm.a0 + (size_t)p0 * W;
     const int lim = gm.amax - gm.a0 - p0 * W;      // valid flat range seen from img
     const float4* Bg = (const float4*)(Bf + (size_t)(s / gm.B) * ldbf) + lane;
@@ -1337,17 +1351,17 @@ __global__ __launch_bounds__(256) void k_ana_lds(const float* __restrict__ A, co
     // fragments of window row j, chunk ch: channels ch*CC + 8 * f .., f < FJ
     auto bbase = [&](int ch, int j) -> const float4* { return Bg + ((((size_t)j * W + (size_t)ch * CC) >> 3) << 6); };
     float4 br[PF];
-    gload(0);
+    gload(ch0 * CC);
     {
-        const float4* b0 = bbase(0, wave * JW);
+        const float4* b0 = bbase(ch0, wave * JW);
 #pragma unroll
         for (int i = 0; i < PF; i++) br[i] = b0[i * 64];
     }
-    lstore(lds);
+    lstore(lds + (ch0 & 1) * (ROWS * ST));
     __syncthreads();
-    for (int ch = 0; ch < NCH; ch++) {
+    for (int ch = ch0; ch < ch1; ch++) {
         float* buf = lds + (ch & 1) * (ROWS * ST);
-        const bool more = ch + 1 < NCH;
+        const bool more = ch + 1 < ch1;
         if (more) gload((ch + 1) * CC);            // in flight under the MFMAs below
         const float* a = buf + aoff;
         float ar[4];
@@ -1433,8 +1447,21 @@ static bool launch_ana_lds(Engine& e, const float* A, const float* Bm, float* C,
     int lds = (160 * 1024 / best) & ~1023;
     if (lds > 64 * 1024) lds = 64 * 1024;
     if (lds < need) lds = need;
+    const int nch = gm.sa / CC;
+    if (jobs < 64 && nch > 1 && gm.ldc == (int64_t)gm.P * gm.N) {   // few reads: a block per (job, channel chunk), partial tiles, one sum
+        const size_t cn = (size_t)gm.S * gm.ldc;
+        float* part = e.arena.alloc(cn * nch);
+        if (!part) {
+            e.failed = true;
+            return true;
+        }
+        hipLaunchKernelGGL((k_ana_lds<H, CC>), dim3((unsigned)(jobs * nch)), dim3(256), (size_t)lds, e.st, A, Bf, part, gm, 0, tps,
+                           (int64_t)(gm.ldb == 0 ? 0 : perf), nch, cn);
+        hipLaunchKernelGGL(k_sum_parts, dim3(nblocks(cn / 4 + 1, 256, 1024)), dim3(256), 0, e.st, part, cn, nch, C, acc);
+        return true;
+    }
     hipLaunchKernelGGL((k_ana_lds<H, CC>), dim3((unsigned)jobs), dim3(256), (size_t)lds, e.st, A, Bf, C, gm, acc, tps,
-                       (int64_t)(gm.ldb == 0 ? 0 : perf));
+                       (int64_t)(gm.ldb == 0 ? 0 : perf), 1, (size_t)0);
     return true;
 }
 
@@ -2907,10 +2934,20 @@ __global__ __launch_bounds__(1024) void k_sp_wgrad_syn_reads(NzView nz, const fl
         const float* ds = dOut + (size_t)s * d.c * d.W + (size_t)(d.h - 1 - ip) * d.W + jc;
         const int cnt = nz.cnt[s];
         const uint2* es = nz.ent + (size_t)s * nz.cap;
-        for (int z = 0; z < cnt; z++) {                  // wave-uniform
-            const uint2 en = es[z];
-            const int p = (int)__umulhi(en.x, kmagic(d.K)), k = (int)(en.x - (unsigned)p * d.K);
-            mine[k * 128 + tx] = fmaf(__uint_as_float(en.y), ds[(size_t)p * d.W], mine[k * 128 + tx]);
+        for (int z = 0; z < cnt; z += 4) {               // wave-uniform; four image values in flight, added in entry order
+            uint2 en[4];
+            float x[4];
+            int kk[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                en[u] = es[min(z + u, cnt - 1)];
+                const int p = (int)__umulhi(en[u].x, kmagic(d.K));
+                kk[u] = (int)(en[u].x - (unsigned)p * d.K);
+                x[u] = ds[(size_t)p * d.W];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (z + u < cnt) mine[kk[u] * 128 + tx] = fmaf(__uint_as_float(en[u].y), x[u], mine[kk[u] * 128 + tx]);
         }
     }
     __syncthreads();
@@ -2936,10 +2973,20 @@ __global__ __launch_bounds__(1024) void k_sp_wgrad_ana_reads(const float* __rest
         const float* is = img + (size_t)s * d.c * d.W + (size_t)i * d.W + jc;
         const int cnt = nz.cnt[s];
         const uint2* es = nz.ent + (size_t)s * nz.cap;
-        for (int z = 0; z < cnt; z++) {
-            const uint2 en = es[z];
-            const int p = (int)__umulhi(en.x, kmagic(d.K)), k = (int)(en.x - (unsigned)p * d.K);
-            my[k] = fmaf(__uint_as_float(en.y), is[(size_t)p * d.W], my[k]);
+        for (int z = 0; z < cnt; z += 4) {               // four image values in flight, added in entry order
+            uint2 en[4];
+            float x[4];
+            int kk[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                en[u] = es[min(z + u, cnt - 1)];
+                const int p = (int)__umulhi(en[u].x, kmagic(d.K));
+                kk[u] = (int)(en[u].x - (unsigned)p * d.K);
+                x[u] = is[(size_t)p * d.W];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (z + u < cnt) my[kk[u]] = fmaf(__uint_as_float(en[u].y), x[u], my[kk[u]]);
         }
     }
     __syncthreads();
