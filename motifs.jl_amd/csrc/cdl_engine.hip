@@ -1759,6 +1759,131 @@ __global__ __launch_bounds__(256) void k_rowgemm_lds(const float* __restrict__ A
         }
     }
 }
+// The tall form in ONE launch for steps of few reads (the row GEMM and the gather after it were two launches of ~36 blocks):
+// a block owns TR = 33 - H output rows of one read, takes the 32 image rows rho = r0 + off .. r0 + off + 31 they draw on into
+// LDS (rows outside the read are zeros), forms their [32][H N] products as k_rowgemm_lds does, and adds the H shifted slices
+//     C[s][r][n] (+)= sum_ip W[r + ip + off][ip][n]   (+ yb * y[s][r][n])
+// straight from the partial tiles.  The image rows of neighbouring blocks overlap by H - 1: only worth it while the launch,
+// not HBM, is the cost.
+template <int NT>
+__global__ __launch_bounds__(256) void k_tall_fused(const float* __restrict__ A, const float* __restrict__ Bf, float* __restrict__ C, int R, int P,
+                                                    int H, int Q, int N, int off, int tps, int B, int64_t ldbf, int64_t ldc, int acc,
+                                                    const float* __restrict__ y, float yb) {
+    constexpr int NV = 15, U = 4;
+    extern __shared__ float lds[];                 // [32][Q + 4]; at the end 4 x [32][16 NT]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int TR = 33 - H;
+    const int s = blockIdx.x / tps, r0 = (blockIdx.x - s * tps) * TR;
+    const int rho0 = r0 + off, ST = Q + 4, Q4 = Q >> 2;
+    const float4* At = (const float4*)(A + (size_t)s * R * Q);
+    const int tf4 = 32 * Q4;
+    float4 v[NV];
+    {
+        int row = tid / Q4, c4 = tid - row * Q4;
+        const int drow = 256 / Q4, dc = 256 - drow * Q4;
+#pragma unroll
+        for (int i = 0; i < NV; i++) {
+            const int rho = rho0 + row;
+            const bool ok = tid + i * 256 < tf4 && rho >= 0 && rho < R;
+            const float4 x = At[ok ? (size_t)rho * Q4 + c4 : 0];
+            v[i] = ok ? x : make_float4(0.f, 0.f, 0.f, 0.f);
+            row += drow, c4 += dc;
+            if (c4 >= Q4) c4 -= Q4, row++;
+        }
+    }
+    {
+        int row = tid / Q4, c4 = tid - row * Q4;
+        const int drow = 256 / Q4, dc = 256 - drow * Q4;
+#pragma unroll
+        for (int i = 0; i < NV; i++) {
+            if (tid + i * 256 < tf4) *(float4*)(lds + row * ST + c4 * 4) = v[i];
+            row += drow, c4 += dc;
+            if (c4 >= Q4) c4 -= Q4, row++;
+        }
+    }
+    __syncthreads();
+    f32x4 accv[2][NT];
+#pragma unroll
+    for (int rb = 0; rb < 2; rb++)
+#pragma unroll
+        for (int cb = 0; cb < NT; cb++) accv[rb][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nks = Q >> 4;                        // reduction steps (4 channels each) of this wave
+    const float* a0p = lds + (lane & 15) * ST + wave * (Q >> 2) + (lane >> 4);
+    const float* a1p = a0p + 16 * ST;
+    const float4* bp = (const float4*)(Bf + (size_t)(s / B) * ldbf) + (size_t)(wave * nks) * 64 + lane;
+    float4 cur[U], nxt[U];
+#pragma unroll
+    for (int i = 0; i < U; i++) cur[i] = bp[(size_t)min(i, nks - 1) * 64];
+    for (int u0 = 0; u0 < nks; u0 += U) {
+#pragma unroll
+        for (int i = 0; i < U; i++) nxt[i] = bp[(size_t)min(u0 + U + i, nks - 1) * 64];
+#pragma unroll
+        for (int i = 0; i < U; i++) {
+            if (u0 + i < nks) {
+                const float a0 = a0p[4 * (u0 + i)], a1 = a1p[4 * (u0 + i)];
+                const float bv[4] = {cur[i].x, cur[i].y, cur[i].z, cur[i].w};
+#pragma unroll
+                for (int cb = 0; cb < NT; cb++) {
+                    accv[0][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bv[cb], accv[0][cb], 0, 0, 0);
+                    accv[1][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bv[cb], accv[1][cb], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < U; i++) cur[i] = nxt[i];
+    }
+    __syncthreads();                               // the image rows are done with: partial tiles take their place
+    constexpr int RW = 16 * NT;
+    float* red = lds + wave * (32 * RW);
+#pragma unroll
+    for (int rb = 0; rb < 2; rb++)
+#pragma unroll
+        for (int cb = 0; cb < NT; cb++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) red[(rb * 16 + 4 * (lane >> 4) + r) * RW + cb * 16 + (lane & 15)] = accv[rb][cb][r];
+    __syncthreads();
+    const int nrow = min(TR, P - r0);
+    for (int e = tid; e < nrow * N; e += 256) {
+        const int rr = e / N, n = e - rr * N;
+        float a = 0.0f;
+        for (int ip = 0; ip < H; ip++) {           // W row (local) rr + ip, column ip N + n; rows outside the read were zeros
+            const float* q = lds + (rr + ip) * RW + ip * N + n;
+            a += (q[0] + q[32 * RW]) + (q[64 * RW] + q[96 * RW]);
+        }
+        const size_t oi = (size_t)s * ldc + (size_t)(r0 + rr) * N + n;
+        if (y) a += yb * y[oi];
+        C[oi] = acc ? C[oi] + a : a;
+    }
+}
+static bool launch_tall_fused(Engine& e, const float* A, const float* Bt, float* C, const ToepGeom& gm, const ToepGeom& rg, int acc, const float* y,
+                              float yb) {
+    static const bool off = getenv("MOTIFS_NO_TALL_FUSED") != nullptr;
+    const int H = gm.Q / gm.sa, R = gm.amax / gm.sa;
+    if (off || H < 2 || H > 16 || gm.a0 % gm.sa != 0) return false;
+    if (rg.a0 != 0 || rg.sa != rg.Q || rg.lda != (int64_t)rg.P * rg.Q) return false;
+    if ((rg.Q & 15) || rg.Q > 480 || rg.Q < 64 || rg.N < 9 || rg.N > 64 || (((uintptr_t)A) & 15)) return false;
+    const int TR = 33 - H, tps = (gm.P + TR - 1) / TR;
+    if ((long)gm.S * tps > 512) return false;      // many reads: the two-launch form reads every image row once
+    const int groups = rg.ldb == 0 ? 1 : rg.S / rg.B;
+    const size_t perf = (size_t)(rg.Q / 4) * 256;
+    bool fresh;
+    float* Bf = e.relayout(Bt, 2, rg.Q, rg.N, 0, perf * groups, fresh);
+    if (!Bf) return true;
+    if (fresh) hipLaunchKernelGGL(k_frag_b16, dim3(nblocks(perf * groups)), dim3(256), 0, e.st, Bt, groups, rg.Q, rg.N, Bf);
+    const int NT = (rg.N + 15) / 16;
+    const size_t lds = std::max((size_t)32 * (rg.Q + 4) * 4, (size_t)4 * 32 * 16 * NT * 4);
+    const dim3 grid((unsigned)(gm.S * tps));
+    const int64_t ldbf = rg.ldb == 0 ? 0 : (int64_t)perf;
+#define TALLF(NTV) \
+    hipLaunchKernelGGL((k_tall_fused<NTV>), grid, dim3(256), lds, e.st, A, Bf, C, R, gm.P, H, rg.Q, gm.N, gm.a0 / gm.sa, tps, gm.B, ldbf, gm.ldc, acc, y, yb)
+    if (NT == 1) TALLF(1);
+    else if (NT == 2) TALLF(2);
+    else if (NT == 3) TALLF(3);
+    else TALLF(4);
+#undef TALLF
+    return true;
+}
+
 // rows must be contiguous ([S][P][Q] with nothing between sequences), Q a multiple of 16 up to 480, N <= 64
 static bool launch_rowgemm_lds(Engine& e, const float* A, const float* Bm, float* C, const ToepGeom& rg, int acc) {
     if (rg.a0 != 0 || rg.sa != rg.Q || rg.lda != (int64_t)rg.P * rg.Q || rg.ldc != (int64_t)rg.P * rg.N) return false;
@@ -1953,6 +2078,7 @@ static void launch_toep(Engine& e, const float* A, const float* Bm, float* C, co
         if (fresh) hipLaunchKernelGGL(k_tall_bt, dim3(nblocks(per * gB)), dim3(256), 0, st, Bm, gB, H, gm.sa, gm.N, Bt);
         const ToepGeom rg = tall_row_geom(gm);
         static const bool legacy_rows = getenv("MOTIFS_TOEP_LEGACY") != nullptr;
+        if (!legacy_rows && launch_tall_fused(e, A, Bt, C, gm, rg, acc, y, yb)) return;
         if (legacy_rows || !launch_rowgemm_lds(e, A, Bt, Wt, rg, 0)) {
             const int grp_rows = rg.B * rg.P;
             hipLaunchKernelGGL(k_toep_mfma, dim3((unsigned)((grp_rows + 63) / 64), (unsigned)(rg.S / rg.B), (unsigned)((rg.N + 31) / 32)),
@@ -2202,6 +2328,25 @@ __global__ void k_sum_segments(const float* x, size_t per, int B, size_t total, 
     }
 }
 
+// k_sum_segments followed by k_tall_bt_T in one pass: dBm[g][ip][j][n] (+)= sum_b part[g B + b][j][ip][n]
+__global__ void k_sum_segments_btT(const float* __restrict__ x, int B, int G, int H, int W, int N, float* __restrict__ dBm, int acc) {
+    const size_t per = (size_t)H * W * N, total = per * G;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t g = i / per, r = i - g * per;       // r indexes dBm [H][W][N]
+        const int n = (int)(r % N), j = (int)((r / N) % W), ip = (int)(r / ((size_t)N * W));
+        const size_t src = ((size_t)j * H + ip) * N + n;
+        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+        int b = 0;
+        for (; b + 4 <= B; b += 4) {
+            a0 += x[(g * B + b) * per + src], a1 += x[(g * B + b + 1) * per + src];
+            a2 += x[(g * B + b + 2) * per + src], a3 += x[(g * B + b + 3) * per + src];
+        }
+        for (; b < B; b++) a0 += x[(g * B + b) * per + src];
+        const float a = (a0 + a1) + (a2 + a3);
+        dBm[i] = acc ? dBm[i] + a : a;
+    }
+}
+
 // The window matrix of a Toeplitz operand, Wn[s][p][q] = A[s][a0 + p sa + q] (zero outside the valid range): with it
 // the filter gradient of a short-window, wide-output form is the row GEMM's, transposed.
 __global__ void k_windows(const float* __restrict__ A, ToepGeom gm, float* __restrict__ Wn) {
@@ -2274,10 +2419,10 @@ static void launch_wgrad(Engine& e, const float* A, const float* C, float* dB, c
                 hipLaunchKernelGGL(k_wgrad_mfma, dim3((rg.Q + 127) / 128, gm.S, (rg.N + 31) / 32), dim3(256), 0, st, A, dW, part, r1, 0);
                 nparts = rg.B;
             }
-            hipLaunchKernelGGL(k_sum_segments, dim3(nblocks(per * G)), dim3(256), 0, st, part, per, nparts, per * G, dBt, 0);
-        } else {
-            hipLaunchKernelGGL(k_wgrad_mfma, dim3((rg.Q + 127) / 128, G, (rg.N + 31) / 32), dim3(256), 0, st, A, dW, dBt, rg, 0);
+            hipLaunchKernelGGL(k_sum_segments_btT, dim3(nblocks(per * G)), dim3(256), 0, st, part, nparts, G, H, gm.sa, gm.N, dB, acc);
+            return;
         }
+        hipLaunchKernelGGL(k_wgrad_mfma, dim3((rg.Q + 127) / 128, G, (rg.N + 31) / 32), dim3(256), 0, st, A, dW, dBt, rg, 0);
         hipLaunchKernelGGL(k_tall_bt_T, dim3(nblocks(per * G)), dim3(256), 0, st, dBt, G, H, gm.sa, gm.N, dB, acc);
         return;
     }
