@@ -2196,9 +2196,17 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ A, cons
 // rows at a time (rows to LDS with 16-byte accesses, the next 32 already in flight in registers); wave w owns the
 // 16-row blocks w, w+4, .. of q for all column blocks (v_mfma_f32_16x16x4_f32, the accumulators stay in registers
 // for the whole sequence).  Row strides of both LDS tiles are 16 mod 32 floats: conflict-free operand reads.
+// Where the C rows come from.  mode 0: rows of N floats in memory.  mode 1: the scatter of a tall form,
+// C[s][rho][ip][n] = src[s][rho - ip - off][n] (n < 4 n4s; zero outside 0 <= row < P), and mode 2: the window matrix of a
+// Toeplitz operand, C[s][p][q] = src[s][a0 + p sa + q] (zero outside [0, amax)) - both were kernels of their own
+// (k_tall_scatter, k_windows) that wrote what this one then read.
+struct RowSrc {
+    int mode, n4s, off, P, a0, sa, amax;
+    int64_t ld;
+};
 template <int QW, int NW>
 __global__ __launch_bounds__(NW * 64) void k_rowwgrad_lds(const float* __restrict__ A, const float* __restrict__ C, float* __restrict__ part,
-                                                      int R, int Q, int N, int ST, int SN, int TS) {
+                                                      int R, int Q, int N, int ST, int SN, int TS, RowSrc cs) {
     constexpr int NT = 3, TH = NW * 64, NVA = (32 * 120 + TH - 1) / TH, NVC = (32 * 16 + TH - 1) / TH;   // 16-byte loads per thread: 32 x Q (Q <= 480) of A, 32 x N (N <= 64) of C
     extern __shared__ float lds[];                 // A tile [32][ST], C tile [32][SN]
     float* Cs = lds + 32 * ST;
@@ -2208,7 +2216,7 @@ __global__ __launch_bounds__(NW * 64) void k_rowwgrad_lds(const float* __restric
     // per-read ones
     const int s = blockIdx.x / TS, ts = blockIdx.x - s * TS, Q4 = Q >> 2, N4 = N >> 2, QB = Q >> 4;
     const float4* Ag = (const float4*)(A + (size_t)s * R * Q);
-    const float4* Cg = (const float4*)(C + (size_t)s * R * N);
+    const float4* Cg = (const float4*)(C + (cs.mode == 0 ? (size_t)s * R * N : (size_t)s * cs.ld));
     float4 va[NVA], vc[NVC];
     auto gload = [&](int r0) {
         const int na = min(32, R - r0) * Q4, nc = min(32, R - r0) * N4;
@@ -2221,8 +2229,23 @@ __global__ __launch_bounds__(NW * 64) void k_rowwgrad_lds(const float* __restric
 #pragma unroll
         for (int i = 0; i < NVC; i++) {
             const int idx = tid + i * TH;
-            const float4 x = Cg[(size_t)r0 * N4 + (idx < nc ? idx : 0)];
-            vc[i] = idx < nc ? x : make_float4(0.f, 0.f, 0.f, 0.f);
+            bool ok = idx < nc;
+            size_t at = (size_t)r0 * N4 + (ok ? idx : 0);
+            if (cs.mode != 0) {
+                const int r = idx / N4, c = idx - r * N4;
+                if (cs.mode == 1) {
+                    const int ip = c / cs.n4s, row = r0 + r - ip - cs.off;
+                    ok = ok && row >= 0 && row < cs.P;
+                    at = (size_t)row * cs.n4s + (c - ip * cs.n4s);
+                } else {
+                    const int e = cs.a0 + (r0 + r) * cs.sa + 4 * c;
+                    ok = ok && e >= 0 && e + 3 < cs.amax;
+                    at = (size_t)(e >> 2);
+                }
+                if (!ok) at = 0;
+            }
+            const float4 x = Cg[at];
+            vc[i] = ok ? x : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     auto lstore = [&]() {
@@ -2292,10 +2315,14 @@ __global__ __launch_bounds__(NW * 64) void k_rowwgrad_lds(const float* __restric
 static int rowwgrad_split(const ToepGeom& rg) { return rg.S >= 48 ? 1 : std::max(1, std::min(8, (rg.P + 31) / 32)); }
 // per-sequence partial banks part[S * TS][Q][N] (TS = rowwgrad_split) of the row GEMM's filter gradient; false when the
 // shape is not covered
-static bool launch_rowwgrad_lds(Engine& e, const float* A, const float* C, float* part, const ToepGeom& rg) {
+static bool rowwgrad_lds_ok(const float* A, const ToepGeom& rg) {
     if (rg.a0 != 0 || rg.sa != rg.Q || rg.lda != (int64_t)rg.P * rg.Q || rg.ldc != (int64_t)rg.P * rg.N) return false;
     if ((rg.Q & 15) || rg.Q > 480 || rg.Q < 64 || rg.N < 33 || rg.N > 48 || (rg.N & 3)) return false;
-    if ((((uintptr_t)A) & 15) || (((uintptr_t)C) & 15)) return false;
+    return (((uintptr_t)A) & 15) == 0;
+}
+static bool launch_rowwgrad_lds(Engine& e, const float* A, const float* C, float* part, const ToepGeom& rg, const RowSrc* src = nullptr) {
+    if (!rowwgrad_lds_ok(A, rg) || (((uintptr_t)C) & 15)) return false;
+    const RowSrc cs = src ? *src : RowSrc{0, 0, 0, 0, 0, 0, 0, 0};
     auto pad16 = [](int x) { return x + ((16 - x % 32) + 32) % 32; };     // smallest stride >= x that is 16 mod 32
     const int ST = pad16(rg.Q), SN = pad16(48);
     const size_t lds = (size_t)32 * (ST + SN) * 4;
@@ -2305,7 +2332,7 @@ static bool launch_rowwgrad_lds(Engine& e, const float* A, const float* C, float
     // few (54 -> 48 us; 16 waves: 53 us)
     const int QW = (QB + 7) / 8;
     const int TS = rowwgrad_split(rg);
-#define ROWWGRAD(QWV) hipLaunchKernelGGL((k_rowwgrad_lds<QWV, 8>), dim3(rg.S * TS), dim3(512), lds, e.st, A, C, part, rg.P, rg.Q, rg.N, ST, SN, TS)
+#define ROWWGRAD(QWV) hipLaunchKernelGGL((k_rowwgrad_lds<QWV, 8>), dim3(rg.S * TS), dim3(512), lds, e.st, A, C, part, rg.P, rg.Q, rg.N, ST, SN, TS, cs)
     if (QW <= 2) ROWWGRAD(2);
     else if (QW == 3) ROWWGRAD(3);
     else ROWWGRAD(4);
@@ -2400,10 +2427,16 @@ static void launch_wgrad(Engine& e, const float* A, const float* C, float* dB, c
             e.failed = true;
             return;
         }
-        hipLaunchKernelGGL(k_tall_scatter, dim3(nblocks((size_t)gm.S * R * H * gm.N)), dim3(256), 0, st, C, dW, gm.S, gm.P, H, gm.N, R,
-                           gm.a0 / gm.sa, gm.ldc);
         const ToepGeom rg = tall_row_geom(gm);
         const int rtiles = ((rg.Q + 127) / 128) * ((rg.N + 31) / 32);
+        static const bool legacy_rows = getenv("MOTIFS_TOEP_LEGACY") != nullptr;
+        static const bool no_src = getenv("MOTIFS_NO_ROW_SRC") != nullptr;
+        // few reads: the row kernel forms the scattered rows itself, from C
+        const bool in_kernel = !legacy_rows && !no_src && gm.S < 48 && rg.B > 1 && rtiles * G < 2048 && (gm.N & 3) == 0 && (gm.ldc & 3) == 0 &&
+                               gm.a0 % gm.sa == 0 && rowwgrad_lds_ok(A, rg) && (((uintptr_t)C) & 15) == 0;
+        if (!in_kernel)
+            hipLaunchKernelGGL(k_tall_scatter, dim3(nblocks((size_t)gm.S * R * H * gm.N)), dim3(256), 0, st, C, dW, gm.S, gm.P, H, gm.N, R,
+                               gm.a0 / gm.sa, gm.ldc);
         if (rg.B > 1 && rtiles * G < 2048) {      // per-sequence partial banks, then their sums (see below)
             const int TS = rowwgrad_split(rg);
             float* part = e.arena.alloc(per * gm.S * TS);
@@ -2413,9 +2446,11 @@ static void launch_wgrad(Engine& e, const float* A, const float* C, float* dB, c
             }
             ToepGeom r1 = rg;
             r1.B = 1;
-            static const bool legacy_rows = getenv("MOTIFS_TOEP_LEGACY") != nullptr;
             int nparts = rg.B * TS;                // partial banks per group
-            if (legacy_rows || !launch_rowwgrad_lds(e, A, dW, part, rg)) {
+            const RowSrc scat{1, gm.N / 4, gm.a0 / gm.sa, gm.P, 0, 0, 0, gm.ldc};
+            if (in_kernel) {
+                (void)launch_rowwgrad_lds(e, A, C, part, rg, &scat);
+            } else if (legacy_rows || !launch_rowwgrad_lds(e, A, dW, part, rg)) {
                 hipLaunchKernelGGL(k_wgrad_mfma, dim3((rg.Q + 127) / 128, gm.S, (rg.N + 31) / 32), dim3(256), 0, st, A, dW, part, r1, 0);
                 nparts = rg.B;
             }
@@ -2439,8 +2474,13 @@ static void launch_wgrad(Engine& e, const float* A, const float* C, float* dB, c
             e.failed = true;
             return;
         }
-        hipLaunchKernelGGL(k_windows, dim3(nblocks((size_t)gm.S * gm.P * gm.Q)), dim3(256), 0, st, A, gm, Wn);
-        if (launch_rowwgrad_lds(e, C, Wn, part, rg)) {
+        static const bool no_src = getenv("MOTIFS_NO_ROW_SRC") != nullptr;
+        // few reads: the row kernel reads the windows from the signal itself
+        const bool in_kernel = !no_src && gm.S < 48 && (gm.a0 & 3) == 0 && (gm.sa & 3) == 0 && (gm.amax & 3) == 0 && (gm.lda & 3) == 0 &&
+                               rowwgrad_lds_ok(C, rg) && (((uintptr_t)A) & 15) == 0;
+        const RowSrc win{2, 0, 0, 0, gm.a0, gm.sa, gm.amax, gm.lda};
+        if (!in_kernel) hipLaunchKernelGGL(k_windows, dim3(nblocks((size_t)gm.S * gm.P * gm.Q)), dim3(256), 0, st, A, gm, Wn);
+        if (in_kernel ? launch_rowwgrad_lds(e, C, A, part, rg, &win) : launch_rowwgrad_lds(e, C, Wn, part, rg)) {
             if (G * ((gm.N + 31) / 32) >= 128)
                 hipLaunchKernelGGL(k_sum_segments_T<32>, dim3((gm.N + 31) / 32, G), dim3(256), 0, st, part, gm.Q, gm.N, gm.B * rowwgrad_split(rg), dB, acc);
             else
