@@ -3110,7 +3110,9 @@ __global__ __launch_bounds__(128) void k_sp_wgrad_ana(const float* __restrict__ 
 // accumulators, and the B partial banks are added in read order on the way out.
 __global__ __launch_bounds__(1024) void k_sp_wgrad_syn_reads(NzView nz, const float* __restrict__ dOut, float* __restrict__ dF, SpDims d) {
     extern __shared__ float accs[];                      // [B][K][128]
+    __shared__ uint2 stg[16][64];
     const int g = blockIdx.z, ip = blockIdx.y, tx = threadIdx.x & 127, b = threadIdx.x >> 7, j0 = blockIdx.x * 128;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int jc = min(j0 + tx, d.W - 1);
     float* mine = accs + (size_t)b * d.K * 128;
     for (int k = 0; k < d.K; k++) mine[k * 128 + tx] = 0.0f;
@@ -3119,20 +3121,26 @@ __global__ __launch_bounds__(1024) void k_sp_wgrad_syn_reads(NzView nz, const fl
         const float* ds = dOut + (size_t)s * d.c * d.W + (size_t)(d.h - 1 - ip) * d.W + jc;
         const int cnt = nz.cnt[s];
         const uint2* es = nz.ent + (size_t)s * nz.cap;
-        for (int z = 0; z < cnt; z += 4) {               // wave-uniform; four image values in flight, added in entry order
-            uint2 en[4];
-            float x[4];
-            int kk[4];
+        // 64 entries at a time come to the wave's LDS slot in one coalesced load; the image values they point at are then
+        // fetched eight at a time (entry -> value was a chain of two trips to memory per entry)
+        for (int z0 = 0; z0 < cnt; z0 += 64) {
+            const int n = min(64, cnt - z0);
+            if (lane < n) stg[wv][lane] = es[z0 + lane];
+            for (int u0 = 0; u0 < n; u0 += 8) {
+                uint2 en[8];
+                float x[8];
+                int kk[8];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                en[u] = es[min(z + u, cnt - 1)];
-                const int p = (int)__umulhi(en[u].x, kmagic(d.K));
-                kk[u] = (int)(en[u].x - (unsigned)p * d.K);
-                x[u] = ds[(size_t)p * d.W];
+                for (int u = 0; u < 8; u++) {
+                    en[u] = stg[wv][min(u0 + u, n - 1)];
+                    const int p = (int)__umulhi(en[u].x, kmagic(d.K));
+                    kk[u] = (int)(en[u].x - (unsigned)p * d.K);
+                    x[u] = ds[(size_t)p * d.W];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    if (u0 + u < n) mine[kk[u] * 128 + tx] = fmaf(__uint_as_float(en[u].y), x[u], mine[kk[u] * 128 + tx]);
             }
-#pragma unroll
-            for (int u = 0; u < 4; u++)
-                if (z + u < cnt) mine[kk[u] * 128 + tx] = fmaf(__uint_as_float(en[u].y), x[u], mine[kk[u] * 128 + tx]);
         }
     }
     __syncthreads();
@@ -3148,7 +3156,9 @@ __global__ __launch_bounds__(1024) void k_sp_wgrad_syn_reads(NzView nz, const fl
 
 __global__ __launch_bounds__(1024) void k_sp_wgrad_ana_reads(const float* __restrict__ img, NzView nz, float* __restrict__ dB, SpDims d, int acc) {
     extern __shared__ float accs[];                      // [B][128][K + 1]
+    __shared__ uint2 stg[16][64];
     const int g = blockIdx.z, i = blockIdx.y, tx = threadIdx.x & 127, b = threadIdx.x >> 7, j0 = blockIdx.x * 128;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int jc = min(j0 + tx, d.W - 1);
     const int per = 128 * (d.K + 1);
     float* my = accs + (size_t)b * per + (size_t)tx * (d.K + 1);
@@ -3158,20 +3168,24 @@ __global__ __launch_bounds__(1024) void k_sp_wgrad_ana_reads(const float* __rest
         const float* is = img + (size_t)s * d.c * d.W + (size_t)i * d.W + jc;
         const int cnt = nz.cnt[s];
         const uint2* es = nz.ent + (size_t)s * nz.cap;
-        for (int z = 0; z < cnt; z += 4) {               // four image values in flight, added in entry order
-            uint2 en[4];
-            float x[4];
-            int kk[4];
+        for (int z0 = 0; z0 < cnt; z0 += 64) {           // as in k_sp_wgrad_syn_reads
+            const int n = min(64, cnt - z0);
+            if (lane < n) stg[wv][lane] = es[z0 + lane];
+            for (int u0 = 0; u0 < n; u0 += 8) {
+                uint2 en[8];
+                float x[8];
+                int kk[8];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                en[u] = es[min(z + u, cnt - 1)];
-                const int p = (int)__umulhi(en[u].x, kmagic(d.K));
-                kk[u] = (int)(en[u].x - (unsigned)p * d.K);
-                x[u] = is[(size_t)p * d.W];
+                for (int u = 0; u < 8; u++) {
+                    en[u] = stg[wv][min(u0 + u, n - 1)];
+                    const int p = (int)__umulhi(en[u].x, kmagic(d.K));
+                    kk[u] = (int)(en[u].x - (unsigned)p * d.K);
+                    x[u] = is[(size_t)p * d.W];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    if (u0 + u < n) my[kk[u]] = fmaf(__uint_as_float(en[u].y), x[u], my[kk[u]]);
             }
-#pragma unroll
-            for (int u = 0; u < 4; u++)
-                if (z + u < cnt) my[kk[u]] = fmaf(__uint_as_float(en[u].y), x[u], my[kk[u]]);
         }
     }
     __syncthreads();
