@@ -1928,10 +1928,12 @@ __global__ void k_frag_bw(const float* __restrict__ Bm, int G, int Q, int N, flo
 }
 template <int KG>
 __global__ __launch_bounds__(256) void k_toep_wide(const float* __restrict__ A, const float* __restrict__ Bf, float* __restrict__ C,
-                                                   ToepGeom gm, int acc, int tps, int64_t ldbf, int SO) {
+                                                   ToepGeom gm, int acc, int tps, int64_t ldbf, int SO, int cs) {
     extern __shared__ float lds[];                 // the block's 32 output rows, [32][SO]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int s = blockIdx.x / tps, p0 = (blockIdx.x - s * tps) * 32;
+    // cs > 1 (few reads): cs blocks share a job's 32 rows, each takes a run of column tiles
+    const int job = blockIdx.x / cs, part = blockIdx.x - job * cs;
+    const int s = job / tps, p0 = (job - s * tps) * 32;
     const float* sig = A + (size_t)s * gm.lda;
     float a[4 * KG];
     // the block's windows overlap: their span (31 sa + Q floats) goes through LDS once, coalesced, instead of one
@@ -1961,13 +1963,14 @@ __global__ __launch_bounds__(256) void k_toep_wide(const float* __restrict__ A, 
         }
     }
     const float4* bp = (const float4*)(Bf + (size_t)(s / gm.B) * ldbf) + lane;
-    const int nct = (gm.N + 31) >> 5;
+    const int nct_all = (gm.N + 31) >> 5;
+    const int ct_lo = part * nct_all / cs, nct = (part + 1) * nct_all / cs;      // this block's tiles [ct_lo, nct)
     float4 cur[KG], nxt[KG];
-    if (wave < nct) {
+    if (ct_lo + wave < nct) {
 #pragma unroll
-        for (int kg = 0; kg < KG; kg++) cur[kg] = bp[(size_t)(wave * KG + kg) * 64];
+        for (int kg = 0; kg < KG; kg++) cur[kg] = bp[(size_t)((ct_lo + wave) * KG + kg) * 64];
     }
-    for (int ct = wave; ct < nct; ct += 4) {       // wave w: column tiles w, w+4, ..
+    for (int ct = ct_lo + wave; ct < nct; ct += 4) {       // wave w: column tiles w, w+4, ..
         const int cn = min(ct + 4, nct - 1);
 #pragma unroll
         for (int kg = 0; kg < KG; kg++) nxt[kg] = bp[(size_t)(cn * KG + kg) * 64];
@@ -1993,7 +1996,15 @@ __global__ __launch_bounds__(256) void k_toep_wide(const float* __restrict__ A, 
     // the rows leave whole: [nrow][N] is one contiguous span of the output
     const int nrow = min(32, gm.P - p0), N4 = gm.N >> 2;
     float* Cs = C + (size_t)s * gm.ldc + (size_t)p0 * gm.N;
-    if ((gm.N & 3) == 0 && (((uintptr_t)Cs) & 15) == 0) {
+    if (cs > 1) {                                  // this block's columns of every row
+        const int c_lo = ct_lo * 32, nc = min(gm.N, nct * 32) - c_lo;
+        for (int idx = tid; idx < nrow * nc; idx += 256) {
+            const int row = idx / nc, col = c_lo + idx - row * nc;
+            const float o = lds[row * SO + col];
+            float* dst = Cs + (size_t)row * gm.N + col;
+            *dst = acc ? *dst + o : o;
+        }
+    } else if ((gm.N & 3) == 0 && (((uintptr_t)Cs) & 15) == 0) {
         int row = tid / N4, c4 = tid - row * N4;
         const int drow = 256 / N4, dc = 256 - drow * N4;
         for (int idx = tid; idx < nrow * N4; idx += 256) {
@@ -2025,11 +2036,12 @@ static bool launch_toep_wide(Engine& e, const float* A, const float* Bm, float* 
     if (!Bf) return true;
     if (fresh) hipLaunchKernelGGL(k_frag_bw, dim3(nblocks(perf * gB)), dim3(256), 0, e.st, Bm, gB, gm.Q, gm.N, Bf);
     const int tps = (gm.P + 31) / 32;
-    const dim3 grid((unsigned)((long)gm.S * tps));
+    const int cs = (long)gm.S * tps < 64 ? std::min(4, NCT) : 1;      // few reads: four blocks per row tile, a wave per column tile
+    const dim3 grid((unsigned)((long)gm.S * tps * cs));
     const int SO = ((gm.N + 15) & ~15) + 8;        // 4 rows apart = 32 banks apart: the two lane halves of a tile store never meet
     const size_t lds = (size_t)32 * SO * 4;
     const int64_t ldbf = gm.ldb == 0 ? 0 : (int64_t)perf;
-#define TOEPWIDE(K) hipLaunchKernelGGL((k_toep_wide<K>), grid, dim3(256), lds, e.st, A, Bf, C, gm, acc, tps, ldbf, SO)
+#define TOEPWIDE(K) hipLaunchKernelGGL((k_toep_wide<K>), grid, dim3(256), lds, e.st, A, Bf, C, gm, acc, tps, ldbf, SO, cs)
     if (KG == 4) TOEPWIDE(4);
     else if (KG == 5) TOEPWIDE(5);
     else if (KG == 6) TOEPWIDE(6);
