@@ -2367,22 +2367,23 @@ __global__ void k_sum_segments(const float* x, size_t per, int B, size_t total, 
     }
 }
 
-// k_sum_segments followed by k_tall_bt_T in one pass: dBm[g][ip][j][n] (+)= sum_b part[g B + b][j][ip][n]
+// k_sum_segments followed by k_tall_bt_T in one pass: dBm[g][ip][j][n] (+)= sum_b part[g B + b][j][ip][n].  Threads walk the
+// partial banks in their own order (B coalesced streams); the sums leave as N-float pieces to the transposed place.
 __global__ void k_sum_segments_btT(const float* __restrict__ x, int B, int G, int H, int W, int N, float* __restrict__ dBm, int acc) {
     const size_t per = (size_t)H * W * N, total = per * G;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const size_t g = i / per, r = i - g * per;       // r indexes dBm [H][W][N]
-        const int n = (int)(r % N), j = (int)((r / N) % W), ip = (int)(r / ((size_t)N * W));
-        const size_t src = ((size_t)j * H + ip) * N + n;
+        const size_t g = i / per, r = i - g * per;       // r indexes a partial bank [W][H][N]
+        const int n = (int)(r % N), ip = (int)((r / N) % H), j = (int)(r / ((size_t)N * H));
         float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
         int b = 0;
         for (; b + 4 <= B; b += 4) {
-            a0 += x[(g * B + b) * per + src], a1 += x[(g * B + b + 1) * per + src];
-            a2 += x[(g * B + b + 2) * per + src], a3 += x[(g * B + b + 3) * per + src];
+            a0 += x[(g * B + b) * per + r], a1 += x[(g * B + b + 1) * per + r];
+            a2 += x[(g * B + b + 2) * per + r], a3 += x[(g * B + b + 3) * per + r];
         }
-        for (; b < B; b++) a0 += x[(g * B + b) * per + src];
+        for (; b < B; b++) a0 += x[(g * B + b) * per + r];
         const float a = (a0 + a1) + (a2 + a3);
-        dBm[i] = acc ? dBm[i] + a : a;
+        float* o = dBm + g * per + ((size_t)ip * W + j) * N + n;
+        *o = acc ? *o + a : a;
     }
 }
 
