@@ -1791,6 +1791,12 @@ __global__ __launch_bounds__(256) void k_tall_fused(const float* __restrict__ A,
             if (c4 >= Q4) c4 -= Q4, row++;
         }
     }
+    // the first bank fragments are on their way while the image rows settle in LDS
+    const int nks = Q >> 4;                        // reduction steps (4 channels each) of this wave
+    const float4* bp = (const float4*)(Bf + (size_t)(s / B) * ldbf) + (size_t)(wave * nks) * 64 + lane;
+    float4 cur[U], nxt[U];
+#pragma unroll
+    for (int i = 0; i < U; i++) cur[i] = bp[(size_t)min(i, nks - 1) * 64];
     {
         int row = tid / Q4, c4 = tid - row * Q4;
         const int drow = 256 / Q4, dc = 256 - drow * Q4;
@@ -1807,13 +1813,8 @@ __global__ __launch_bounds__(256) void k_tall_fused(const float* __restrict__ A,
     for (int rb = 0; rb < 2; rb++)
 #pragma unroll
         for (int cb = 0; cb < NT; cb++) accv[rb][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int nks = Q >> 4;                        // reduction steps (4 channels each) of this wave
     const float* a0p = lds + (lane & 15) * ST + wave * (Q >> 2) + (lane >> 4);
     const float* a1p = a0p + 16 * ST;
-    const float4* bp = (const float4*)(Bf + (size_t)(s / B) * ldbf) + (size_t)(wave * nks) * 64 + lane;
-    float4 cur[U], nxt[U];
-#pragma unroll
-    for (int i = 0; i < U; i++) cur[i] = bp[(size_t)min(i, nks - 1) * 64];
     for (int u0 = 0; u0 < nks; u0 += U) {
 #pragma unroll
         for (int i = 0; i < U; i++) nxt[i] = bp[(size_t)min(u0 + U + i, nks - 1) * 64];
@@ -3801,15 +3802,18 @@ static __device__ void med_select_block(MedState* state, uint32_t* hist, int pas
             loc[j] = hh[tid * 8 + j];
             sum += loc[j];
         }
-        part[tid] = sum;
-        __syncthreads();
-        for (int d = 1; d < 256; d <<= 1) {        // inclusive scan
-            const uint32_t v = tid >= d ? part[tid - d] : 0;
-            __syncthreads();
-            part[tid] += v;
-            __syncthreads();
+        // inclusive scan over the 256 threads: inside each wave by shuffles, the four wave totals through LDS
+        uint32_t incl = sum;
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t v = __shfl_up(incl, d);
+            if ((tid & 63) >= d) incl += v;
         }
-        const uint32_t total = part[255], before = part[tid] - sum;
+        __syncthreads();                            // part[] of the previous selection has been read
+        if ((tid & 63) == 63) part[tid >> 6] = incl;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int w = 0; w < (tid >> 6); w++) woff += part[w];
+        const uint32_t total = part[0] + part[1] + part[2] + part[3], before = woff + incl - sum;
         if (pass == 0 && sel == 0 && tid == 0) {
             sst.cnt = total;
             sst.pref[0] = sst.pref[1] = 0;
@@ -3869,7 +3873,8 @@ uint32_t* median_hist_ptr(void* workspace, int G) {
 void median_threshold(hipStream_t st, const float* ZY, float* thr, int G, int n_per_group, void* workspace, bool have_pass0) {
     MedState* state = (MedState*)workspace;
     uint32_t* hist = median_hist_ptr(workspace, G);
-    const unsigned nb = (unsigned)std::min<size_t>((n_per_group + 256 * 16 - 1) / (256 * 16), 64);
+    // blocks per group: 64 when the groups fill the chip, up to 256 for a step of few mini-batches
+    const unsigned nb = (unsigned)std::min<size_t>((n_per_group + 256 * 16 - 1) / (256 * 16), G >= 4 ? 64 : 256);
     for (int pass = 0; pass < 3; pass++) {            // the workspace arrives zeroed (Engine::zeros)
         float* out = pass == 2 ? thr : nullptr;
         if (pass == 0 && have_pass0) {                // the kernel that wrote the codes has counted the top digits already
