@@ -729,7 +729,7 @@ Tensor Engine::zy_step(Tensor ZY, Tensor g1, Tensor FX, Tensor ab, Tensor pen, T
             float* ds = lst->needs_grad ? grad(lst) : nullptr;
             float* dl = ls->needs_grad ? grad(ls) : nullptr;
             if (failed) return;
-            hipLaunchKernelGGL(k_zy_step_bwd, dim3(nblocks(out->n, 256 * 8, 2048)), dim3(256), 0, st, out->g, out->v, ZY->v, g1->v, FX->v,
+            hipLaunchKernelGGL(k_zy_step_bwd, dim3(nblocks(out->n, 256 * 16, 2048)), dim3(256), 0, st, out->g, out->v, ZY->v, g1->v, FX->v,
                                ab ? ab->v : nullptr, pen->v, lst->v, ls->v, out->n, d0, a0, d1, a1, d2, a2, d3, a3, dp, ds, dl);
         });
     return out;
@@ -770,7 +770,7 @@ Tensor Engine::f_step(Tensor Fc, Tensor Fgrad, float sg, Tensor kst, Tensor ks, 
                 failed = true;
                 return;
             }
-            hipLaunchKernelGGL(k_f_step_bwd, dim3(nblocks(out->n, 256, 2048)), dim3(256), 0, st, out->g, out->v, Fgrad ? Fgrad->v : nullptr, sg,
+            hipLaunchKernelGGL(k_f_step_bwd, dim3(nblocks(out->n, 256 * 4, 2048)), dim3(256), 0, st, out->g, out->v, Fgrad ? Fgrad->v : nullptr, sg,
                                kst->v, ks->v, out->n, d0, a0, d1, a1, dt, dk, ds);
             if (dt) bcast_reduce(st, dt, nullptr, out->n, Fc->n, 1.0f, grad(Fc));   // the shared bank: sum over the groups
         });
@@ -828,11 +828,11 @@ std::pair<Tensor, Tensor> Engine::zy_step2(Tensor ZY, Tensor g1, Tensor FX, Tens
             const bool v4 = (per & 3) == 0 && al16(out->g) && al16(abn->g) && al16(g3) && al16(out->v) && al16(ZY->v) && al16(g1->v) &&
                             al16(FX->v) && al16(abp ? abp->v : nullptr) && al16(d0) && al16(d1) && al16(d2) && al16(d3);
             if (v4)
-                hipLaunchKernelGGL(k_zy_step2_bwd<4>, dim3(nblocks(per / 4, 256, std::max<size_t>(2048 / G, 1)), G), dim3(256), 0, st, out->g, abn->g,
+                hipLaunchKernelGGL(k_zy_step2_bwd<4>, dim3(nblocks(per / 4, 256 * 4, std::max<size_t>(2048 / G, 1)), G), dim3(256), 0, st, out->g, abn->g,
                                    g3, out->fl_b, g3 ? out->fl_thr : nullptr, out->v, ZY->v, g1->v, FX->v, abp ? abp->v : nullptr, pen->v, lst->v,
                                    ls->v, per, d0, a0, d1, a1, d2, a2, d3, a3, dp, ds, dl);
             else
-                hipLaunchKernelGGL(k_zy_step2_bwd<1>, dim3(nblocks(per, 256, std::max<size_t>(2048 / G, 1)), G), dim3(256), 0, st, out->g, abn->g, g3,
+                hipLaunchKernelGGL(k_zy_step2_bwd<1>, dim3(nblocks(per, 256 * 16, std::max<size_t>(2048 / G, 1)), G), dim3(256), 0, st, out->g, abn->g, g3,
                                    out->fl_b, g3 ? out->fl_thr : nullptr, out->v, ZY->v, g1->v, FX->v, abp ? abp->v : nullptr, pen->v, lst->v,
                                    ls->v, per, d0, a0, d1, a1, d2, a2, d3, a3, dp, ds, dl);
         });
