@@ -729,7 +729,7 @@ Tensor Engine::zy_step(Tensor ZY, Tensor g1, Tensor FX, Tensor ab, Tensor pen, T
             float* ds = lst->needs_grad ? grad(lst) : nullptr;
             float* dl = ls->needs_grad ? grad(ls) : nullptr;
             if (failed) return;
-            hipLaunchKernelGGL(k_zy_step_bwd, dim3(nblocks(out->n, 256 * 16, 2048)), dim3(256), 0, st, out->g, out->v, ZY->v, g1->v, FX->v,
+            hipLaunchKernelGGL(k_zy_step_bwd, dim3(nblocks(out->n, 256 * 8, 2048)), dim3(256), 0, st, out->g, out->v, ZY->v, g1->v, FX->v,
                                ab ? ab->v : nullptr, pen->v, lst->v, ls->v, out->n, d0, a0, d1, a1, d2, a2, d3, a3, dp, ds, dl);
         });
     return out;
