@@ -6,7 +6,7 @@ import numpy as np, torch
 from _pkg import load_pkg
 pkg = load_pkg(); lib, sy = pkg._lib, pkg.synth
 ctx = lib.Context(0)
-N, L, K = 20000, 200, 200
+N, L, K = int(sys.argv[1]) if len(sys.argv) > 1 else 20000, 200, 200
 codes = sy.gen_codes(N, L, 1)
 pwms, lens = sy.gen_pwm_bank(K, 2, 12, 12)
 bank = sy.pad_bank(pwms, lens)
@@ -23,4 +23,4 @@ for _ in range(20): ctx.pwm_scan_dense_dev(bank, lens, dcodes.data_ptr(), N, L, 
 ctx.synchronize()
 ms, k = ctx.kernel_ms(lib.KS_SCAN_DENSE)
 byts = N * L + K * 4 * 12 * 2 + N * K * Lout * 2
-print(f"dense {ms / k:.4f} ms per launch, {byts / (ms / k) / 1e6:.0f} GB/s = {byts / (ms / k) / 8e9:.3f} of 8 TB/s")
+print(f"N {N}: dense {ms / k:.4f} ms per launch, {byts / (ms / k) / 1e6:.0f} GB/s = {byts / (ms / k) / 8e9:.3f} of 8 TB/s")
