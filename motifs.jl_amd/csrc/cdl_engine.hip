@@ -3550,11 +3550,32 @@ static __device__ uint32_t block_radix_select(const float* x, int n, uint32_t k,
     for (int shift = 24; shift >= 0; shift -= 8) {
         for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
         __syncthreads();
-        for (int i = threadIdx.x; i < n; i += blockDim.x) {
-            const float v = x[i];
-            if (!pred(v)) continue;
-            const uint32_t key = fkey(v);
-            if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 0xffu], 1u);
+        if (shift == 24) {
+            // the leading digit (sign + 7 exponent bits) takes a handful of values over a whole read: one LDS atomic per element
+            // would queue thousands of adds on two or three bins, so each wave counts its lanes per distinct digit first
+            // (as many ballots as the wave holds distinct digits) and adds the counts
+            const int nround = (n + (int)blockDim.x - 1) / (int)blockDim.x;
+            for (int rd = 0; rd < nround; rd++) {
+                const int i = rd * (int)blockDim.x + (int)threadIdx.x;
+                const float v = i < n ? x[i] : 0.0f;
+                bool todo = i < n && pred(v);
+                const uint32_t d = fkey(v) >> 24;
+                while (true) {
+                    const unsigned long long live = __ballot(todo);
+                    if (!live) break;
+                    const uint32_t lead = (uint32_t)__shfl((int)d, __builtin_ctzll(live));
+                    const unsigned long long same = __ballot(todo && d == lead);
+                    if ((threadIdx.x & 63) == (unsigned)__builtin_ctzll(live)) atomicAdd(&hist[lead], (uint32_t)__builtin_popcountll(same));
+                    if (d == lead) todo = false;
+                }
+            }
+        } else {
+            for (int i = threadIdx.x; i < n; i += blockDim.x) {
+                const float v = x[i];
+                if (!pred(v)) continue;
+                const uint32_t key = fkey(v);
+                if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 0xffu], 1u);
+            }
         }
         __syncthreads();
         if (threadIdx.x < 64) {                     // first bin whose running count exceeds k: 4 bins per lane, wave scan
