@@ -263,6 +263,28 @@ def test_df_telescoping_equals_literal_sequence(ctx, pkg, tmp_path):
     assert rel_inf(outs["short"]["flat"], outs["literal"]["flat"]) <= 1e-5
 
 
+def test_fused_forms_equal_the_separate_launches(ctx, pkg, tmp_path):
+    """Round 3 folded neighbouring kernels of the engine into one another (update_X's step + projection + entry lists, the +-S image
+    into the synthesis gather, row GEMM + gather, the scattered rows / windows formed inside the row filter-gradient kernel,
+    the a4 scan on base codes).  Every fold keeps its separate-launch form behind a switch that is read once per process: the
+    configs[1]-shape mini-batch with all of them off gives the same loss and gradient (the fixture is also held against the
+    float64 oracle in test_cfg2_golden)."""
+    import subprocess
+    import sys
+    switches = {"MOTIFS_NO_X_PROJECT": "1", "MOTIFS_NO_TOEP_PLUS": "1", "MOTIFS_NO_TALL_FUSED": "1", "MOTIFS_NO_ROW_SRC": "1", "MOTIFS_NO_ONEHOT_SCAN": "1"}
+    outs = {}
+    for tag, env in (("fused", {}), ("separate", switches)):
+        path = str(tmp_path / (tag + ".npz"))
+        e = dict(os.environ)
+        for k in switches:
+            e.pop(k, None)
+        e.update(env)
+        subprocess.run([sys.executable, os.path.join(HERE, "_df_literal_helper.py"), path], check=True, env=e, timeout=300)
+        outs[tag] = np.load(path)
+    assert abs(outs["fused"]["loss"][0] - outs["separate"]["loss"][0]) <= 2e-6 * abs(outs["separate"]["loss"][0])
+    assert rel_inf(outs["fused"]["flat"], outs["separate"]["flat"]) <= 1e-5
+
+
 def test_train_step_matches_adabelief_oracle(ctx, pkg):
     hp, codes, cdl_o = tiny(5, G=1)
     cdl = to_model(pkg, ctx, hp, codes.shape[1], cdl_o)
