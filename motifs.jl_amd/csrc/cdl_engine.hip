@@ -1448,7 +1448,7 @@ static bool launch_ana_lds(Engine& e, const float* A, const float* Bm, float* C,
     if (lds > 64 * 1024) lds = 64 * 1024;
     if (lds < need) lds = need;
     const int nch = gm.sa / CC;
-    if (jobs < 64 && nch > 1 && gm.ldc == (int64_t)gm.P * gm.N) {   // few reads: a block per (job, channel chunk), partial tiles, one sum
+    if (jobs < 256 && nch > 1 && gm.ldc == (int64_t)gm.P * gm.N) {   // few reads: a block per (job, channel chunk), partial tiles, one sum
         const size_t cn = (size_t)gm.S * gm.ldc;
         float* part = e.arena.alloc(cn * nch);
         if (!part) {
@@ -1864,7 +1864,7 @@ static bool launch_tall_fused(Engine& e, const float* A, const float* Bt, float*
     if (rg.a0 != 0 || rg.sa != rg.Q || rg.lda != (int64_t)rg.P * rg.Q) return false;
     if ((rg.Q & 15) || rg.Q > 480 || rg.Q < 64 || rg.N < 9 || rg.N > 64 || (((uintptr_t)A) & 15)) return false;
     const int TR = 33 - H, tps = (gm.P + TR - 1) / TR;
-    if ((long)gm.S * tps > 512) return false;      // many reads: the two-launch form reads every image row once
+    if ((long)gm.S * tps > 1024) return false;     // many reads: the two-launch form reads every image row once
     const int groups = rg.ldb == 0 ? 1 : rg.S / rg.B;
     const size_t perf = (size_t)(rg.Q / 4) * 256;
     bool fresh;
@@ -2037,7 +2037,7 @@ static bool launch_toep_wide(Engine& e, const float* A, const float* Bm, float* 
     if (!Bf) return true;
     if (fresh) hipLaunchKernelGGL(k_frag_bw, dim3(nblocks(perf * gB)), dim3(256), 0, e.st, Bm, gB, gm.Q, gm.N, Bf);
     const int tps = (gm.P + 31) / 32;
-    const int cs = (long)gm.S * tps < 64 ? std::min(4, NCT) : 1;      // few reads: four blocks per row tile, a wave per column tile
+    const int cs = (long)gm.S * tps < 256 ? std::min(4, NCT) : 1;      // few reads: four blocks per row tile, a wave per column tile
     const dim3 grid((unsigned)((long)gm.S * tps * cs));
     const int SO = ((gm.N + 15) & ~15) + 8;        // 4 rows apart = 32 banks apart: the two lane halves of a tile store never meet
     const size_t lds = (size_t)32 * SO * 4;
@@ -2325,7 +2325,11 @@ __global__ __launch_bounds__(NW * 64) void k_rowwgrad_lds(const float* __restric
     }
 }
 // blocks per sequence of k_rowwgrad_lds: 1 when the sequences alone fill the chip
-static int rowwgrad_split(const ToepGeom& rg) { return rg.S >= 48 ? 1 : std::max(1, std::min(8, (rg.P + 31) / 32)); }
+static int rowwgrad_split(const ToepGeom& rg) {
+    const int tiles = (rg.P + 31) / 32;
+    if (rg.S >= 192) return 1;
+    return std::max(1, std::min(std::min(8, tiles), (255 + rg.S) / rg.S));     // enough blocks for the chip, at most one per row tile
+}
 // per-sequence partial banks part[S * TS][Q][N] (TS = rowwgrad_split) of the row GEMM's filter gradient; false when the
 // shape is not covered
 static bool rowwgrad_lds_ok(const float* A, const ToepGeom& rg) {
@@ -3403,7 +3407,7 @@ __global__ __launch_bounds__(256) void k_sp_syn_rows(NzView nz, const float* __r
 static void launch_sp_syn(hipStream_t st, const NzView& nz, const float* FAf, float* out, const SpDims& d, int acc) {
     static const bool legacy = getenv("MOTIFS_TOEP_LEGACY") != nullptr;
     if (!legacy && (d.W & 3) == 0 && d.W <= 1024 && (d.ldf & 3) == 0 && ((((uintptr_t)FAf) | ((uintptr_t)out)) & 15) == 0) {
-        if (d.S >= 48) hipLaunchKernelGGL(k_sp_syn_rows<32>, dim3((d.c + 31) / 32, d.S), dim3(256), 0, st, nz, FAf, out, d, acc);
+        if (d.S >= 192) hipLaunchKernelGGL(k_sp_syn_rows<32>, dim3((d.c + 31) / 32, d.S), dim3(256), 0, st, nz, FAf, out, d, acc);
         else hipLaunchKernelGGL(k_sp_syn_rows<2>, dim3((d.c + 1) / 2, d.S), dim3(256), 0, st, nz, FAf, out, d, acc);
         return;
     }

@@ -437,14 +437,21 @@ int motifs_model_create(motifs_ctx* ctx, const motifs_hparams* hp, int L, size_t
     MOTIFS_HIP_CHECK(hipMalloc(&m->grads, m->nP * 4));
     MOTIFS_HIP_CHECK(hipMalloc(&m->ada_m, m->nP * 4));
     MOTIFS_HIP_CHECK(hipMalloc(&m->ada_s, m->nP * 4));
-    MOTIFS_HIP_CHECK(hipMemset(m->params, 0, m->nP * 4));
-    MOTIFS_HIP_CHECK(hipMemset(m->ada_m, 0, m->nP * 4));
-    MOTIFS_HIP_CHECK(hipMemset(m->ada_s, 0, m->nP * 4));
+    // (hipMemset of device memory returns before the fill has run, and it runs on the NULL stream: on a context with its own
+    // non-blocking stream nothing ordered these fills against the first parameter upload - found in round 3 as NaN losses of a
+    // model created right after a large one was freed.  The fills go on the context's stream and are waited for below.)
+    MOTIFS_HIP_CHECK(hipMemsetAsync(m->params, 0, m->nP * 4, ctx->stream));
+    MOTIFS_HIP_CHECK(hipMemsetAsync(m->ada_m, 0, m->nP * 4, ctx->stream));
+    MOTIFS_HIP_CHECK(hipMemsetAsync(m->ada_s, 0, m->nP * 4, ctx->stream));
     m->arena_bytes = arena_bytes ? arena_bytes : ((size_t)8 << 30);
     void* base = nullptr;
     MOTIFS_HIP_CHECK(hipMalloc(&base, m->arena_bytes));
     m->eng.arena.base = (char*)base;
     m->eng.arena.cap = m->arena_bytes;
+    // MOTIFS_POISON_ARENA=1 (debugging aid): the arena starts as NaN bit patterns (at most its first 2 GiB), so a kernel that reads
+    // what nothing wrote shows up as NaN in the loss instead of hiding behind the zero pages of a fresh allocation
+    if (getenv("MOTIFS_POISON_ARENA")) MOTIFS_HIP_CHECK(hipMemsetAsync(base, 0xFF, std::min<size_t>(m->arena_bytes, (size_t)2 << 30), ctx->stream));
+    MOTIFS_HIP_CHECK(hipStreamSynchronize(ctx->stream));               // the caller may bind another stream before its first call
     m->eng.st = ctx->stream;
     m->use_graphs = getenv("MOTIFS_NO_GRAPH") == nullptr;
     *out = m;
@@ -535,8 +542,8 @@ int motifs_model_init_random(motifs_model* m, uint64_t seed) {
     warm[2] = (float)(0.05 * uni());
     m->b1p = 0.9;
     m->b2p = 0.999;
-    MOTIFS_HIP_CHECK(hipMemset(m->ada_m, 0, m->nP * 4));
-    MOTIFS_HIP_CHECK(hipMemset(m->ada_s, 0, m->nP * 4));
+    MOTIFS_HIP_CHECK(hipMemsetAsync(m->ada_m, 0, m->nP * 4, m->ctx->stream));    // on the stream the optimiser runs on (see motifs_model_create)
+    MOTIFS_HIP_CHECK(hipMemsetAsync(m->ada_s, 0, m->nP * 4, m->ctx->stream));
     return motifs_model_set_params(m, D.data(), F.data(), warm, V.data());
 }
 
