@@ -273,16 +273,20 @@ def test_fused_forms_equal_the_separate_launches(ctx, pkg, tmp_path):
     import sys
     switches = {"MOTIFS_NO_X_PROJECT": "1", "MOTIFS_NO_TOEP_PLUS": "1", "MOTIFS_NO_TALL_FUSED": "1", "MOTIFS_NO_ROW_SRC": "1", "MOTIFS_NO_ONEHOT_SCAN": "1"}
     outs = {}
-    for tag, env in (("fused", {}), ("separate", switches)):
+    # third run: the arena starts as NaN bit patterns (MOTIFS_POISON_ARENA), so a kernel that reads what nothing wrote would show
+    for tag, env in (("fused", {}), ("separate", switches), ("poisoned", {"MOTIFS_POISON_ARENA": "1"})):
         path = str(tmp_path / (tag + ".npz"))
         e = dict(os.environ)
-        for k in switches:
+        for k in list(switches) + ["MOTIFS_POISON_ARENA"]:
             e.pop(k, None)
         e.update(env)
         subprocess.run([sys.executable, os.path.join(HERE, "_df_literal_helper.py"), path], check=True, env=e, timeout=300)
         outs[tag] = np.load(path)
     assert abs(outs["fused"]["loss"][0] - outs["separate"]["loss"][0]) <= 2e-6 * abs(outs["separate"]["loss"][0])
     assert rel_inf(outs["fused"]["flat"], outs["separate"]["flat"]) <= 1e-5
+    assert np.isfinite(outs["poisoned"]["flat"]).all()
+    assert abs(outs["fused"]["loss"][0] - outs["poisoned"]["loss"][0]) <= 2e-6 * abs(outs["fused"]["loss"][0])
+    assert rel_inf(outs["fused"]["flat"], outs["poisoned"]["flat"]) <= 1e-5
 
 
 def test_train_step_matches_adabelief_oracle(ctx, pkg):
