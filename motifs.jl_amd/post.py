@@ -20,6 +20,7 @@ def score_range(ctx, hits_t, scores_t, n, K):
     torch = _torch()
     mn = torch.empty(K, dtype=torch.int16, device=hits_t.device)
     mx = torch.empty(K, dtype=torch.int16, device=hits_t.device)
+    _torch_first(mn)
     ctx.hits_minmax_dev(hits_t.data_ptr(), scores_t.data_ptr(), n, K, mn.data_ptr(), mx.data_ptr())
     ctx.synchronize()
     return mn.cpu().numpy().view(np.float16), mx.cpu().numpy().view(np.float16)
@@ -44,12 +45,19 @@ def sweep_thresholds(min_scores, max_scores):
     return thr, [len(r) for r in rows]
 
 
+def _torch_first(t):
+    """The library's kernels run on the context's stream, torch's fills and uploads on torch's: wait for torch's before the
+    library reads what it produced (a no-op when the two are the same stream and idle)."""
+    _torch().cuda.current_stream(t.device).synchronize()
+
+
 def sweep_counts(ctx, hits_t, scores_t, n, thr):
     """counts[m][j] = get_hits(scores of motif m, thr[m][j]) for the whole sweep at once."""
     torch = _torch()
     K, T = thr.shape
     thr_t = torch.from_numpy(np.ascontiguousarray(thr).view(np.int16)).to(hits_t.device)
     counts = torch.zeros((K, T), dtype=torch.int64, device=hits_t.device)
+    _torch_first(counts)
     ctx.hits_threshold_counts_dev(hits_t.data_ptr(), scores_t.data_ptr(), n, K, thr_t.data_ptr(), T, counts.data_ptr())
     ctx.synchronize()
     return counts.cpu().numpy()
@@ -75,6 +83,7 @@ def filter_by_thresh(ctx, hits_t, scores_t, n, thresh):
     th_t = torch.from_numpy(np.ascontiguousarray(thresh, dtype=np.float16).view(np.int16)).to(hits_t.device)
     oh = torch.empty_like(hits_t)
     os_ = torch.empty_like(scores_t)
+    _torch_first(th_t)
     kept = ctx.hits_filter_dev(hits_t.data_ptr(), scores_t.data_ptr(), n, K, th_t.data_ptr(), oh.data_ptr(), os_.data_ptr())
     return oh, os_, kept
 
@@ -85,6 +94,7 @@ def posdicts2countmats(ctx, strands, codes_dev_ptr, L, lens, maxlen, n0=0, ps=0.
     torch = _torch()
     K = len(lens)
     counts = torch.zeros((K, maxlen, 4), dtype=torch.int32, device="cuda")
+    _torch_first(counts)
     for hits_t, n, comp in strands:
         ctx.hits_count_matrices_dev(hits_t.data_ptr(), n, codes_dev_ptr, L, n0, lens, K, maxlen, comp, counts.data_ptr())
     ctx.synchronize()
@@ -98,6 +108,7 @@ def code_quantile(ctx, recs_t, n, p):
     patterns: the two order statistics it interpolates between, then a + gamma*(b - a) as Julia evaluates it."""
     torch = _torch()
     hist = torch.empty(65536, dtype=torch.int32, device=recs_t.device)
+    _torch_first(hist)
     ctx.codes_mag_histogram_dev(recs_t.data_ptr(), n, hist.data_ptr())
     ctx.synchronize()
     hcnt = hist.cpu().numpy().astype(np.int64)
@@ -121,6 +132,7 @@ def filter_code_components(ctx, recs_t, n, p):
     torch = _torch()
     thr = code_quantile(ctx, recs_t, n, p)
     out = torch.empty_like(recs_t)
+    _torch_first(out)
     m = ctx.codes_filter_dev(recs_t.data_ptr(), n, thr, out.data_ptr())
     return out, m, thr
 
@@ -158,6 +170,7 @@ def enumerate_triplets(ctx, recs_t, n, h):
     st = torch.from_numpy(starts.view(np.int32)).to(dev)
     ln = torch.from_numpy(lens.view(np.int32)).to(dev)
     offs = torch.empty(nr, dtype=torch.int64, device=dev)
+    _torch_first(ln)
     total = ctx.triplets_offsets_dev(ln.data_ptr(), nr, offs.data_ptr())
     if total == 0:
         return empty
