@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstdlib>
 
 #include <string>
 #include <thread>
@@ -26,7 +27,14 @@ struct DevBuf {
         hipError_t e = hipMalloc(&p, want);
         if (e != hipSuccess) return e;
         cap = want;
-        return hipSuccess;
+        // MOTIFS_POISON_WS=1 (debugging aid): a new workspace starts as 0xFF bytes instead of whatever the allocator hands out,
+        // so a kernel that reads a cell, entry or slot nothing wrote gives the same wrong answer every time
+        static const bool poison = getenv("MOTIFS_POISON_WS") != nullptr;
+        if (poison) {
+            e = hipMemset(p, 0xFF, want);
+            if (e == hipSuccess) e = hipDeviceSynchronize();
+        }
+        return e;
     }
     void release() {
         if (p) (void)hipFree(p);
