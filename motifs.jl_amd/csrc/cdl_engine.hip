@@ -1280,8 +1280,15 @@ __global__ __launch_bounds__(512) void k_toep_mfma(const float* __restrict__ A, 
 // out[i] (+)= part[0][i] + part[1][i] + ... (k partial images of n floats, added in order)
 __global__ void k_sum_parts(const float* __restrict__ part, size_t n, int k, float* __restrict__ out, int acc) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        float a = part[i];
-        for (int j = 1; j < k; j++) a += part[(size_t)j * n + i];
+        float a = 0.0f;
+        for (int j0 = 0; j0 < k; j0 += 8) {        // eight loads in flight, added in order
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = j0 + u < k ? part[(size_t)(j0 + u) * n + i] : 0.0f;
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (j0 + u < k) a = (j0 + u == 0) ? v[u] : a + v[u];
+        }
         out[i] = acc ? out[i] + a : a;
     }
 }
@@ -1624,9 +1631,18 @@ __global__ void k_tall_gather(const float* __restrict__ Wt, float* __restrict__ 
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int n = (int)(i % N), r = (int)((i / N) % P), s = (int)(i / ((size_t)N * P));
         float a = 0.0f;
-        for (int ip = 0; ip < H; ip++) {
-            const int rho = r + ip + off;
-            if (rho >= 0 && rho < R) a += Wt[(((size_t)s * R + rho) * H + ip) * N + n];
+        for (int i0 = 0; i0 < H; i0 += 8) {        // eight loads in flight, added in order
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int ip = i0 + u, rho = r + ip + off;
+                v[u] = (ip < H && rho >= 0 && rho < R) ? Wt[(((size_t)s * R + rho) * H + ip) * N + n] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int ip = i0 + u, rho = r + ip + off;
+                if (ip < H && rho >= 0 && rho < R) a += v[u];
+            }
         }
         const size_t oi = (size_t)s * ldc + (size_t)r * N + n;
         if (y) a += yb * y[oi];
@@ -2360,14 +2376,16 @@ static bool launch_rowwgrad_lds(Engine& e, const float* A, const float* C, float
 __global__ void k_sum_segments(const float* x, size_t per, int B, size_t total, float* y, int acc) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const size_t g = i / per, j = i - g * per;
-        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;          // four chains: the loads of a long sum overlap
-        int b = 0;
-        for (; b + 4 <= B; b += 4) {
-            a0 += x[(g * B + b) * per + j], a1 += x[(g * B + b + 1) * per + j];
-            a2 += x[(g * B + b + 2) * per + j], a3 += x[(g * B + b + 3) * per + j];
+        float c[4] = {0.0f, 0.0f, 0.0f, 0.0f};                     // four chains of adds, twelve loads in flight (k_sum_segments_T)
+        for (int b = 0; b < B; b += 12) {
+            float v[12];
+#pragma unroll
+            for (int u = 0; u < 12; u++) v[u] = b + u < B ? x[(g * B + b + u) * per + j] : 0.0f;
+#pragma unroll
+            for (int u = 0; u < 12; u++)
+                if (b + u < B) c[u & 3] += v[u];
         }
-        for (; b < B; b++) a0 += x[(g * B + b) * per + j];
-        const float a = (a0 + a1) + (a2 + a3);
+        const float a = (c[0] + c[1]) + (c[2] + c[3]);
         y[i] = acc ? y[i] + a : a;
     }
 }
@@ -2379,14 +2397,16 @@ __global__ void k_sum_segments_btT(const float* __restrict__ x, int B, int G, in
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const size_t g = i / per, r = i - g * per;       // r indexes a partial bank [W][H][N]
         const int n = (int)(r % N), ip = (int)((r / N) % H), j = (int)(r / ((size_t)N * H));
-        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
-        int b = 0;
-        for (; b + 4 <= B; b += 4) {
-            a0 += x[(g * B + b) * per + r], a1 += x[(g * B + b + 1) * per + r];
-            a2 += x[(g * B + b + 2) * per + r], a3 += x[(g * B + b + 3) * per + r];
+        float c[4] = {0.0f, 0.0f, 0.0f, 0.0f};                     // four chains of adds, twelve loads in flight (k_sum_segments_T)
+        for (int b = 0; b < B; b += 12) {
+            float v[12];
+#pragma unroll
+            for (int u = 0; u < 12; u++) v[u] = b + u < B ? x[(g * B + b + u) * per + r] : 0.0f;
+#pragma unroll
+            for (int u = 0; u < 12; u++)
+                if (b + u < B) c[u & 3] += v[u];
         }
-        for (; b < B; b++) a0 += x[(g * B + b) * per + r];
-        const float a = (a0 + a1) + (a2 + a3);
+        const float a = (c[0] + c[1]) + (c[2] + c[3]);
         float* o = dBm + g * per + ((size_t)ip * W + j) * N + n;
         *o = acc ? *o + a : a;
     }
@@ -2414,14 +2434,19 @@ __global__ __launch_bounds__(256) void k_sum_segments_T(const float* __restrict_
     const size_t per = (size_t)Q * N;
     for (int idx = tid; idx < cnt; idx += 256) {
         const float* src = part + (size_t)g * B * per + (size_t)n0 * Q + idx;
-        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;          // four chains: the loads of a long sum overlap
-        int b = 0;
-        for (; b + 4 <= B; b += 4) {
-            a0 += src[(size_t)b * per], a1 += src[(size_t)(b + 1) * per];
-            a2 += src[(size_t)(b + 2) * per], a3 += src[(size_t)(b + 3) * per];
+        // four chains of adds (partial b goes to chain b & 3, as ever); the loads come twelve at a time - with four at a time a
+        // sum over the 36-48 partial banks of a one-mini-batch step was nine to twelve trips to memory in a row
+        float a[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int b = 0; b < B; b += 12) {
+            float v[12];
+#pragma unroll
+            for (int u = 0; u < 12; u++) v[u] = b + u < B ? src[(size_t)(b + u) * per] : 0.0f;
+#pragma unroll
+            for (int u = 0; u < 12; u++)
+                if (b + u < B) a[u & 3] += v[u];
         }
-        for (; b < B; b++) a0 += src[(size_t)b * per];
-        t[idx % Q][idx / Q] = (a0 + a1) + (a2 + a3);
+        // (a tail of 1-3 partials used to go to chain 0 and now goes to chains 0..2: the same terms)
+        t[idx % Q][idx / Q] = (a[0] + a[1]) + (a[2] + a[3]);
     }
     __syncthreads();
     for (int idx = tid; idx < Q * NT; idx += 256) {
