@@ -906,6 +906,76 @@ Tensor Engine::norm4(Tensor x) {
     return out;
 }
 
+// update_D's multiplicative step in one pass (model.jl:285-289): out = norm4(exp(-mu * Dgrad) .* Dc), four bases at a time,
+// with the arithmetic of the five launches it replaces (lin, mul, exp, mul, norm4) and one kernel for their five VJPs.
+__global__ void k_d_step(const float* __restrict__ g, const float* __restrict__ mu, const float* __restrict__ Dc, size_t n4, float* __restrict__ out) {
+    const float neg = -1.0f * *mu;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 gv = ((const float4*)g)[i], dc = ((const float4*)Dc)[i];
+        float4 q;
+        q.x = expf(gv.x * neg) * dc.x, q.y = expf(gv.y * neg) * dc.y, q.z = expf(gv.z * neg) * dc.z, q.w = expf(gv.w * neg) * dc.w;
+        const float s = q.x + q.y + q.z + q.w;
+        ((float4*)out)[i] = make_float4(q.x / s, q.y / s, q.z / s, q.w / s);
+    }
+}
+// go = d out.  dq = (go - <go, out>) / s;  d Dc (+)= dq .* ex;  d Dgrad (+)= -mu * dq .* q;  d mu -= sum(dq .* q .* Dgrad)
+__global__ void k_d_step_bwd(const float* __restrict__ go, const float* __restrict__ out, const float* __restrict__ g, const float* __restrict__ mu,
+                             const float* __restrict__ Dc, size_t n4, float* dg, int ag, float* dDc, int aDc, float* dmu) {
+    const float neg = -1.0f * *mu;
+    double sm = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 gv = ((const float4*)g)[i], dc = ((const float4*)Dc)[i], o = ((const float4*)out)[i], gq = ((const float4*)go)[i];
+        const float ex[4] = {expf(gv.x * neg), expf(gv.y * neg), expf(gv.z * neg), expf(gv.w * neg)};
+        const float dcv[4] = {dc.x, dc.y, dc.z, dc.w}, gg[4] = {gv.x, gv.y, gv.z, gv.w}, ov[4] = {o.x, o.y, o.z, o.w}, gov[4] = {gq.x, gq.y, gq.z, gq.w};
+        const float s = (ex[0] * dcv[0] + ex[1] * dcv[1]) + ex[2] * dcv[2] + ex[3] * dcv[3];
+        const float dot = gov[0] * ov[0] + gov[1] * ov[1] + gov[2] * ov[2] + gov[3] * ov[3];
+        float ddc[4], ddg[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const float dq = (gov[u] - dot) / s;
+            const float dp = (dq * dcv[u]) * ex[u];                 // through the product with Dc, then through exp
+            ddc[u] = dq * ex[u];
+            ddg[u] = dp * neg;
+            sm += (double)dp * (double)gg[u];
+        }
+        if (dDc) {
+            float4 t = aDc ? ((float4*)dDc)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            ((float4*)dDc)[i] = make_float4(t.x + ddc[0], t.y + ddc[1], t.z + ddc[2], t.w + ddc[3]);
+        }
+        if (dg) {
+            float4 t = ag ? ((float4*)dg)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            ((float4*)dg)[i] = make_float4(t.x + ddg[0], t.y + ddg[1], t.z + ddg[2], t.w + ddg[3]);
+        }
+    }
+    if (!dmu) return;
+    for (int d = 32; d >= 1; d >>= 1) sm += __shfl_xor(sm, d);
+    __shared__ double red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sm;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(dmu, -(float)(red[0] + red[1] + red[2] + red[3]));      // d(-mu) = sum: d mu = -sum
+}
+Tensor Engine::d_step(Tensor Dgrad, Tensor mu, Tensor Dc) {
+    static const bool off = getenv("MOTIFS_NO_D_STEP") != nullptr;
+    auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+    if (off || Dc->n != Dgrad->n || (Dgrad->n & 3) || !al16(Dgrad->v) || !al16(Dc->v))   // a bank shared by the mini-batches: the separate launches
+        return norm4(mul(expo(mul(Dgrad, lin(mu, -1.0f, nullptr, 0.0f, 0.0f))), Dc));
+    Tensor out = make(Dgrad->n, Dgrad->needs_grad || mu->needs_grad || Dc->needs_grad);
+    if (failed) return out;
+    const size_t n4 = Dgrad->n / 4;
+    hipLaunchKernelGGL(k_d_step, dim3(nblocks(n4, 256, 1024)), dim3(256), 0, st, Dgrad->v, mu->v, Dc->v, n4, out->v);
+    if (recording && out->needs_grad)
+        tape.push_back([this, out, Dgrad, mu, Dc, n4]() {
+            if (!out->g) return;
+            int ag = 1, ad = 1;
+            float* dg = Dgrad->needs_grad ? grad_first(Dgrad, ag) : nullptr;
+            float* dd = Dc->needs_grad ? grad_first(Dc, ad) : nullptr;
+            float* dm = mu->needs_grad ? grad(mu) : nullptr;
+            if (failed) return;
+            hipLaunchKernelGGL(k_d_step_bwd, dim3(nblocks(n4, 256, 256)), dim3(256), 0, st, out->g, out->v, Dgrad->v, mu->v, Dc->v, n4, dg, ag, dd, ad, dm);
+        });
+    return out;
+}
+
 Tensor Engine::norml2(Tensor x, int seg) {
     Tensor out = make(x->n, x->needs_grad);
     Tensor nrm = make(x->n / seg, false);

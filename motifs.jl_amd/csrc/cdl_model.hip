@@ -259,8 +259,7 @@ static Tensor forward_loss(motifs_model* m, Graph& gr, bool train) {
         // update_D (:275-290): D_grad = Z'(sumZD + sumYRD + S) + reverse(Y'(...)), only the f_len needed lags
         Tensor sig = gr.synD_plus(ZY, bDc, 1.0f);
         Tensor Dgrad = e.collapseD(e.wgrad(sig, ZY, gr.gD1), G, m->M, m->fl);
-        Tensor ex = e.expo(e.mul(Dgrad, e.lin(sc.mu[t], -1.0f, nullptr, 0.0f, 0.0f)));
-        Dc = e.norm4(e.mul(ex, Dc));
+        Dc = e.d_step(Dgrad, sc.mu[t], Dc);
         gD = G;
         bDc = gr.bankD(Dc, gD);
         // update_F (:292-308)
