@@ -38,11 +38,12 @@ struct motifs_model {
     int o_ls, o_ks, o_lst, o_ost, o_kst, o_pen, o_mu;
     Tensor last_X = nullptr;
     int last_groups = 0;
-    // The forward/backward graph of a step is a fixed sequence of ~500 short launches on fixed arena addresses: from the
-    // second call with the same (mini-batch count, buffers) on it is captured once into a hipGraph and replayed, which
-    // takes the host out of the reference's one-step-per-6-reads schedule (train.jl:40-46; 527 nodes at configs[1], worth
-    // 1.5 % while the small-grid kernels themselves bound the step).  Larger steps hide their launches and stay eager.
-    // MOTIFS_NO_GRAPH=1: always eager.
+    // The forward/backward graph of a step is a fixed sequence of ~350 short launches on fixed arena addresses (527 in round 2):
+    // from the second call with the same (mini-batch count, buffers) on it is captured once into a hipGraph and replayed, which
+    // takes the host out of the reference's one-step-per-6-reads schedule (train.jl:40-46).  A dependent launch is 1.6-2.0 us
+    // replayed against 3.0 us from the stream (tools/ubench/launch_floor.hip); the kernels' own 2-10 us bound the step, so the
+    // replay is worth a percent or two.  Every node is a kernel (see motifs_model_loss_grad_dev).  Steps of more than
+    // graph_max_groups mini-batches hide their launches and stay eager.  MOTIFS_NO_GRAPH=1: always eager.
     struct StepGraph {
         int n_groups = 0;
         const void* codes = nullptr;
