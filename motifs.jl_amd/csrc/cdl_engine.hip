@@ -3866,7 +3866,13 @@ constexpr int MED_BINS = 2048;
 static __host__ __device__ __forceinline__ int med_shift(int pass) { return pass == 0 ? 21 : pass == 1 ? 10 : 0; }
 static __host__ __device__ __forceinline__ int med_bits(int pass) { return pass == 2 ? 10 : 11; }
 
-static __device__ __forceinline__ void med_hist_block(const float* __restrict__ x, int n, const MedState* state, uint32_t* hist, int pass,
+// The workspace of one median_threshold call (zeroed by the caller): three MedState arrays [G] - the select's state before pass
+// 0 (zeros), after pass 0 and after pass 1 - then three histograms [G][2][MED_BINS], one per pass (never re-zeroed, never reused).
+static __host__ __device__ __forceinline__ size_t med_states_bytes(int G) { return (((size_t)3 * G * sizeof(MedState)) + 255) & ~(size_t)255; }
+
+// histogram of digit `pass` over the block's share of group g, for the entries whose higher digits are p0 (ranks' lower middle)
+// and p1 (upper middle); added to hist[g] at the end
+static __device__ __forceinline__ void med_hist_block(const float* __restrict__ x, int n, uint32_t p0, uint32_t p1, uint32_t* hist, int pass,
                                                       uint32_t (*h)[MED_BINS]) {
     const int g = blockIdx.y;
     for (int i = threadIdx.x; i < 2 * MED_BINS; i += 256) (&h[0][0])[i] = 0;
@@ -3874,7 +3880,6 @@ static __device__ __forceinline__ void med_hist_block(const float* __restrict__ 
     const int shift = med_shift(pass);
     const uint32_t dmask = (1u << med_bits(pass)) - 1u;
     const uint32_t mask = pass == 0 ? 0u : (0xffffffffu << (shift + med_bits(pass)));
-    const uint32_t p0 = pass == 0 ? 0u : state[g].pref[0], p1 = pass == 0 ? 0u : state[g].pref[1];
     const float* xs = x + (size_t)g * n;
     // consecutive entries of a lane often share the leading digit: runs are counted in registers, one atomic per run
     uint32_t run_d = 0xffffffffu, run_c = 0;
@@ -3909,13 +3914,12 @@ static __device__ __forceinline__ void med_hist_block(const float* __restrict__ 
     }
 }
 
-// digit choice: the first bin whose running count exceeds k (the last bin if none does); 256 threads x 8 bins.
-// After the last pass (thr != null) also the median itself.
-static __device__ void med_select_block(MedState* state, uint32_t* hist, int pass, int g, float* thr, uint32_t* part, MedState& sst) {
+// One digit choice on a group's histogram h ([MED_BINS] shared by both ranks in pass 0, [2][MED_BINS] later): the first bin whose
+// running count exceeds k (the last bin if none does); 256 threads x 8 bins.  sst (LDS) holds the state before and after;
+// nothing else is written, so every block of the next histogram pass can make the choice for itself.
+static __device__ void med_select_core(MedState& sst, const uint32_t* h, int pass, uint32_t* part) {
     const int tid = threadIdx.x, shift = med_shift(pass);
-    uint32_t* h = hist + (size_t)g * 2 * MED_BINS;
-    if (tid == 0) sst = state[g];
-    __syncthreads();
+    __syncthreads();                                // sst as the caller left it is visible
     for (int sel = 0; sel < 2; sel++) {
         const uint32_t* hh = h + (pass == 0 ? 0 : sel * MED_BINS);
         uint32_t loc[8], sum = 0;
@@ -3960,54 +3964,65 @@ static __device__ void med_select_block(MedState* state, uint32_t* hist, int pas
         }
         __syncthreads();
     }
-    if (tid == 0) {
-        state[g] = sst;
-        if (thr) {                                     // after the last pass: the median itself
-            float med = -INFINITY;                     // no positive entry: everything passes
-            if (sst.cnt) {
-                const float lo = __uint_as_float(sst.pref[0]), hi = __uint_as_float(sst.pref[1]);
-                med = (sst.cnt & 1u) ? lo : lo / 2 + hi / 2;
-            }
-            thr[g] = med;
-        }
-    }
-    for (int i = tid; i < 2 * MED_BINS; i += 256) h[i] = 0;   // ready for the next pass
 }
-__global__ __launch_bounds__(256) void k_med_select(MedState* state, uint32_t* hist, int pass, float* thr) {
+
+// pass 0 on its own (when the kernel that wrote the codes did not count their top digits on the way)
+__global__ __launch_bounds__(256) void k_med_hist0(const float* __restrict__ x, int n, uint32_t* hist0) {
+    __shared__ uint32_t h[2][MED_BINS];
+    med_hist_block(x, n, 0u, 0u, hist0, 0, h);
+}
+// Passes 1 and 2: every block first makes the digit choice of the pass before from that pass's (complete) histogram - the
+// choice used to be a launch of its own between two histogram launches, five launches per median - then counts its share of
+// the group.  Block 0 leaves the state for the next launch.
+__global__ __launch_bounds__(256) void k_med_pass(const float* __restrict__ x, int n, const MedState* st_in, const uint32_t* hist_prev,
+                                                  uint32_t* hist_cur, int pass, MedState* st_out) {
+    __shared__ uint32_t h[2][MED_BINS];
     __shared__ uint32_t part[256];
     __shared__ MedState sst;
-    med_select_block(state, hist, pass, blockIdx.x, thr, part, sst);
+    const int g = blockIdx.y;
+    if (threadIdx.x == 0) sst = st_in[g];
+    med_select_core(sst, hist_prev + (size_t)g * 2 * MED_BINS, pass - 1, part);
+    const uint32_t p0 = sst.pref[0], p1 = sst.pref[1];
+    if (blockIdx.x == 0 && threadIdx.x == 0) st_out[g] = sst;
+    med_hist_block(x, n, p0, p1, hist_cur, pass, h);
 }
-
-__global__ __launch_bounds__(256) void k_med_hist(const float* __restrict__ x, int n, const MedState* state, uint32_t* hist, int pass) {
-    __shared__ uint32_t h[2][MED_BINS];
-    med_hist_block(x, n, state, hist, pass, h);
-}
-
-// (A pass as ONE launch - every block takes a ticket after its atomics and the block that draws the last one makes the digit
-// choice - was measured and lost: the fence in front of the ticket is an L2 write-back per block; 17.5 us per pass against
-// 7 + 5 for the two launches at one mini-batch, 420 us against 39 at 64.)
-
-static_assert(MED_BINS == ZH_BINS, "the fused first pass (zy_step kernels) fills the same histogram");
-uint32_t* median_hist_ptr(void* workspace, int G) {
-    return (uint32_t*)((char*)workspace + (((size_t)G * sizeof(MedState) + 255) & ~(size_t)255));
-}
-void median_threshold(hipStream_t st, const float* ZY, float* thr, int G, int n_per_group, void* workspace, bool have_pass0) {
-    MedState* state = (MedState*)workspace;
-    uint32_t* hist = median_hist_ptr(workspace, G);
-    // blocks per group: 64 when the groups fill the chip, up to 256 for a step of few mini-batches
-    const unsigned nb = (unsigned)std::min<size_t>((n_per_group + 256 * 16 - 1) / (256 * 16), G >= 4 ? 64 : 256);
-    for (int pass = 0; pass < 3; pass++) {            // the workspace arrives zeroed (Engine::zeros)
-        float* out = pass == 2 ? thr : nullptr;
-        if (pass == 0 && have_pass0) {                // the kernel that wrote the codes has counted the top digits already
-            hipLaunchKernelGGL(k_med_select, dim3(G), dim3(256), 0, st, state, hist, pass, out);
-        } else {
-            hipLaunchKernelGGL(k_med_hist, dim3(nb, G), dim3(256), 0, st, ZY, n_per_group, state, hist, pass);
-            hipLaunchKernelGGL(k_med_select, dim3(G), dim3(256), 0, st, state, hist, pass, out);
+// the last digit choice and the median itself
+__global__ __launch_bounds__(256) void k_med_final(const MedState* st_in, const uint32_t* hist2, float* thr) {
+    __shared__ uint32_t part[256];
+    __shared__ MedState sst;
+    const int g = blockIdx.x;
+    if (threadIdx.x == 0) sst = st_in[g];
+    med_select_core(sst, hist2 + (size_t)g * 2 * MED_BINS, 2, part);
+    if (threadIdx.x == 0) {
+        float med = -INFINITY;                         // no positive entry: everything passes
+        if (sst.cnt) {
+            const float lo = __uint_as_float(sst.pref[0]), hi = __uint_as_float(sst.pref[1]);
+            med = (sst.cnt & 1u) ? lo : lo / 2 + hi / 2;
         }
+        thr[g] = med;
     }
 }
-size_t median_workspace_bytes(int G) { return (((size_t)G * sizeof(MedState) + 255) & ~(size_t)255) + (size_t)G * 2 * MED_BINS * 4; }
+
+// (A pass as ONE launch with the choice AFTER the counts - every block takes a ticket after its atomics and the block that draws
+// the last one makes the digit choice - was measured and lost: the fence in front of the ticket is an L2 write-back per block;
+// 17.5 us per pass against 7 + 5 for the two launches at one mini-batch, 420 us against 39 at 64.)
+
+static_assert(MED_BINS == ZH_BINS, "the fused first pass (zy_step kernels) fills the same histogram");
+uint32_t* median_hist_ptr(void* workspace, int G) { return (uint32_t*)((char*)workspace + med_states_bytes(G)); }   // the pass-0 histogram
+void median_threshold(hipStream_t st, const float* ZY, float* thr, int G, int n_per_group, void* workspace, bool have_pass0) {
+    MedState* s0 = (MedState*)workspace;               // the workspace arrives zeroed (Engine::zeros)
+    MedState *s1 = s0 + G, *s2 = s1 + G;
+    const size_t hsz = (size_t)G * 2 * MED_BINS;
+    uint32_t* h0 = median_hist_ptr(workspace, G);
+    uint32_t *h1 = h0 + hsz, *h2 = h1 + hsz;
+    // blocks per group: 64 when the groups fill the chip, up to 256 for a step of few mini-batches
+    const unsigned nb = (unsigned)std::min<size_t>((n_per_group + 256 * 16 - 1) / (256 * 16), G >= 4 ? 64 : 256);
+    if (!have_pass0) hipLaunchKernelGGL(k_med_hist0, dim3(nb, G), dim3(256), 0, st, ZY, n_per_group, h0);   // else: counted by the kernel that wrote the codes
+    hipLaunchKernelGGL(k_med_pass, dim3(nb, G), dim3(256), 0, st, ZY, n_per_group, s0, h0, h1, 1, s1);
+    hipLaunchKernelGGL(k_med_pass, dim3(nb, G), dim3(256), 0, st, ZY, n_per_group, s1, h1, h2, 2, s2);
+    hipLaunchKernelGGL(k_med_final, dim3(G), dim3(256), 0, st, s2, h2, thr);
+}
+size_t median_workspace_bytes(int G) { return med_states_bytes(G) + (size_t)3 * G * 2 * MED_BINS * 4; }
 
 __global__ void k_onehot(const uint8_t* codes, int pitch, float* S, int nseq, int L) {
     const size_t total = (size_t)nseq * L;
