@@ -2968,6 +2968,101 @@ Tensor Engine::collapseD(Tensor GA, int g, int M, int fl) {
     return out;
 }
 
+// The D bank in every layout its consumers ask for, in one launch (expandD, flipT, k_tall_bt, k_frag_b16 and k_frag_bw were five
+// launches per bank and four banks per step): every output element is one element of D,
+//   an[(k,a)][j]   = da(4k + a, j)                      da(q, j) = j < M ? D[j][q] : D[j - M][4 fl - 1 - q]     (expandD)
+//   syn[ip][x][y]  = da(4 (fl-1-ip) + y, x)             (flipT of an viewed [fl][4][2M])
+//   Bt[j][ip][n]   = da(4 (fl-1-ip) + n, j)             (k_tall_bt of syn viewed [fl][2M][4])
+//   Bf16[ks][l][cb] = Bt'[4 ks + (l >> 4)][16 cb + (l & 15)]    (k_frag_b16 of Bt viewed [2M][4 fl], columns clamped / zero)
+//   Bfw[ct][kg][l][u] = an[8 kg + 2 u + (l >> 5)][32 ct + (l & 31)]   (k_frag_bw of an, columns clamped)
+__global__ void k_bankD(const float* __restrict__ D, int g, int M, int fl, float* __restrict__ an, float* __restrict__ syn, float* __restrict__ Bt,
+                        float* __restrict__ Bf16, float* __restrict__ Bfw) {
+    const int Q = 4 * fl, N2 = 2 * M, KG = Q / 8, NCT = (N2 + 31) / 32;
+    const size_t per = (size_t)Q * N2, per16 = (size_t)(N2 / 4) * 256, perw = (size_t)NCT * KG * 256;
+    const size_t tot_bank = 3 * per + per16 + perw, total = tot_bank * g;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t gg = i / tot_bank;
+        size_t r = i - gg * tot_bank;
+        const float* Dg = D + gg * (size_t)M * Q;
+        auto da = [&](int q, int j) { return j < M ? Dg[(size_t)j * Q + q] : Dg[(size_t)(j - M) * Q + (Q - 1 - q)]; };
+        if (r < per) {                                              // an [Q][2M]
+            an[gg * per + r] = da((int)(r / N2), (int)(r % N2));
+        } else if ((r -= per) < per) {                              // syn [fl][2M][4]
+            const int y = (int)(r % 4), x = (int)((r / 4) % N2), ip = (int)(r / ((size_t)4 * N2));
+            syn[gg * per + r] = da(4 * (fl - 1 - ip) + y, x);
+        } else if ((r -= per) < per) {                              // Bt [2M][fl][4]
+            const int n = (int)(r % 4), ip = (int)((r / 4) % fl), j = (int)(r / ((size_t)4 * fl));
+            Bt[gg * per + r] = da(4 * (fl - 1 - ip) + n, j);
+        } else if ((r -= per) < per16) {                            // Bf16 [2M/4][64][4]
+            const int cb = (int)(r & 3), lane = (int)((r >> 2) & 63);
+            const int qq = 4 * (int)(r >> 8) + (lane >> 4);
+            float v = 0.0f;
+            if (16 * cb < Q) {
+                const int c = min(16 * cb + (lane & 15), Q - 1);
+                v = da(4 * (fl - 1 - c / 4) + (c & 3), qq);
+            }
+            Bf16[gg * per16 + r] = v;
+        } else {                                                    // Bfw [NCT][KG][64][4]
+            r -= per16;
+            const int u = (int)(r & 3), lane = (int)((r >> 2) & 63);
+            const int kg = (int)((r >> 8) % KG), ct = (int)((r >> 8) / KG);
+            Bfw[gg * perw + r] = da(8 * kg + 2 * u + (lane >> 5), min(32 * ct + (lane & 31), N2 - 1));
+        }
+    }
+}
+// its VJP: d D[j][q] (+)= g(q, j) + g(4 fl - 1 - q, M + j),  g(q, x) = d an[q][x] + d syn[fl - 1 - q/4][x][q%4]  (either may be absent)
+__global__ void k_bankD_bwd(const float* __restrict__ dan, const float* __restrict__ dsyn, int g, int M, int fl, float* __restrict__ dD, int acc) {
+    const int Q = 4 * fl, N2 = 2 * M;
+    const size_t per = (size_t)Q * N2, total = (size_t)g * M * Q;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int q = (int)(i % Q);
+        const size_t t = i / Q;
+        const int j = (int)(t % M);
+        const size_t gg = t / M;
+        auto gq = [&](int qq, int x) {
+            float v = 0.0f;
+            if (dan) v += dan[gg * per + (size_t)qq * N2 + x];
+            if (dsyn) v += dsyn[gg * per + ((size_t)(fl - 1 - qq / 4) * N2 + x) * 4 + (qq & 3)];
+            return v;
+        };
+        const float v = gq(q, j) + gq(Q - 1 - q, M + j);
+        dD[i] = acc ? dD[i] + v : v;
+    }
+}
+std::pair<Tensor, Tensor> Engine::bankD(Tensor D, int g, int M, int fl) {
+    static const bool off = getenv("MOTIFS_NO_BANK_FUSION") != nullptr;
+    const int Q = 4 * fl, N2 = 2 * M;
+    if (off || (fl & 1) || (N2 & 3)) {
+        Tensor DA = expandD(D, g, M, fl);
+        return {DA, flipT(DA, g, fl, 4, N2)};
+    }
+    const size_t per = (size_t)Q * N2, per16 = (size_t)(N2 / 4) * 256, perw = (size_t)((N2 + 31) / 32) * (Q / 8) * 256;
+    Tensor an = make(per * g, D->needs_grad), syn = make(per * g, D->needs_grad);
+    float* Bt = arena.alloc(per * g);
+    float* Bf16 = arena.alloc(per16 * g);
+    float* Bfw = arena.alloc(perw * g);
+    if (failed || !Bt || !Bf16 || !Bfw) {
+        failed = true;
+        return {an, syn};
+    }
+    hipLaunchKernelGGL(k_bankD, dim3(nblocks((3 * per + per16 + perw) * g)), dim3(256), 0, st, D->v, g, M, fl, an->v, syn->v, Bt, Bf16, Bfw);
+    // the re-layouts the consumers will ask for (launch_toep's tall form on syn, launch_rowgemm_lds / k_tall_fused on its Bt,
+    // launch_toep_wide on an), and the two forms as each other's flip (toep_adjoint_a)
+    derived[RelayoutKey{(const void*)syn->v, 4, N2, 4, fl, per * g}] = Bt;
+    derived[RelayoutKey{(const void*)Bt, 2, N2, Q, 0, per16 * g}] = Bf16;
+    derived[RelayoutKey{(const void*)an->v, 3, Q, N2, 0, perw * g}] = Bfw;
+    derived[RelayoutKey{(const void*)syn->v, 5, N2, 4, fl, per * g}] = an->v;
+    derived[RelayoutKey{(const void*)an->v, 5, 4, N2, fl, per * g}] = syn->v;
+    if (recording && D->needs_grad)
+        tape.push_back([this, an, syn, D, g, M, fl]() {
+            if (!an->g && !syn->g) return;
+            int acc;
+            float* dx = grad_first(D, acc);
+            if (dx) EW(k_bankD_bwd, D->n, an->g, syn->g, g, M, fl, dx, acc);
+        });
+    return {an, syn};
+}
+
 // per group [d0][d1][d2] -> [d2][d1][d0]
 __global__ void k_swap02(const float* x, int g, int d0, int d1, int d2, float* out, int acc) {
     const size_t per = (size_t)d0 * d1 * d2, total = per * g;

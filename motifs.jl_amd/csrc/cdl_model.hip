@@ -118,18 +118,9 @@ struct Graph {
     SpDims spd(int g) const {
         return SpDims{S, m->B, m->l, m->K, m->c, m->twoM, m->h, g == 1 ? 0 : (int64_t)m->h * m->twoM * m->K};
     }
-    Bank bankD(Tensor D, int g) {   // D [g][M][4fl]
-        Tensor DA = e.expandD(D, g, m->M, m->fl);
-        Tensor syn = e.flipT(DA, g, m->fl, 4, m->twoM);
-        // The two forms are each other's flipT, which is what the adjoint of a convolution with one of them asks the engine
-        // for (toep_adjoint_a): told so, it takes the partner - and the fragment re-layouts the forward pass made of it -
-        // instead of flipping and re-laying-out again (4 banks per step, ~20 small launches)
-        if (!e.failed) {
-            const size_t n = DA->n;
-            e.derived[Engine::RelayoutKey{(const void*)syn->v, 5, m->twoM, 4, m->fl, n}] = DA->v;
-            e.derived[Engine::RelayoutKey{(const void*)DA->v, 5, 4, m->twoM, m->fl, n}] = syn->v;
-        }
-        return Bank{DA, syn, D, g};
+    Bank bankD(Tensor D, int g) {   // D [g][M][4fl]: both forms and the re-layouts their consumers ask for, in one launch
+        auto b = e.bankD(D, g, m->M, m->fl);
+        return Bank{b.first, b.second, D, g};
     }
     Bank bankF(Tensor F, int g) {   // F [g][K][2M][h]
         Tensor FA = e.swap02(F, g, m->K, m->twoM, m->h);
