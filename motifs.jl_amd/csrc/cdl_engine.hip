@@ -3063,6 +3063,50 @@ std::pair<Tensor, Tensor> Engine::bankD(Tensor D, int g, int M, int fl) {
     return {an, syn};
 }
 
+// The F bank (reference layout F[g][K][2M][h]) in its two GEMM forms in one launch (swap02 then flipT were two):
+//   FA[i][j][k] = F[k][j][i]        syn[ip][k][j] = FA[h-1-ip][j][k] = F[k][j][h-1-ip]
+// Threads walk F in memory order; both outputs leave as K-strided pieces (the bank is 115 200 floats at configs[1]).
+__global__ void k_bankF(const float* __restrict__ F, int g, int K, int N2, int h, float* __restrict__ FA, float* __restrict__ syn) {
+    const size_t per = (size_t)K * N2 * h, total = per * g;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t gg = i / per, r = i - gg * per;
+        const int ii = (int)(r % h), j = (int)((r / h) % N2), k = (int)(r / ((size_t)h * N2));
+        const float v = F[i];
+        FA[gg * per + ((size_t)ii * N2 + j) * K + k] = v;
+        syn[gg * per + ((size_t)(h - 1 - ii) * K + k) * N2 + j] = v;
+    }
+}
+// d F[k][j][i] (+)= d FA[i][j][k] + d syn[h-1-i][k][j]   (either may be absent)
+__global__ void k_bankF_bwd(const float* __restrict__ dFA, const float* __restrict__ dsyn, int g, int K, int N2, int h, float* __restrict__ dF, int acc) {
+    const size_t per = (size_t)K * N2 * h, total = per * g;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t gg = i / per, r = i - gg * per;
+        const int ii = (int)(r % h), j = (int)((r / h) % N2), k = (int)(r / ((size_t)h * N2));
+        float v = 0.0f;
+        if (dFA) v += dFA[gg * per + ((size_t)ii * N2 + j) * K + k];
+        if (dsyn) v += dsyn[gg * per + ((size_t)(h - 1 - ii) * K + k) * N2 + j];
+        dF[i] = acc ? dF[i] + v : v;
+    }
+}
+std::pair<Tensor, Tensor> Engine::bankF(Tensor F, int g, int K, int N2, int h) {
+    static const bool off = getenv("MOTIFS_NO_BANK_FUSION") != nullptr;
+    if (off || F->n > ((size_t)1 << 20)) {              // a bank per mini-batch of a large step: the tiled transposes (13.07 against 13.18 ms at 64)
+        Tensor FA = swap02(F, g, K, N2, h);
+        return {FA, flipT(FA, g, h, N2, K)};
+    }
+    Tensor FA = make(F->n, F->needs_grad), syn = make(F->n, F->needs_grad);
+    if (failed) return {FA, syn};
+    EW(k_bankF, F->n, F->v, g, K, N2, h, FA->v, syn->v);
+    if (recording && F->needs_grad)
+        tape.push_back([this, FA, syn, F, g, K, N2, h]() {
+            if (!FA->g && !syn->g) return;
+            int acc;
+            float* dx = grad_first(F, acc);
+            if (dx) EW(k_bankF_bwd, F->n, FA->g, syn->g, g, K, N2, h, dx, acc);
+        });
+    return {FA, syn};
+}
+
 // per group [d0][d1][d2] -> [d2][d1][d0]
 __global__ void k_swap02(const float* x, int g, int d0, int d1, int d2, float* out, int acc) {
     const size_t per = (size_t)d0 * d1 * d2, total = per * g;

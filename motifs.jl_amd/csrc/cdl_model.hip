@@ -122,9 +122,9 @@ struct Graph {
         auto b = e.bankD(D, g, m->M, m->fl);
         return Bank{b.first, b.second, D, g};
     }
-    Bank bankF(Tensor F, int g) {   // F [g][K][2M][h]
-        Tensor FA = e.swap02(F, g, m->K, m->twoM, m->h);
-        return Bank{FA, e.flipT(FA, g, m->h, m->twoM, m->K), F, g};
+    Bank bankF(Tensor F, int g) {   // F [g][K][2M][h]: both forms in one launch
+        auto b = e.bankF(F, g, m->K, m->twoM, m->h);
+        return Bank{b.first, b.second, F, g};
     }
     Tensor synD(Tensor ZY, const Bank& b) { return e.toep(ZY, b.syn, with(gD2, b.g)); }     // sum_m conv(Z,D)+conv(Y,D,flipped)
     Tensor synD_plus(Tensor ZY, const Bank& b, float sgn) { return e.toep_plus(ZY, b.syn, with(gD2, b.g), Sone, sgn); }   // ... + sgn * S in the same pass
