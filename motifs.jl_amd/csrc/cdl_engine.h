@@ -158,7 +158,8 @@ struct Engine {
     Tensor x_project(Tensor X, Tensor xg, Tensor ost, int S, int q);
     std::pair<Tensor, Tensor> bankD(Tensor D, int g, int M, int fl);       // (analysis form, flipped synthesis form) of a D bank + their fragment re-layouts
     std::pair<Tensor, Tensor> bankF(Tensor F, int g, int K, int N2, int h);   // (analysis form [h][2M][K], flipped synthesis form [h][K][2M]) of an F bank
-    Tensor d_step(Tensor Dgrad, Tensor mu, Tensor Dc);                     // norm4(exp(-mu * Dgrad) .* Dc), model.jl:285-289
+    // norm4(exp(-mu * Dgrad) .* Dc), model.jl:285-289; M > 0: Dgrad is the expanded gradient [g][4 fl][2M], collapsed on the way in
+    Tensor d_step(Tensor Dgrad, Tensor mu, Tensor Dc, int g = 1, int M = 0, int fl = 0);
     Tensor toep_plus(Tensor A, Tensor Bm, const ToepGeom& gm, Tensor y, float b);   // toep(A, Bm) + b * y, y a constant image
     // the same product when A is the one-hot image of `codes` (rows of `pitch` bytes, 0..3, 4 = all-zero column) and the windows
     // advance by whole positions (gm.sa == 4): the forward is fl gathered bank rows per output row, no GEMM; the backward is toep's

@@ -908,25 +908,55 @@ Tensor Engine::norm4(Tensor x) {
 
 // update_D's multiplicative step in one pass (model.jl:285-289): out = norm4(exp(-mu * Dgrad) .* Dc), four bases at a time,
 // with the arithmetic of the five launches it replaces (lin, mul, exp, mul, norm4) and one kernel for their five VJPs.
-__global__ void k_d_step(const float* __restrict__ g, const float* __restrict__ mu, const float* __restrict__ Dc, size_t n4, float* __restrict__ out) {
+// GA (M > 0): Dgrad is read as collapseD of the expanded gradient GA[g][4 fl][2M] it comes from,
+//   Dgrad[g][m][ka] = GA[g][ka][m] + GA[g][4 fl - 1 - ka][M + m],
+// and its gradient is written back the same way (collapseD and its VJP were launches of their own).
+template <bool GA>
+static __device__ __forceinline__ void d_step_load(const float* g, size_t i, int M, int fl, float (&gv)[4], size_t (&at)[2][4]) {
+    if (!GA) {
+        const float4 v = ((const float4*)g)[i];
+        gv[0] = v.x, gv[1] = v.y, gv[2] = v.z, gv[3] = v.w;
+        return;
+    }
+    const int Q = 4 * fl;
+    const size_t e = 4 * i, perD = (size_t)M * Q, gg = e / perD, r = e - gg * perD;
+    const int m = (int)(r / Q), ka0 = (int)(r - (size_t)m * Q);
+    const size_t base = gg * (size_t)Q * 2 * M;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        at[0][u] = base + (size_t)(ka0 + u) * 2 * M + m;
+        at[1][u] = base + (size_t)(Q - 1 - ka0 - u) * 2 * M + M + m;
+        gv[u] = g[at[0][u]] + g[at[1][u]];
+    }
+}
+template <bool GA>
+__global__ void k_d_step(const float* __restrict__ g, const float* __restrict__ mu, const float* __restrict__ Dc, size_t n4, float* __restrict__ out, int M,
+                         int fl) {
     const float neg = -1.0f * *mu;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-        const float4 gv = ((const float4*)g)[i], dc = ((const float4*)Dc)[i];
+        float gv[4];
+        size_t at[2][4];
+        d_step_load<GA>(g, i, M, fl, gv, at);
+        const float4 dc = ((const float4*)Dc)[i];
         float4 q;
-        q.x = expf(gv.x * neg) * dc.x, q.y = expf(gv.y * neg) * dc.y, q.z = expf(gv.z * neg) * dc.z, q.w = expf(gv.w * neg) * dc.w;
+        q.x = expf(gv[0] * neg) * dc.x, q.y = expf(gv[1] * neg) * dc.y, q.z = expf(gv[2] * neg) * dc.z, q.w = expf(gv[3] * neg) * dc.w;
         const float s = q.x + q.y + q.z + q.w;
         ((float4*)out)[i] = make_float4(q.x / s, q.y / s, q.z / s, q.w / s);
     }
 }
 // go = d out.  dq = (go - <go, out>) / s;  d Dc (+)= dq .* ex;  d Dgrad (+)= -mu * dq .* q;  d mu -= sum(dq .* q .* Dgrad)
+template <bool GA>
 __global__ void k_d_step_bwd(const float* __restrict__ go, const float* __restrict__ out, const float* __restrict__ g, const float* __restrict__ mu,
-                             const float* __restrict__ Dc, size_t n4, float* dg, int ag, float* dDc, int aDc, float* dmu) {
+                             const float* __restrict__ Dc, size_t n4, float* dg, int ag, float* dDc, int aDc, float* dmu, int M, int fl) {
     const float neg = -1.0f * *mu;
     double sm = 0;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-        const float4 gv = ((const float4*)g)[i], dc = ((const float4*)Dc)[i], o = ((const float4*)out)[i], gq = ((const float4*)go)[i];
-        const float ex[4] = {expf(gv.x * neg), expf(gv.y * neg), expf(gv.z * neg), expf(gv.w * neg)};
-        const float dcv[4] = {dc.x, dc.y, dc.z, dc.w}, gg[4] = {gv.x, gv.y, gv.z, gv.w}, ov[4] = {o.x, o.y, o.z, o.w}, gov[4] = {gq.x, gq.y, gq.z, gq.w};
+        float gg[4];
+        size_t at[2][4];
+        d_step_load<GA>(g, i, M, fl, gg, at);
+        const float4 dc = ((const float4*)Dc)[i], o = ((const float4*)out)[i], gq = ((const float4*)go)[i];
+        const float ex[4] = {expf(gg[0] * neg), expf(gg[1] * neg), expf(gg[2] * neg), expf(gg[3] * neg)};
+        const float dcv[4] = {dc.x, dc.y, dc.z, dc.w}, ov[4] = {o.x, o.y, o.z, o.w}, gov[4] = {gq.x, gq.y, gq.z, gq.w};
         const float s = (ex[0] * dcv[0] + ex[1] * dcv[1]) + ex[2] * dcv[2] + ex[3] * dcv[3];
         const float dot = gov[0] * ov[0] + gov[1] * ov[1] + gov[2] * ov[2] + gov[3] * ov[3];
         float ddc[4], ddg[4];
@@ -942,9 +972,16 @@ __global__ void k_d_step_bwd(const float* __restrict__ go, const float* __restri
             float4 t = aDc ? ((float4*)dDc)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
             ((float4*)dDc)[i] = make_float4(t.x + ddc[0], t.y + ddc[1], t.z + ddc[2], t.w + ddc[3]);
         }
-        if (dg) {
+        if (dg && !GA) {
             float4 t = ag ? ((float4*)dg)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
             ((float4*)dg)[i] = make_float4(t.x + ddg[0], t.y + ddg[1], t.z + ddg[2], t.w + ddg[3]);
+        }
+        if (dg && GA) {                                            // every element of d GA is one of these: expandD of d Dgrad
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                dg[at[0][u]] = (ag ? dg[at[0][u]] : 0.0f) + ddg[u];
+                dg[at[1][u]] = (ag ? dg[at[1][u]] : 0.0f) + ddg[u];
+            }
         }
     }
     if (!dmu) return;
@@ -954,24 +991,33 @@ __global__ void k_d_step_bwd(const float* __restrict__ go, const float* __restri
     __syncthreads();
     if (threadIdx.x == 0) atomicAdd(dmu, -(float)(red[0] + red[1] + red[2] + red[3]));      // d(-mu) = sum: d mu = -sum
 }
-Tensor Engine::d_step(Tensor Dgrad, Tensor mu, Tensor Dc) {
+// Dgrad: [g][M][4 fl], or with M > 0 the expanded gradient GA [g][4 fl][2M] it is the collapseD of
+Tensor Engine::d_step(Tensor Dgrad, Tensor mu, Tensor Dc, int g, int M, int fl) {
     static const bool off = getenv("MOTIFS_NO_D_STEP") != nullptr;
     auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
-    if (off || Dc->n != Dgrad->n || (Dgrad->n & 3) || !al16(Dgrad->v) || !al16(Dc->v))   // a bank shared by the mini-batches: the separate launches
-        return norm4(mul(expo(mul(Dgrad, lin(mu, -1.0f, nullptr, 0.0f, 0.0f))), Dc));
-    Tensor out = make(Dgrad->n, Dgrad->needs_grad || mu->needs_grad || Dc->needs_grad);
+    const bool ga = M > 0;
+    const size_t n = ga ? Dgrad->n / 2 : Dgrad->n;
+    if (off || Dc->n != n || (n & 3) || !al16(Dgrad->v) || !al16(Dc->v)) {   // a bank shared by the mini-batches: the separate launches
+        Tensor Dg = ga ? collapseD(Dgrad, g, M, fl) : Dgrad;
+        return norm4(mul(expo(mul(Dg, lin(mu, -1.0f, nullptr, 0.0f, 0.0f))), Dc));
+    }
+    Tensor out = make(n, Dgrad->needs_grad || mu->needs_grad || Dc->needs_grad);
     if (failed) return out;
-    const size_t n4 = Dgrad->n / 4;
-    hipLaunchKernelGGL(k_d_step, dim3(nblocks(n4, 256, 1024)), dim3(256), 0, st, Dgrad->v, mu->v, Dc->v, n4, out->v);
+    const size_t n4 = n / 4;
+    if (ga) hipLaunchKernelGGL(k_d_step<true>, dim3(nblocks(n4, 256, 1024)), dim3(256), 0, st, Dgrad->v, mu->v, Dc->v, n4, out->v, M, fl);
+    else hipLaunchKernelGGL(k_d_step<false>, dim3(nblocks(n4, 256, 1024)), dim3(256), 0, st, Dgrad->v, mu->v, Dc->v, n4, out->v, 0, 0);
     if (recording && out->needs_grad)
-        tape.push_back([this, out, Dgrad, mu, Dc, n4]() {
+        tape.push_back([this, out, Dgrad, mu, Dc, n4, ga, M, fl]() {
             if (!out->g) return;
             int ag = 1, ad = 1;
             float* dg = Dgrad->needs_grad ? grad_first(Dgrad, ag) : nullptr;
             float* dd = Dc->needs_grad ? grad_first(Dc, ad) : nullptr;
             float* dm = mu->needs_grad ? grad(mu) : nullptr;
             if (failed) return;
-            hipLaunchKernelGGL(k_d_step_bwd, dim3(nblocks(n4, 256, 256)), dim3(256), 0, st, out->g, out->v, Dgrad->v, mu->v, Dc->v, n4, dg, ag, dd, ad, dm);
+            if (ga)
+                hipLaunchKernelGGL(k_d_step_bwd<true>, dim3(nblocks(n4, 256, 256)), dim3(256), 0, st, out->g, out->v, Dgrad->v, mu->v, Dc->v, n4, dg, ag, dd, ad, dm, M, fl);
+            else
+                hipLaunchKernelGGL(k_d_step_bwd<false>, dim3(nblocks(n4, 256, 256)), dim3(256), 0, st, out->g, out->v, Dgrad->v, mu->v, Dc->v, n4, dg, ag, dd, ad, dm, 0, 0);
         });
     return out;
 }

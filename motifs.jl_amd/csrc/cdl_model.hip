@@ -250,8 +250,7 @@ static Tensor forward_loss(motifs_model* m, Graph& gr, bool train) {
     for (int t = 0; t < P; t++) {
         // update_D (:275-290): D_grad = Z'(sumZD + sumYRD + S) + reverse(Y'(...)), only the f_len needed lags
         Tensor sig = gr.synD_plus(ZY, bDc, 1.0f);
-        Tensor Dgrad = e.collapseD(e.wgrad(sig, ZY, gr.gD1), G, m->M, m->fl);
-        Dc = e.d_step(Dgrad, sc.mu[t], Dc);
+        Dc = e.d_step(e.wgrad(sig, ZY, gr.gD1), sc.mu[t], Dc, G, m->M, m->fl);     // collapseD of the expanded gradient rides in the step
         gD = G;
         bDc = gr.bankD(Dc, gD);
         // update_F (:292-308)
