@@ -129,6 +129,7 @@ struct Engine {
     void backward();
 
     // ---- primitives (each records its VJP) ----
+    Tensor shrink(Tensor x, float a, float c);                            // relu(a*x + c)
     Tensor lin(Tensor x, float a, Tensor y, float b, float cst);          // a*x + b*y(bcast modulo y.n) + cst
     // a*x + b*(ymask .* y) + c*z in one pass (z, ymask optional; ymask is a constant 0/1 mask)
     Tensor lin3(Tensor x, float a, Tensor y, float b, Tensor z, float c, const float* ythr = nullptr, int groups = 1);   // ythr: y counts where y >= ythr[group]
@@ -152,10 +153,10 @@ struct Engine {
     Tensor norml2(Tensor x, int seg);                                     // x / ||x|| per segment
     Tensor sumsq_groups(Tensor x, float coef, int groups);                // [groups]: coef * sum x^2 per group
     // coef * sum_group (x + b*[y >= thr[group]]*y)^2 without writing the residual
-    Tensor resid_sumsq_groups(Tensor x, Tensor y, float b, const float* thr, float coef, int groups);
+    Tensor resid_sumsq_groups(Tensor x, Tensor y, float b, const float* thr, float coef, int groups, Tensor into = nullptr);
     Tensor toep(Tensor A, Tensor Bm, const ToepGeom& gm, const float* y = nullptr, float yb = 0.0f);   // Toeplitz GEMM (+ yb * y: tall forms only, see toep_plus)
     // project_X(X - ost * xg) (xg == null: project_X(X)), model.jl:253 + :181-192, with the entry lists of the result and of its mask
-    Tensor x_project(Tensor X, Tensor xg, Tensor ost, int S, int q);
+    Tensor x_project(Tensor X, Tensor xg, Tensor ost, int S, int q, float scale = 1.0f);   // scale (xg == null only): project_X(scale * X)
     std::pair<Tensor, Tensor> bankD(Tensor D, int g, int M, int fl);       // (analysis form, flipped synthesis form) of a D bank + their fragment re-layouts
     std::pair<Tensor, Tensor> bankF(Tensor F, int g, int K, int N2, int h);   // (analysis form [h][2M][K], flipped synthesis form [h][K][2M]) of an F bank
     // norm4(exp(-mu * Dgrad) .* Dc), model.jl:285-289; M > 0: Dgrad is the expanded gradient [g][4 fl][2M], collapsed on the way in

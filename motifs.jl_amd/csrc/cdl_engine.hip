@@ -659,6 +659,30 @@ Tensor Engine::lin(Tensor x, float a, Tensor y, float b, float cst) {
     return out;
 }
 
+// relu(a * x + c) in one pass (warmup_ZY's shrinkage, model.jl:176-177: a lin and a relu before), with k_lin's arithmetic
+__global__ void k_shrink(const float* x, float a, float c, size_t n, float* out) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float u = a * x[i] + 0.0f + c;
+        out[i] = u > 0.0f ? u : 0.0f;
+    }
+}
+__global__ void k_shrink_bwd(const float* go, const float* out, float a, size_t n, float* dx, int acc) {   // dx (+)= a * [out > 0] * go
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        dx[i] = (acc ? dx[i] : 0.0f) + a * (out[i] > 0.0f ? go[i] : 0.0f);
+}
+Tensor Engine::shrink(Tensor x, float a, float c) {
+    Tensor out = make(x->n, x->needs_grad);
+    if (failed) return out;
+    EW(k_shrink, x->n, x->v, a, c, x->n, out->v);
+    if (recording && out->needs_grad)
+        tape.push_back([this, out, x, a]() {
+            int acc;
+            float* dx = out->g ? grad_first(x, acc) : nullptr;
+            if (dx) EW(k_shrink_bwd, out->n, out->g, out->v, a, out->n, dx, acc);
+        });
+    return out;
+}
+
 Tensor Engine::lin3(Tensor x, float a, Tensor y, float b, Tensor z, float c, const float* ythr, int groups) {
     Tensor out = make(x->n, x->needs_grad || y->needs_grad || (z && z->needs_grad));
     if (failed) return out;
@@ -1035,11 +1059,14 @@ Tensor Engine::norml2(Tensor x, int seg) {
     return out;
 }
 
-Tensor Engine::resid_sumsq_groups(Tensor x, Tensor y, float b, const float* thr, float coef, int groups) {
-    Tensor out = make(groups, x->needs_grad || y->needs_grad);
+// into: the per-group sums are ADDED to an existing [groups] tensor (the two terms of the loss meet in one buffer instead of in
+// a lin of two; its gradient is read by both VJPs)
+Tensor Engine::resid_sumsq_groups(Tensor x, Tensor y, float b, const float* thr, float coef, int groups, Tensor into) {
+    Tensor out = into ? into : make(groups, x->needs_grad || y->needs_grad);
     if (failed) return out;
     const size_t per = x->n / groups;
-    dev_zero(st, out->v, (size_t)groups);
+    if (into) into->needs_grad = into->needs_grad || x->needs_grad || y->needs_grad;
+    else dev_zero(st, out->v, (size_t)groups);
     hipLaunchKernelGGL(k_resid_sumsq, dim3(nblocks(per, 256, 64), groups), dim3(256), 0, st, x->v, y->v, thr, b, per, coef, out->v);
     if (recording && out->needs_grad)
         tape.push_back([this, out, x, y, b, thr, per, coef, groups]() {
@@ -3924,7 +3951,7 @@ void topq_mask(hipStream_t st, const float* X, float* bitmat, int S, int n_per_s
 // their own (k_x_step, k_topq_mask, k_maskmul, k_build_nz twice).  One block per read, Xu staged in LDS.
 __global__ __launch_bounds__(1024) void k_x_project(const float* __restrict__ X, const float* __restrict__ xg, const float* __restrict__ ost, int n,
                                                     int q, float* __restrict__ out, float* __restrict__ bit, int* __restrict__ cnt,
-                                                    uint2* __restrict__ ent, int* __restrict__ mcnt, uint2* __restrict__ ment) {
+                                                    uint2* __restrict__ ent, int* __restrict__ mcnt, uint2* __restrict__ ment, float scale) {
     extern __shared__ float xs[];                  // [n]
     __shared__ uint32_t hist[256];
     __shared__ uint32_t sh[2];
@@ -3932,7 +3959,7 @@ __global__ __launch_bounds__(1024) void k_x_project(const float* __restrict__ X,
     const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nw = blockDim.x >> 6;
     const size_t base = (size_t)s * n;
     const float o = xg ? *ost : 0.0f;
-    for (int i = tid; i < n; i += blockDim.x) xs[i] = xg ? X[base + i] - xg[base + i] * o : X[base + i];
+    for (int i = tid; i < n; i += blockDim.x) xs[i] = xg ? X[base + i] - xg[base + i] * o : (scale == 1.0f ? X[base + i] : scale * X[base + i] + 0.0f + 0.0f);
     __syncthreads();
     const uint32_t key = block_radix_select(xs, n, (uint32_t)(n - q), [](float) { return true; }, hist, sh);
     const float thr = unkey(key);
@@ -3980,12 +4007,12 @@ __global__ __launch_bounds__(1024) void k_x_project(const float* __restrict__ X,
 }
 // VJP: g = bitmat .* d out;  dX (+)= g;  d xg (+)= -ost * g;  d ost += -sum(g .* xg)
 __global__ void k_x_project_bwd(const float* go, const float* bit, const float* xg, const float* ost, size_t n, float* dX, int aX, float* dxg,
-                                int axg, float* dost) {
+                                int axg, float* dost, float scale) {
     const float o = ost ? *ost : 0.0f;
     double so = 0;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const float g = bit[i] * go[i];
-        if (dX) dX[i] = (aX ? dX[i] : 0.0f) + g;
+        if (dX) dX[i] = (aX ? dX[i] : 0.0f) + (scale == 1.0f ? g : scale * g);
         if (dxg) dxg[i] = (axg ? dxg[i] : 0.0f) - o * g;
         if (xg) so -= (double)g * (double)xg[i];
     }
@@ -3997,11 +4024,11 @@ __global__ void k_x_project_bwd(const float* go, const float* bit, const float* 
     if (threadIdx.x == 0) atomicAdd(dost, (float)(red[0] + red[1] + red[2] + red[3]));
 }
 
-Tensor Engine::x_project(Tensor X, Tensor xg, Tensor ost, int S, int q) {
+Tensor Engine::x_project(Tensor X, Tensor xg, Tensor ost, int S, int q, float scale) {
     const int n = (int)(X->n / S);
     static const bool off = getenv("MOTIFS_NO_X_PROJECT") != nullptr;
     if (off || (size_t)n * 4 > ((size_t)48 << 10)) {          // the separate launches
-        Tensor Xu = xg ? x_step(X, xg, ost) : X;
+        Tensor Xu = xg ? x_step(X, xg, ost) : (scale == 1.0f ? X : lin(X, scale, nullptr, 0.0f, 0.0f));
         Tensor bitm = make(Xu->n, false);
         if (failed) return Xu;
         topq_mask(st, Xu->v, bitm->v, S, n, q);
@@ -4020,12 +4047,12 @@ Tensor Engine::x_project(Tensor X, Tensor xg, Tensor ost, int S, int q) {
     int* mc = c + S + 64;
     uint2* men = en + (size_t)S * n;
     hipLaunchKernelGGL(k_x_project, dim3(S), dim3(S >= 256 ? 256 : 1024), (size_t)n * 4, st, X->v, xg ? xg->v : nullptr, xg ? ost->v : nullptr, n, q,
-                       out->v, bitm->v, c, en, mc, men);
+                       out->v, bitm->v, c, en, mc, men, scale);
     out->gmask = bitm->v;          // every gradient into the projected codes passes this mask on its way back
     out->nz_cnt = c, out->nz_ent = en;
     out->gm_cnt = mc, out->gm_ent = men;
     if (recording && out->needs_grad)
-        tape.push_back([this, out, X, xg, ost, bitm]() {
+        tape.push_back([this, out, X, xg, ost, bitm, scale]() {
             if (!out->g) return;
             int a0 = 1, a1 = 1;
             float* d0 = X->needs_grad ? grad_first(X, a0) : nullptr;
@@ -4033,7 +4060,7 @@ Tensor Engine::x_project(Tensor X, Tensor xg, Tensor ost, int S, int q) {
             float* dq = xg && ost->needs_grad ? grad(ost) : nullptr;
             if (failed) return;
             hipLaunchKernelGGL(k_x_project_bwd, dim3(nblocks(out->n, 256, 1024)), dim3(256), 0, st, out->g, bitm->v, xg ? xg->v : nullptr,
-                               xg ? ost->v : nullptr, out->n, d0, a0, d1, a1, dq);
+                               xg ? ost->v : nullptr, out->n, d0, a0, d1, a1, dq, scale);
         });
     return out;
 }

@@ -107,7 +107,7 @@ struct Graph {
         return thr->v;
     }
     // project_X (model.jl:181-192): keep the entries >= the q-th largest of each sequence
-    Tensor project_X(Tensor Xu) { return e.x_project(Xu, nullptr, nullptr, S, m->q); }
+    Tensor project_X(Tensor Xu, float scale = 1.0f) { return e.x_project(Xu, nullptr, nullptr, S, m->q, scale); }   // project_X(scale * Xu)
     // update_X's step and projection in one (:253-254)
     Tensor step_project_X(Tensor X, Tensor xg, Tensor ost) { return e.x_project(X, xg, ost, S, m->q); }
     // the two filter banks in GEMM layout, analysis and (flipped) synthesis form
@@ -174,8 +174,8 @@ static void admm_xyz(motifs_model* m, Graph& gr, const Scalars& sc, const Graph:
     const float lspw = m->warm[0] * m->warm[0], lsw = m->warm[1] * m->warm[1], osw = m->warm[2] * m->warm[2];
     // warm-up (:224-232, :171-179, :212-216)
     Tensor raw = gr.anaD(gr.Sone, bD);                                   // D'S | DS on the aligned rows
-    ZY = e.relu(e.lin(raw, lsw, nullptr, 0.0f, -lspw * lsw));
-    X = gr.project_X(e.lin(gr.anaF(gr.cat_ZY(ZY), bF), osw, nullptr, 0.0f, 0.0f));
+    ZY = e.shrink(raw, lsw, -lspw * lsw);
+    X = gr.project_X(gr.anaF(gr.cat_ZY(ZY), bF), osw);
     Tensor FX = gr.synF(X, bF);
     Tensor ab = nullptr;                                                  // scaled duals alpha|beta, zero at start (:338)
     e.note("ZY0", ZY);
@@ -283,7 +283,7 @@ static Tensor forward_loss(motifs_model* m, Graph& gr, bool train) {
     // loss (:310-325)
     const float nf = 1.0f / (float)m->B;
     Tensor r1 = gr.synD_plus(ZY, bDc, -1.0f);
-    Tensor Lv = e.lin(e.sumsq_groups(r1, nf, G), 1.0f, e.resid_sumsq_groups(FXcur, ZY, zmf, zmt, nf, G), 1.0f, 0.0f);
+    Tensor Lv = e.resid_sumsq_groups(FXcur, ZY, zmf, zmt, nf, G, e.sumsq_groups(r1, nf, G));     // the two terms meet in one buffer
     (void)gD;
     (void)gF;
     return Lv;
