@@ -150,7 +150,8 @@ struct Engine {
     Tensor thrmul(Tensor x, const float* thr, int groups, float c);       // c * [x >= thr[group]] .* x, the selection constant
     Tensor expo(Tensor x);
     Tensor norm4(Tensor x);                                               // x / sum over each 4 consecutive
-    Tensor norml2(Tensor x, int seg);                                     // x / ||x|| per segment
+    Tensor norml2(Tensor x, int seg, bool squared = false);               // per segment x / ||x||_2 (squared: of x .* x)
+    Tensor norm4sq(Tensor x, float eps);                                  // norm4(x .* x + eps)
     Tensor sumsq_groups(Tensor x, float coef, int groups);                // [groups]: coef * sum x^2 per group
     // coef * sum_group (x + b*[y >= thr[group]]*y)^2 without writing the residual
     Tensor resid_sumsq_groups(Tensor x, Tensor y, float b, const float* thr, float coef, int groups, Tensor into = nullptr);

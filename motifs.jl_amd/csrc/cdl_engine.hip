@@ -214,6 +214,26 @@ __global__ void k_exp(const float* x, size_t n, float* out) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         out[i] = expf(x[i]);
 }
+// prep_filters (model.jl:139-146) in one pass: norm4(x .* x + eps) (a mul, a lin and a norm4 before)
+__global__ void k_norm4sq(const float* x, float eps, size_t n4, float* out) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 v = ((const float4*)x)[i];
+        const float4 t = make_float4(1.0f * (v.x * v.x) + 0.0f + eps, 1.0f * (v.y * v.y) + 0.0f + eps, 1.0f * (v.z * v.z) + 0.0f + eps, 1.0f * (v.w * v.w) + 0.0f + eps);
+        const float s = t.x + t.y + t.z + t.w;
+        ((float4*)out)[i] = make_float4(t.x / s, t.y / s, t.z / s, t.w / s);
+    }
+}
+__global__ void k_norm4sq_bwd(const float* go, const float* x, const float* out, float eps, size_t n4, float* dx) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 v = ((const float4*)x)[i], o = ((const float4*)out)[i], g = ((const float4*)go)[i];
+        const float s = (1.0f * (v.x * v.x) + 0.0f + eps) + (1.0f * (v.y * v.y) + 0.0f + eps) + (1.0f * (v.z * v.z) + 0.0f + eps) + (1.0f * (v.w * v.w) + 0.0f + eps);
+        const float dot = g.x * o.x + g.y * o.y + g.z * o.z + g.w * o.w;
+        const float4 dq = make_float4((g.x - dot) / s, (g.y - dot) / s, (g.z - dot) / s, (g.w - dot) / s);
+        float4 d = ((float4*)dx)[i];
+        d.x += dq.x * v.x + dq.x * v.x, d.y += dq.y * v.y + dq.y * v.y, d.z += dq.z * v.z + dq.z * v.z, d.w += dq.w * v.w + dq.w * v.w;
+        ((float4*)dx)[i] = d;
+    }
+}
 __global__ void k_norm4(const float* x, size_t n4, float* out) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         const float4 v = ((const float4*)x)[i];
@@ -235,10 +255,15 @@ __global__ void k_norm4_bwd(const float* go, const float* x, const float* out, s
     }
 }
 // one block per segment
+// SQ: the segment is x .* x (prep_syntax_filters, model.jl:148-151: the square was a launch of its own)
+template <bool SQ>
 __global__ void k_norml2(const float* x, int seg, float* out, float* nrm_out) {
     const float* xs = x + (size_t)blockIdx.x * seg;
     double acc = 0;
-    for (int i = threadIdx.x; i < seg; i += blockDim.x) acc += (double)xs[i] * xs[i];
+    for (int i = threadIdx.x; i < seg; i += blockDim.x) {
+        const float t = SQ ? xs[i] * xs[i] : xs[i];
+        acc += (double)t * t;
+    }
     for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
     __shared__ double red[16];
     __shared__ float nrm;
@@ -251,9 +276,10 @@ __global__ void k_norml2(const float* x, int seg, float* out, float* nrm_out) {
         nrm_out[blockIdx.x] = nrm;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < seg; i += blockDim.x) out[(size_t)blockIdx.x * seg + i] = xs[i] / nrm;
+    for (int i = threadIdx.x; i < seg; i += blockDim.x) out[(size_t)blockIdx.x * seg + i] = (SQ ? xs[i] * xs[i] : xs[i]) / nrm;
 }
-__global__ void k_norml2_bwd(const float* go, const float* out, const float* nrm_in, int seg, float* dx) {
+template <bool SQ>
+__global__ void k_norml2_bwd(const float* go, const float* out, const float* nrm_in, int seg, float* dx, const float* x) {
     const size_t base = (size_t)blockIdx.x * seg;
     double acc = 0;
     for (int i = threadIdx.x; i < seg; i += blockDim.x) acc += (double)go[base + i] * out[base + i];
@@ -269,7 +295,10 @@ __global__ void k_norml2_bwd(const float* go, const float* out, const float* nrm
     }
     __syncthreads();
     const float nrm = nrm_in[blockIdx.x];
-    for (int i = threadIdx.x; i < seg; i += blockDim.x) dx[base + i] += (go[base + i] - out[base + i] * dot) / nrm;
+    for (int i = threadIdx.x; i < seg; i += blockDim.x) {
+        const float dt = (go[base + i] - out[base + i] * dot) / nrm;
+        dx[base + i] += SQ ? dt * x[base + i] + dt * x[base + i] : dt;      // through x .* x: once per factor
+    }
 }
 // out[grp] = coef * sum of squares of the group's slice; one block per (group, chunk) + atomics
 __global__ void k_sumsq_groups(const float* x, size_t per_group, float coef, float* out) {
@@ -1046,15 +1075,35 @@ Tensor Engine::d_step(Tensor Dgrad, Tensor mu, Tensor Dc, int g, int M, int fl) 
     return out;
 }
 
-Tensor Engine::norml2(Tensor x, int seg) {
+Tensor Engine::norm4sq(Tensor x, float eps) {
+    if ((x->n & 3) || (((uintptr_t)x->v) & 15)) return norm4(lin(mul(x, x), 1.0f, nullptr, 0.0f, eps));
+    Tensor out = make(x->n, x->needs_grad);
+    if (failed) return out;
+    EW(k_norm4sq, x->n / 4, x->v, eps, x->n / 4, out->v);
+    if (recording && out->needs_grad)
+        tape.push_back([this, out, x, eps]() {
+            if (out->g) EW(k_norm4sq_bwd, out->n / 4, out->g, x->v, out->v, eps, out->n / 4, grad(x));
+        });
+    return out;
+}
+
+Tensor Engine::norml2(Tensor x, int seg, bool squared) {
     Tensor out = make(x->n, x->needs_grad);
     Tensor nrm = make(x->n / seg, false);
     if (failed) return out;
     const unsigned nseg = (unsigned)(x->n / seg);
-    hipLaunchKernelGGL(k_norml2, dim3(nseg), dim3(nseg >= 256 ? 256 : 1024), 0, st, x->v, seg, out->v, nrm->v);   // few segments: more waves on each
+    if (squared) {
+        hipLaunchKernelGGL(k_norml2<true>, dim3(nseg), dim3(nseg >= 256 ? 256 : 1024), 0, st, x->v, seg, out->v, nrm->v);
+        if (recording && out->needs_grad)
+            tape.push_back([this, out, x, nrm, seg, nseg]() {
+                if (out->g) hipLaunchKernelGGL(k_norml2_bwd<true>, dim3(nseg), dim3(nseg >= 256 ? 256 : 1024), 0, st, out->g, out->v, nrm->v, seg, grad(x), x->v);
+            });
+        return out;
+    }
+    hipLaunchKernelGGL(k_norml2<false>, dim3(nseg), dim3(nseg >= 256 ? 256 : 1024), 0, st, x->v, seg, out->v, nrm->v);   // few segments: more waves on each
     if (recording && out->needs_grad)
         tape.push_back([this, out, x, nrm, seg, nseg]() {
-            if (out->g) hipLaunchKernelGGL(k_norml2_bwd, dim3(nseg), dim3(nseg >= 256 ? 256 : 1024), 0, st, out->g, out->v, nrm->v, seg, grad(x));
+            if (out->g) hipLaunchKernelGGL(k_norml2_bwd<false>, dim3(nseg), dim3(nseg >= 256 ? 256 : 1024), 0, st, out->g, out->v, nrm->v, seg, grad(x), (const float*)nullptr);
         });
     return out;
 }

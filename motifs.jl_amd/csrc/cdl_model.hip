@@ -218,8 +218,8 @@ static Tensor forward_loss(motifs_model* m, Graph& gr, bool train) {
     Tensor Fraw = e.wrap(m->params + m->nD, m->grads + m->nD, m->nF, train);
     Scalars sc = prep_scalars(m, gr, train);
     // prep_filters (:139-146), prep_syntax_filters (:148-151)
-    Tensor Dp = e.norm4(e.lin(gr.sq(Draw), 1.0f, nullptr, 0.0f, 0.001f));
-    Tensor Fp = e.norml2(gr.sq(Fraw), m->h * m->twoM);
+    Tensor Dp = e.norm4sq(Draw, 0.001f);
+    Tensor Fp = e.norml2(Fraw, m->h * m->twoM, true);
     e.note("Dp", Dp);
     e.note("Fp", Fp);
     Graph::Bank bD = gr.bankD(Dp, 1), bF = gr.bankF(Fp, 1);
@@ -808,7 +808,7 @@ int motifs_model_l1_syntax(motifs_model* m, float* out) {
     e.reset();
     e.recording = false;
     Tensor Fraw = e.wrap(m->params + m->nD, nullptr, m->nF, false);
-    Tensor Fp = e.norml2(e.mul(Fraw, Fraw), m->h * m->twoM);
+    Tensor Fp = e.norml2(Fraw, m->h * m->twoM, true);
     Tensor acc = e.make(1, false);
     if (e.failed) return MOTIFS_ERR_UNSUPPORTED;
     MOTIFS_HIP_CHECK(hipMemsetAsync(acc->v, 0, 4, e.st));
@@ -915,8 +915,8 @@ int motifs_model_retrieve_codes(motifs_model* m, const void* data, int kind, int
         gr.codes = (const uint8_t*)c->codes.p;
         Tensor Draw = e.wrap(m->params, nullptr, m->nD, false), Fraw = e.wrap(m->params + m->nD, nullptr, m->nF, false);
         Scalars sc = prep_scalars(m, gr, false);
-        Tensor Dp = e.norm4(e.lin(gr.sq(Draw), 1.0f, nullptr, 0.0f, 0.001f));
-        Tensor Fp = e.norml2(gr.sq(Fraw), m->h * m->twoM);
+        Tensor Dp = e.norm4sq(Draw, 0.001f);
+        Tensor Fp = e.norml2(Fraw, m->h * m->twoM, true);
         Graph::Bank bD = gr.bankD(Dp, 1), bF = gr.bankF(Fp, 1);
         Tensor ZY, X;
         admm_xyz(m, gr, sc, bD, bF, ZY, X);
@@ -979,7 +979,7 @@ int motifs_model_time_filter_scan(motifs_model* m, const uint8_t* codes_dev, int
     gr.Sone = make_onehot(m, codes_dev, gr.S);
     gr.codes = codes_dev;
     Tensor Draw = e.wrap(m->params, nullptr, m->nD, false);
-    Tensor Dp = e.norm4(e.lin(gr.sq(Draw), 1.0f, nullptr, 0.0f, 0.001f));
+    Tensor Dp = e.norm4sq(Draw, 0.001f);
     Graph::Bank bD = gr.bankD(Dp, 1);
     (void)gr.anaD(gr.Sone, bD);                       // warm-up: the bank's fragment re-layout is built here
     const size_t mark = e.arena.off;
@@ -1021,8 +1021,8 @@ int motifs_model_time_syntax_conv(motifs_model* m, const uint8_t* codes_dev, int
     gr.Sone = make_onehot(m, codes_dev, gr.S);
     gr.codes = codes_dev;
     Tensor Draw = e.wrap(m->params, nullptr, m->nD, false), Fraw = e.wrap(m->params + m->nD, nullptr, m->nF, false);
-    Tensor Dp = e.norm4(e.lin(gr.sq(Draw), 1.0f, nullptr, 0.0f, 0.001f));
-    Tensor Fp = e.norml2(gr.sq(Fraw), m->h * m->twoM);
+    Tensor Dp = e.norm4sq(Draw, 0.001f);
+    Tensor Fp = e.norml2(Fraw, m->h * m->twoM, true);
     Graph::Bank bD = gr.bankD(Dp, 1), bF = gr.bankF(Fp, 1);
     Tensor ZY = gr.anaD(gr.Sone, bD);                 // an image of the right shape and scale: [S][c][2M]
     (void)gr.anaF(ZY, bF);                            // warm-up: the bank's fragment re-layout is built here
