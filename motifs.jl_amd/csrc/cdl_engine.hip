@@ -523,24 +523,36 @@ __global__ void k_x_step_bwd(const float* go, const float* xg, const float* ost,
 // (n_c < n); sg = +-1 (the gradient may arrive negated), Fgrad may be absent (identically zero).
 // VJP in one pass: dt = go * [out > 0]; dFgrad (+)= -sg kst dt; dFc (+)= dt (same size) or dt is written out for the
 // reduction over groups; d kst += -sum(dt (sg Fgrad + ks)); d ks += -kst sum(dt).
-__global__ void k_f_step(const float* Fc, size_t nc, const float* Fgrad, float sg, const float* kst, const float* ks, size_t n, float* out) {
+// sw (h, 2M, K; h == 0: none): Fgrad is still in the layout its kernel wrote, [g][h][2M][K], and is read through swap02's index
+// map (element (k, j, i) of the step is element (i, j, k) of Fgrad) - for banks of few mini-batches, where the swap was a launch
+struct SwapDims {
+    int h, n2, k;
+};
+static __device__ __forceinline__ size_t fgrad_at(size_t i, const SwapDims& sw) {
+    if (!sw.h) return i;
+    const size_t per = (size_t)sw.h * sw.n2 * sw.k, gg = i / per, r = i - gg * per;
+    const int ii = (int)(r % sw.h), j = (int)((r / sw.h) % sw.n2), k = (int)(r / ((size_t)sw.h * sw.n2));
+    return gg * per + ((size_t)ii * sw.n2 + j) * sw.k + k;
+}
+__global__ void k_f_step(const float* Fc, size_t nc, const float* Fgrad, float sg, const float* kst, const float* ks, size_t n, float* out, SwapDims sw) {
     const float a = *kst, m2 = *kst * *ks;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const float m1 = Fgrad ? (sg * Fgrad[i]) * a : 0.0f;
+        const float m1 = Fgrad ? (sg * Fgrad[fgrad_at(i, sw)]) * a : 0.0f;
         const float t3 = (Fc[nc == n ? i : i % nc] - m1) - m2;
         out[i] = t3 > 0.0f ? t3 : 0.0f;
     }
 }
 __global__ void k_f_step_bwd(const float* go, const float* out, const float* Fgrad, float sg, const float* kst, const float* ks, size_t n,
-                             float* dFc, int aFc, float* dFg, int aFg, float* dt_out, float* dkst, float* dks) {
+                             float* dFc, int aFc, float* dFg, int aFg, float* dt_out, float* dkst, float* dks, SwapDims sw) {
     const float a = *kst, b = *ks;
     double sk = 0, ss = 0;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const float dt = out[i] > 0.0f ? go[i] : 0.0f;
+        const size_t gi = fgrad_at(i, sw);
         if (dFc) dFc[i] = (aFc ? dFc[i] : 0.0f) + dt;
         if (dt_out) dt_out[i] = dt;
-        if (dFg) dFg[i] = (aFg ? dFg[i] : 0.0f) - (sg * a) * dt;
-        sk -= (double)dt * (double)((Fgrad ? sg * Fgrad[i] : 0.0f) + b);
+        if (dFg) dFg[gi] = (aFg ? dFg[gi] : 0.0f) - (sg * a) * dt;
+        sk -= (double)dt * (double)((Fgrad ? sg * Fgrad[gi] : 0.0f) + b);
         ss -= (double)dt * (double)a;
     }
     for (int d = 32; d >= 1; d >>= 1) {
@@ -805,12 +817,14 @@ Tensor Engine::lin3_zy(Tensor FX, Tensor zy, float b, Tensor abn, const float* t
     return out;
 }
 
-Tensor Engine::f_step(Tensor Fc, Tensor Fgrad, float sg, Tensor kst, Tensor ks, size_t n) {
+// sw_h > 0: Fgrad is [g][h][2M][K] as wgrad_sp wrote it (the step reads it through swap02's map)
+Tensor Engine::f_step(Tensor Fc, Tensor Fgrad, float sg, Tensor kst, Tensor ks, size_t n, int sw_h, int sw_n2, int sw_k) {
     Tensor out = make(n, Fc->needs_grad || (Fgrad && Fgrad->needs_grad) || kst->needs_grad || ks->needs_grad);
     if (failed) return out;
-    EW(k_f_step, out->n, Fc->v, Fc->n, Fgrad ? Fgrad->v : nullptr, sg, kst->v, ks->v, out->n, out->v);
+    const SwapDims sw{Fgrad ? sw_h : 0, sw_n2, sw_k};
+    EW(k_f_step, out->n, Fc->v, Fc->n, Fgrad ? Fgrad->v : nullptr, sg, kst->v, ks->v, out->n, out->v, sw);
     if (recording && out->needs_grad)
-        tape.push_back([this, out, Fc, Fgrad, sg, kst, ks]() {
+        tape.push_back([this, out, Fc, Fgrad, sg, kst, ks, sw]() {
             if (!out->g) return;
             const bool same = Fc->n == out->n;
             int a0 = 1, a1 = 1;
@@ -824,7 +838,7 @@ Tensor Engine::f_step(Tensor Fc, Tensor Fgrad, float sg, Tensor kst, Tensor ks, 
                 return;
             }
             hipLaunchKernelGGL(k_f_step_bwd, dim3(nblocks(out->n, 256 * 4, 2048)), dim3(256), 0, st, out->g, out->v, Fgrad ? Fgrad->v : nullptr, sg,
-                               kst->v, ks->v, out->n, d0, a0, d1, a1, dt, dk, ds);
+                               kst->v, ks->v, out->n, d0, a0, d1, a1, dt, dk, ds, sw);
             if (dt) bcast_reduce(st, dt, nullptr, out->n, Fc->n, 1.0f, grad(Fc));   // the shared bank: sum over the groups
         });
     return out;
