@@ -159,6 +159,7 @@ struct Engine {
     // project_X(X - ost * xg) (xg == null: project_X(X)), model.jl:253 + :181-192, with the entry lists of the result and of its mask
     Tensor x_project(Tensor X, Tensor xg, Tensor ost, int S, int q, float scale = 1.0f);   // scale (xg == null only): project_X(scale * X)
     std::pair<Tensor, Tensor> bankD(Tensor D, int g, int M, int fl);       // (analysis form, flipped synthesis form) of a D bank + their fragment re-layouts
+    void prelayout_an(const float* an, int g, int M, int fl);               // a bank given in analysis form: its flip and fragment re-layouts, one launch
     std::pair<Tensor, Tensor> bankF(Tensor F, int g, int K, int N2, int h);   // (analysis form [h][2M][K], flipped synthesis form [h][K][2M]) of an F bank
     // norm4(exp(-mu * Dgrad) .* Dc), model.jl:285-289; M > 0: Dgrad is the expanded gradient [g][4 fl][2M], collapsed on the way in
     Tensor d_step(Tensor Dgrad, Tensor mu, Tensor Dc, int g = 1, int M = 0, int fl = 0);

@@ -3035,6 +3035,9 @@ Tensor Engine::wgrad(Tensor A, Tensor C, const ToepGeom& gm) {
             if (!out->g) return;
             ToepGeom g2 = gm;
             g2.ldb = (int64_t)gm.Q * gm.N;   // the "filter" of the adjoints is dOut, one slice per group
+            // the D-layer's filter gradient (Q = 4 fl rows of N = 2M): both adjoints' re-layouts of dOut in one launch
+            if (A->needs_grad && C->needs_grad && gm.sa == 4 && (gm.Q & 3) == 0 && (gm.N & 1) == 0) prelayout_an(out->g, gm.S / gm.B, gm.N / 2, gm.Q / 4);
+            if (failed) return;
             if (A->needs_grad) {
                 int a = 1;
                 const bool whole = gm.amax == gm.lda && gm.amax % gm.sa == 0;
@@ -3111,18 +3114,23 @@ Tensor Engine::collapseD(Tensor GA, int g, int M, int fl) {
 //   Bt[j][ip][n]   = da(4 (fl-1-ip) + n, j)             (k_tall_bt of syn viewed [fl][2M][4])
 //   Bf16[ks][l][cb] = Bt'[4 ks + (l >> 4)][16 cb + (l & 15)]    (k_frag_b16 of Bt viewed [2M][4 fl], columns clamped / zero)
 //   Bfw[ct][kg][l][u] = an[8 kg + 2 u + (l >> 5)][32 ct + (l & 31)]   (k_frag_bw of an, columns clamped)
+// src_an != null: the bank is given in its analysis form already (the gradient a wgrad VJP uses as its filter): da(q, j) = src_an[q][j],
+// `an` is not written
 __global__ void k_bankD(const float* __restrict__ D, int g, int M, int fl, float* __restrict__ an, float* __restrict__ syn, float* __restrict__ Bt,
-                        float* __restrict__ Bf16, float* __restrict__ Bfw) {
+                        float* __restrict__ Bf16, float* __restrict__ Bfw, const float* __restrict__ src_an) {
     const int Q = 4 * fl, N2 = 2 * M, KG = Q / 8, NCT = (N2 + 31) / 32;
     const size_t per = (size_t)Q * N2, per16 = (size_t)(N2 / 4) * 256, perw = (size_t)NCT * KG * 256;
     const size_t tot_bank = 3 * per + per16 + perw, total = tot_bank * g;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const size_t gg = i / tot_bank;
         size_t r = i - gg * tot_bank;
-        const float* Dg = D + gg * (size_t)M * Q;
-        auto da = [&](int q, int j) { return j < M ? Dg[(size_t)j * Q + q] : Dg[(size_t)(j - M) * Q + (Q - 1 - q)]; };
+        const float* Dg = src_an ? src_an + gg * per : D + gg * (size_t)M * Q;
+        auto da = [&](int q, int j) {
+            if (src_an) return Dg[(size_t)q * N2 + j];
+            return j < M ? Dg[(size_t)j * Q + q] : Dg[(size_t)(j - M) * Q + (Q - 1 - q)];
+        };
         if (r < per) {                                              // an [Q][2M]
-            an[gg * per + r] = da((int)(r / N2), (int)(r % N2));
+            if (!src_an) an[gg * per + r] = da((int)(r / N2), (int)(r % N2));
         } else if ((r -= per) < per) {                              // syn [fl][2M][4]
             const int y = (int)(r % 4), x = (int)((r / 4) % N2), ip = (int)(r / ((size_t)4 * N2));
             syn[gg * per + r] = da(4 * (fl - 1 - ip) + y, x);
@@ -3181,7 +3189,7 @@ std::pair<Tensor, Tensor> Engine::bankD(Tensor D, int g, int M, int fl) {
         failed = true;
         return {an, syn};
     }
-    hipLaunchKernelGGL(k_bankD, dim3(nblocks((3 * per + per16 + perw) * g)), dim3(256), 0, st, D->v, g, M, fl, an->v, syn->v, Bt, Bf16, Bfw);
+    hipLaunchKernelGGL(k_bankD, dim3(nblocks((3 * per + per16 + perw) * g)), dim3(256), 0, st, D->v, g, M, fl, an->v, syn->v, Bt, Bf16, Bfw, (const float*)nullptr);
     // the re-layouts the consumers will ask for (launch_toep's tall form on syn, launch_rowgemm_lds / k_tall_fused on its Bt,
     // launch_toep_wide on an), and the two forms as each other's flip (toep_adjoint_a)
     derived[RelayoutKey{(const void*)syn->v, 4, N2, 4, fl, per * g}] = Bt;
@@ -3197,6 +3205,31 @@ std::pair<Tensor, Tensor> Engine::bankD(Tensor D, int g, int M, int fl) {
             if (dx) EW(k_bankD_bwd, D->n, an->g, syn->g, g, M, fl, dx, acc);
         });
     return {an, syn};
+}
+
+// The re-layouts a convolution takes of a bank that is given in its analysis form [g][4 fl][2M] and is not a tensor of the graph
+// (the gradient a wgrad VJP uses as the filter of its two adjoints): flipped form, tall form, fragment orders - one launch, the
+// same keys the consumers look up (was flipT, k_tall_bt, k_frag_b16 and k_frag_bw, per DF pass)
+void Engine::prelayout_an(const float* an, int g, int M, int fl) {
+    static const bool off = getenv("MOTIFS_NO_BANK_FUSION") != nullptr;
+    const int Q = 4 * fl, N2 = 2 * M;
+    if (off || (fl & 1) || (N2 & 3)) return;
+    const size_t per = (size_t)Q * N2, per16 = (size_t)(N2 / 4) * 256, perw = (size_t)((N2 + 31) / 32) * (Q / 8) * 256;
+    if (derived.count(RelayoutKey{(const void*)an, 5, 4, N2, fl, per * g})) return;
+    float* syn = arena.alloc(per * g);
+    float* Bt = arena.alloc(per * g);
+    float* Bf16 = arena.alloc(per16 * g);
+    float* Bfw = arena.alloc(perw * g);
+    if (!syn || !Bt || !Bf16 || !Bfw) {
+        failed = true;
+        return;
+    }
+    hipLaunchKernelGGL(k_bankD, dim3(nblocks((3 * per + per16 + perw) * g)), dim3(256), 0, st, (const float*)nullptr, g, M, fl, (float*)nullptr, syn, Bt, Bf16,
+                       Bfw, an);
+    derived[RelayoutKey{(const void*)an, 5, 4, N2, fl, per * g}] = syn;
+    derived[RelayoutKey{(const void*)syn, 4, N2, 4, fl, per * g}] = Bt;
+    derived[RelayoutKey{(const void*)Bt, 2, N2, Q, 0, per16 * g}] = Bf16;
+    derived[RelayoutKey{(const void*)an, 3, Q, N2, 0, perw * g}] = Bfw;
 }
 
 // The F bank (reference layout F[g][K][2M][h]) in its two GEMM forms in one launch (swap02 then flipT were two):
