@@ -526,7 +526,7 @@ def main():
             "device_ms_fwd_bwd": gms / max(gn, 1),
             "ms_per_step_g1": g1dt / g1_steps * 1e3,
             "seqs_per_s_g1": hp.batch_size * world * g1_steps / g1dt,
-            "g1_note": "reference schedule (train.jl:40-46): one AdaBelief step per mini-batch of 6 reads per GPU; ~280 launches of 2-10 us "
+            "g1_note": "reference schedule (train.jl:40-46): one AdaBelief step per mini-batch of 6 reads per GPU; ~270 launches of 2-10 us "
                        "(profiles/r03_g1_step_kernels.txt, DESIGN 3)",
             "filter_scan_a4": {
                 "kernel": "k_onehot_bank_scan (warmup_ZY's conv(S,D) pair, model.jl:171-173: S is one-hot, so each output is fl bank rows picked by base "
