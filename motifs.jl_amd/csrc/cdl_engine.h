@@ -140,6 +140,8 @@ struct Engine {
     Tensor lin3_zy(Tensor FX, Tensor zy, float b, Tensor abn, const float* thr, int groups);
     // relu((Fc - sg*Fgrad*kst) - kst*ks) with n outputs; Fc is broadcast over groups if smaller, Fgrad may be null (zero)
     Tensor f_step(Tensor Fc, Tensor Fgrad, float sg, Tensor kst, Tensor ks, size_t n, int sw_h = 0, int sw_n2 = 0, int sw_k = 0);
+    // norml2(f_step(...), seg) in one kernel per direction (Fc of the output's size; else the two launches)
+    Tensor f_step_norm(Tensor Fc, Tensor Fgrad, float sg, Tensor kst, Tensor ks, size_t n, int seg, int sw_h = 0, int sw_n2 = 0, int sw_k = 0);
     Tensor x_step(Tensor X, Tensor xg, Tensor ost);   // X - ost * xg (update_X before the projection), VJP in one pass
     // the same with the dual update folded in: abn = FX - ZY + abp (abp optional), then the step with abn; returns {out, abn}
     std::pair<Tensor, Tensor> zy_step2(Tensor ZY, Tensor g1, Tensor FX, Tensor abp, Tensor pen, Tensor lst, Tensor ls, uint32_t* hist0 = nullptr,

@@ -1122,6 +1122,101 @@ Tensor Engine::norml2(Tensor x, int seg, bool squared) {
     return out;
 }
 
+// update_F's proximal step and the normalisation after it in one kernel per direction (model.jl:298-308; f_step then norml2 before):
+//   t = relu((Fc - sg * Fgrad * kst) - kst * ks),  out = t / ||t||_2 per segment (one block per segment, as k_norml2)
+// Fgrad through swap02's map (SwapDims), Fc of the same size as the output (a bank per mini-batch, or one mini-batch).
+__global__ void k_f_step_norm(const float* Fc, const float* Fgrad, float sg, const float* kst, const float* ks, int seg, float* out, float* nrm_out,
+                              SwapDims sw) {
+    const size_t base = (size_t)blockIdx.x * seg;
+    const float a = *kst, m2 = *kst * *ks;
+    double acc = 0;
+    for (int i = threadIdx.x; i < seg; i += blockDim.x) {
+        const float m1 = Fgrad ? (sg * Fgrad[fgrad_at(base + i, sw)]) * a : 0.0f;
+        const float t3 = (Fc[base + i] - m1) - m2;
+        const float t = t3 > 0.0f ? t3 : 0.0f;
+        out[base + i] = t;                                          // kept until the norm is known
+        acc += (double)t * t;
+    }
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+    __shared__ double red[16];
+    __shared__ float nrm;
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0;
+        for (int i = 0; i < (int)(blockDim.x >> 6); i++) t += red[i];
+        nrm = (float)sqrt(t);
+        nrm_out[blockIdx.x] = nrm;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < seg; i += blockDim.x) out[base + i] = out[base + i] / nrm;
+}
+// go = d out.  dt = [out > 0] * (go - out * <go, out>) / nrm;  then f_step's VJP on dt
+__global__ void k_f_step_norm_bwd(const float* go, const float* out, const float* nrm_in, const float* Fgrad, float sg, const float* kst, const float* ks,
+                                  int seg, float* dFc, int aFc, float* dFg, int aFg, float* dkst, float* dks, SwapDims sw) {
+    const size_t base = (size_t)blockIdx.x * seg;
+    double acc = 0;
+    for (int i = threadIdx.x; i < seg; i += blockDim.x) acc += (double)go[base + i] * out[base + i];
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+    __shared__ double red[3][16];
+    __shared__ float dot;
+    if ((threadIdx.x & 63) == 0) red[0][threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0;
+        for (int i = 0; i < (int)(blockDim.x >> 6); i++) t += red[0][i];
+        dot = (float)t;
+    }
+    __syncthreads();
+    const float nrm = nrm_in[blockIdx.x], a = *kst, b = *ks;
+    double sk = 0, ss = 0;
+    for (int i = threadIdx.x; i < seg; i += blockDim.x) {
+        const float o = out[base + i];
+        const float dn = (go[base + i] - o * dot) / nrm;
+        const float dt = o > 0.0f ? dn : 0.0f;
+        const size_t gi = fgrad_at(base + i, sw);
+        if (dFc) dFc[base + i] = (aFc ? dFc[base + i] : 0.0f) + dt;
+        if (dFg) dFg[gi] = (aFg ? dFg[gi] : 0.0f) - (sg * a) * dt;
+        sk -= (double)dt * (double)((Fgrad ? sg * Fgrad[gi] : 0.0f) + b);
+        ss -= (double)dt * (double)a;
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+        sk += __shfl_xor(sk, d);
+        ss += __shfl_xor(ss, d);
+    }
+    if ((threadIdx.x & 63) == 0) red[1][threadIdx.x >> 6] = sk, red[2][threadIdx.x >> 6] = ss;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tk = 0, ts = 0;
+        for (int i = 0; i < (int)(blockDim.x >> 6); i++) tk += red[1][i], ts += red[2][i];
+        if (dkst) atomicAdd(dkst, (float)tk);
+        if (dks) atomicAdd(dks, (float)ts);
+    }
+}
+Tensor Engine::f_step_norm(Tensor Fc, Tensor Fgrad, float sg, Tensor kst, Tensor ks, size_t n, int seg, int sw_h, int sw_n2, int sw_k) {
+    static const bool off = getenv("MOTIFS_NO_F_STEP_NORM") != nullptr;
+    if (off || Fc->n != n || n % seg) return norml2(f_step(Fc, Fgrad, sg, kst, ks, n, sw_h, sw_n2, sw_k), seg);   // a shared bank: the separate launches
+    Tensor out = make(n, Fc->needs_grad || (Fgrad && Fgrad->needs_grad) || kst->needs_grad || ks->needs_grad);
+    Tensor nrm = make(n / seg, false);
+    if (failed) return out;
+    const SwapDims sw{Fgrad ? sw_h : 0, sw_n2, sw_k};
+    const unsigned nseg = (unsigned)(n / seg), thr = nseg >= 256 ? 256 : 1024;
+    hipLaunchKernelGGL(k_f_step_norm, dim3(nseg), dim3(thr), 0, st, Fc->v, Fgrad ? Fgrad->v : nullptr, sg, kst->v, ks->v, seg, out->v, nrm->v, sw);
+    if (recording && out->needs_grad)
+        tape.push_back([this, out, nrm, Fc, Fgrad, sg, kst, ks, seg, nseg, thr, sw]() {
+            if (!out->g) return;
+            int a0 = 1, a1 = 1;
+            float* d0 = Fc->needs_grad ? grad_first(Fc, a0) : nullptr;
+            float* d1 = (Fgrad && Fgrad->needs_grad) ? grad_first(Fgrad, a1) : nullptr;
+            float* dk = kst->needs_grad ? grad(kst) : nullptr;
+            float* ds = ks->needs_grad ? grad(ks) : nullptr;
+            if (failed) return;
+            hipLaunchKernelGGL(k_f_step_norm_bwd, dim3(nseg), dim3(thr), 0, st, out->g, out->v, nrm->v, Fgrad ? Fgrad->v : nullptr, sg, kst->v, ks->v, seg, d0,
+                               a0, d1, a1, dk, ds, sw);
+        });
+    return out;
+}
+
 // into: the per-group sums are ADDED to an existing [groups] tensor (the two terms of the loss meet in one buffer instead of in
 // a lin of two; its gradient is read by both VJPs)
 Tensor Engine::resid_sumsq_groups(Tensor x, Tensor y, float b, const float* thr, float coef, int groups, Tensor into) {

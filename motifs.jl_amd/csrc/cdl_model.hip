@@ -249,9 +249,10 @@ static Tensor forward_loss(motifs_model* m, Graph& gr, bool train) {
     std::vector<Tensor> thetas;                                            // theta_0 ..
     // the proximal step on the gradient wgrad_sp wrote, [G][h][2M][K]: read through swap02's map while the bank is small (a bank
     // per mini-batch of a large step goes through the tiled swap, whose reads are contiguous)
-    auto f_step_of = [&](Tensor Fg_hnk, Tensor Fcur, float sg, int t) {
-        if (nbank <= ((size_t)1 << 20)) return e.f_step(Fcur, Fg_hnk, sg, sc.kst[t], sc.ks[t], nbank, m->h, m->twoM, m->K);
-        return e.f_step(Fcur, e.swap02(Fg_hnk, G, m->h, m->twoM, m->K), sg, sc.kst[t], sc.ks[t], nbank);
+    const int fseg = m->h * m->twoM;
+    auto f_step_of = [&](Tensor Fg_hnk, Tensor Fcur, float sg, int t) {      // ... and the normalisation after it (:306-308)
+        if (nbank <= ((size_t)1 << 20)) return e.f_step_norm(Fcur, Fg_hnk, sg, sc.kst[t], sc.ks[t], nbank, fseg, m->h, m->twoM, m->K);
+        return e.f_step_norm(Fcur, e.swap02(Fg_hnk, G, m->h, m->twoM, m->K), sg, sc.kst[t], sc.ks[t], nbank, fseg);
     };
     for (int t = 0; t < P; t++) {
         // update_D (:275-290): D_grad = Z'(sumZD + sumYRD + S) + reverse(Y'(...)), only the f_len needed lags
@@ -266,11 +267,11 @@ static Tensor forward_loss(motifs_model* m, Graph& gr, bool train) {
             Fc = e.norml2(e.f_step(Fc, Fgrad, 1.0f, sc.kst[t], sc.ks[t], nbank), m->h * m->twoM);
         } else if (t == 0) {
             Tensor R = e.lin3(FXcur, 1.0f, ZY, zmf, nullptr, 0.0f, zmt, G);
-            Fc = e.norml2(f_step_of(e.wgrad_sp(R, X, gr.spd(G)), Fc, 1.0f, t), m->h * m->twoM);
+            Fc = f_step_of(e.wgrad_sp(R, X, gr.spd(G)), Fc, 1.0f, t);
         } else if (t == 1) {                                               // R_1 = 0: the gradient of F vanishes identically
-            Fc = e.norml2(e.f_step(Fc, nullptr, 1.0f, sc.kst[t], sc.ks[t], nbank), m->h * m->twoM);
+            Fc = e.f_step_norm(Fc, nullptr, 1.0f, sc.kst[t], sc.ks[t], nbank, fseg);
         } else {                                                           // R_t = -theta_{t-2}: the sign goes into the step
-            Fc = e.norml2(f_step_of(e.wgrad_sp(thetas[t - 2], X, gr.spd(G)), Fc, -1.0f, t), m->h * m->twoM);
+            Fc = f_step_of(e.wgrad_sp(thetas[t - 2], X, gr.spd(G)), Fc, -1.0f, t);
         }
         gF = G;
         bFc = gr.bankF(Fc, gF);

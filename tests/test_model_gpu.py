@@ -271,7 +271,7 @@ def test_fused_forms_equal_the_separate_launches(ctx, pkg, tmp_path):
     float64 oracle in test_cfg2_golden)."""
     import subprocess
     import sys
-    switches = {"MOTIFS_NO_BANK_FUSION": "1", "MOTIFS_NO_D_STEP": "1", "MOTIFS_NO_X_PROJECT": "1", "MOTIFS_NO_TOEP_PLUS": "1", "MOTIFS_NO_TALL_FUSED": "1", "MOTIFS_NO_ROW_SRC": "1", "MOTIFS_NO_ONEHOT_SCAN": "1"}
+    switches = {"MOTIFS_NO_F_STEP_NORM": "1", "MOTIFS_NO_BANK_FUSION": "1", "MOTIFS_NO_D_STEP": "1", "MOTIFS_NO_X_PROJECT": "1", "MOTIFS_NO_TOEP_PLUS": "1", "MOTIFS_NO_TALL_FUSED": "1", "MOTIFS_NO_ROW_SRC": "1", "MOTIFS_NO_ONEHOT_SCAN": "1"}
     outs = {}
     # third run: the arena starts as NaN bit patterns (MOTIFS_POISON_ARENA), so a kernel that reads what nothing wrote would show
     for tag, env in (("fused", {}), ("separate", switches), ("poisoned", {"MOTIFS_POISON_ARENA": "1"})):
