@@ -2253,6 +2253,15 @@ __global__ __launch_bounds__(256) void k_toep_wide(const float* __restrict__ A, 
     const int job = blockIdx.x / cs, part = blockIdx.x - job * cs;
     const int s = job / tps, p0 = (job - s * tps) * 32;
     const float* sig = A + (size_t)s * gm.lda;
+    // this wave's first bank fragments are on their way while the windows are staged
+    const float4* bp = (const float4*)(Bf + (size_t)(s / gm.B) * ldbf) + lane;
+    const int nct_all = (gm.N + 31) >> 5;
+    const int ct_lo = part * nct_all / cs, nct = (part + 1) * nct_all / cs;      // this block's tiles [ct_lo, nct)
+    float4 cur[KG], nxt[KG];
+    if (ct_lo + wave < nct) {
+#pragma unroll
+        for (int kg = 0; kg < KG; kg++) cur[kg] = bp[(size_t)((ct_lo + wave) * KG + kg) * 64];
+    }
     float a[4 * KG];
     // the block's windows overlap: their span (31 sa + Q floats) goes through LDS once, coalesced, instead of one
     // strided 4-byte gather per operand and wave
@@ -2279,14 +2288,6 @@ __global__ __launch_bounds__(256) void k_toep_wide(const float* __restrict__ A, 
             const float x = sig[ok ? e : 0];
             a[ks] = ok ? x : 0.0f;
         }
-    }
-    const float4* bp = (const float4*)(Bf + (size_t)(s / gm.B) * ldbf) + lane;
-    const int nct_all = (gm.N + 31) >> 5;
-    const int ct_lo = part * nct_all / cs, nct = (part + 1) * nct_all / cs;      // this block's tiles [ct_lo, nct)
-    float4 cur[KG], nxt[KG];
-    if (ct_lo + wave < nct) {
-#pragma unroll
-        for (int kg = 0; kg < KG; kg++) cur[kg] = bp[(size_t)((ct_lo + wave) * KG + kg) * 64];
     }
     for (int ct = ct_lo + wave; ct < nct; ct += 4) {       // wave w: column tiles w, w+4, ..
         const int cn = min(ct + 4, nct - 1);
