@@ -289,6 +289,30 @@ def test_fused_forms_equal_the_separate_launches(ctx, pkg, tmp_path):
     assert rel_inf(outs["fused"]["flat"], outs["poisoned"]["flat"]) <= 1e-5
 
 
+@pytest.mark.parametrize("G", [16, 40])
+def test_step_sizes_take_different_kernels_and_agree(ctx, pkg, G):
+    """The engine picks its kernel forms by step size (per-read sparse gradients to 24 mini-batches, 2-row synthesis blocks and
+    split row walks below 192 reads, the fused tall form to ~100 reads, fused bank forms for small banks, ...).  The one-mini-batch
+    forms are held against the float64 oracle (test_cfg2_golden); here a launch of G mini-batches at the configs[1] shape - 16: the
+    middle forms, 40: the large-step forms - against G launches of one: the same losses, and the sum of the gradients."""
+    md, sy = pkg.model, pkg.synth
+    hp = md.Hyperparam(filter_len=12, M=200)
+    L = 200
+    cdl = md.ucdl(hp, L, ctx=ctx, seed=3, arena_bytes=int((1.3 * G + 2) * (1 << 30)))
+    try:
+        codes = sy.gen_codes(G * hp.batch_size, L, 91, n_plant=5, k=12)
+        l_all, g_all = gpu_loss_grad(pkg, ctx, cdl, codes, G)
+        l_one, g_sum = [], np.zeros(cdl.model.nP, dtype=np.float64)
+        for g in range(G):
+            l, gr = gpu_loss_grad(pkg, ctx, cdl, codes[g * hp.batch_size:(g + 1) * hp.batch_size], 1)
+            l_one.append(l[0])
+            g_sum += gr
+        assert np.all(np.isfinite(l_all)) and np.allclose(np.array(l_one), l_all, rtol=1e-5)
+        assert rel_inf(g_all, g_sum.astype(np.float32)) <= 2e-5
+    finally:
+        cdl.model.close()
+
+
 def test_train_step_matches_adabelief_oracle(ctx, pkg):
     hp, codes, cdl_o = tiny(5, G=1)
     cdl = to_model(pkg, ctx, hp, codes.shape[1], cdl_o)
