@@ -111,6 +111,11 @@ enum motifs_kernel_slot {
 int motifs_ctx_enable_timing(motifs_ctx* ctx, int on);
 int motifs_ctx_reset_timing(motifs_ctx* ctx);
 int motifs_ctx_kernel_ms(motifs_ctx* ctx, int slot, double* ms, int64_t* launches);
+/* How the last hit-record scan on this context was laid out (diagnostics for tests and benchmarks; the records do not
+ * depend on it): plan[0] = 1 when the candidates travelled as compact 16-bit entries, plan[1] = chunks of 128 PWMs per
+ * chunk group of the re-scoring (0: the whole table sat in one block's LDS or was gathered from L2), plan[2] = chunk
+ * groups, plan[3] = super-batch launches of the last strand scanned. */
+int motifs_ctx_scan_plan(motifs_ctx* ctx, int32_t plan[4]);
 
 /* ---- device memory for a host without a GPU array package ----------------- */
 

@@ -65,6 +65,7 @@ SIGNATURES = {
     "motifs_ctx_enable_timing": (_int, [_p, _int]),
     "motifs_ctx_reset_timing": (_int, [_p]),
     "motifs_ctx_kernel_ms": (_int, [_p, _int, C.POINTER(C.c_double), C.POINTER(_i64)]),
+    "motifs_ctx_scan_plan": (_int, [_p, C.POINTER(C.c_int32)]),
     "motifs_codes_bytes": (C.c_size_t, [_i64, _int]),
     "motifs_codes_pitch": (_int, [_int]),
     "motifs_encode_dev": (_int, [_p, _p, _int, _i64, _int, _p, _p]),
@@ -260,6 +261,12 @@ class Context:
         ms, n = C.c_double(0), _i64(0)
         check(lib().motifs_ctx_kernel_ms(self._h, int(slot), C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def scan_plan(self):
+        """Layout of the last hit-record scan: dict(compact, cg_chunks, cg_groups, launches) (motifs_ctx_scan_plan)."""
+        v = (C.c_int32 * 4)()
+        check(lib().motifs_ctx_scan_plan(self._h, v))
+        return {"compact": bool(v[0]), "cg_chunks": int(v[1]), "cg_groups": int(v[2]), "launches": int(v[3])}
 
     # ---- sequence encoding ----
     @staticmethod

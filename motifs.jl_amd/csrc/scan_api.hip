@@ -370,16 +370,49 @@ static void scan_args(motifs_ctx* c, const BankSlot& bank, int K, const uint8_t*
     f.div_nch.m = d == 1 ? 0u : (uint32_t)((((uint64_t)1 << 32) * (((uint64_t)1 << sh) - d)) / d + 1);
 }
 
+// Geometry of the hit-record pipeline for one bank: rows, staging slots, bytes per ordering batch, the super-batch size under the
+// workspace bound.  Compact entries need a bank scaled to one slack with PWMs of up to 20 positions (cand_compact_ok); chunk groups
+// (scan_mfma.hip) need compact entries.  The bound counts everything a launch allocates per ordering batch: cells (16 B each),
+// entries (4 B per cell), staged words (8 B per cell) - twice the first two when one candidate launch serves both strands.
+struct HitGeom {
+    bool compact;
+    int cgc, ncg;              // chunk groups (0 = off)
+    int rpr, parts, row_slots;
+    size_t per_batch, stage_per_batch;
+    int64_t nb_max;            // ordering batches per launch
+};
+static HitGeom hit_geom(const motifs_ctx* c, const BankSlot& bank, int K, int Lout, int batch, bool emit, int64_t N, bool two_strands = false) {
+    HitGeom g{};
+    g.compact = c->compact_cells && bank.uniform_eps && bank.lenp <= 20;
+    g.cgc = (g.compact && c->cg_chunks != 0) ? stage_cg_chunks(K, bank.nch, bank.lenp, bank.tabk_stride, c->cg_chunks > 0 ? c->cg_chunks : 0) : 0;
+    g.ncg = g.cgc ? (bank.nch + g.cgc - 1) / g.cgc : 1;
+    g.rpr = g.cgc ? 512 / g.cgc : stage_row_reads(bank.nch);
+    g.parts = (batch + g.rpr - 1) / g.rpr;
+    g.row_slots = g.cgc ? 2 * 512 : 2 * g.rpr * bank.nch;            // staged hits per (row, group) before the slow path
+    g.per_batch = (size_t)Lout * batch * bank.nch * 16;
+    // (chunk groups: + the per-read hit counts in front of every (row, group)'s slots, 16 bits per read)
+    g.stage_per_batch = emit ? (size_t)Lout * g.parts * g.ncg * (g.row_slots + (g.cgc ? 256 / g.cgc : 0)) * 4 : 0;
+    const size_t cand_bytes = g.per_batch + (g.compact ? g.per_batch / 4 : 0);
+    const size_t all = (two_strands ? 2 : 1) * cand_bytes + g.stage_per_batch;
+    int64_t nb_max = (int64_t)(c->ws_limit / all);
+    // compact entries: the kernels keep 32-bit BYTE offsets into the entry array (2 bytes per half cell = per_batch / 4 bytes per
+    // batch), so a launch holds fewer than 2^31 entries
+    if (g.compact) nb_max = std::min<int64_t>(nb_max, (int64_t)((((size_t)1 << 31) - 1) / (g.per_batch / 8)));
+    g.nb_max = std::max<int64_t>(1, std::min<int64_t>(nb_max, (N + batch - 1) / batch));
+    if (g.compact && (size_t)g.nb_max * (g.per_batch / 8) >= ((size_t)1 << 31)) {     // a single ordering batch past the offsets' range
+        g.compact = false;
+        g.cgc = 0;
+        g.ncg = 1;
+        g.rpr = stage_row_reads(bank.nch);
+        g.parts = (batch + g.rpr - 1) / g.rpr;
+        g.row_slots = 2 * g.rpr * bank.nch;
+        g.stage_per_batch = emit ? (size_t)Lout * g.parts * g.row_slots * 4 : 0;
+    }
+    return g;
+}
 // reads one launch of the matrix-core path takes under the workspace bound (whole ordering batches)
-static int64_t reads_per_launch(const motifs_ctx* c, const BankSlot& bank, int Lout, int batch, bool emit, int64_t N) {
-    const int rpr = stage_row_reads(bank.nch);
-    const int parts = (batch + rpr - 1) / rpr;
-    const int row_slots = 2 * rpr * bank.nch;
-    const size_t per_batch = (size_t)Lout * batch * bank.nch * 16;
-    const size_t stage_per_batch = emit ? (size_t)Lout * parts * row_slots * 4 : 0;
-    int64_t nb_max = (int64_t)(c->ws_limit / (per_batch + stage_per_batch));
-    nb_max = std::max<int64_t>(1, std::min<int64_t>(nb_max, (N + batch - 1) / batch));
-    return nb_max * batch;
+static int64_t reads_per_launch(const motifs_ctx* c, const BankSlot& bank, int K, int Lout, int batch, bool emit, int64_t N, bool two_strands = false) {
+    return hit_geom(c, bank, K, Lout, batch, emit, N, two_strands).nb_max * batch;
 }
 
 // Hit records through the matrix cores: candidates (scan_cand_kernel) -> exact verification, staged hits and
@@ -393,23 +426,16 @@ static int scan_hits_mfma(motifs_ctx* c, const BankSlot& bank, int K, const uint
     // slot: which pair of running totals in c->small this strand uses; finish = false: everything is enqueued, the
     // total stays on the device at totals_of(slot) and the caller reads it after its own synchronisation
     const bool emit = hits_dev != nullptr && cap > 0;
-    const int rpr = stage_row_reads(bank.nch);                       // reads per row of cells
-    const int parts = (batch + rpr - 1) / rpr;
-    const int row_slots = 2 * rpr * bank.nch;                        // staged hits per row before the slow path
-    const size_t per_batch = (size_t)Lout * batch * bank.nch * 16;
-    const size_t stage_per_batch = emit ? (size_t)Lout * parts * row_slots * 4 : 0;
-    int64_t nb_max = (int64_t)(c->ws_limit / (per_batch + stage_per_batch));
-    nb_max = std::max<int64_t>(1, std::min<int64_t>(nb_max, (N + batch - 1) / batch));
+    const HitGeom hg = hit_geom(c, bank, K, Lout, batch, emit, N, cand_mode != 0);
+    const int rpr = hg.rpr;                                          // reads per row of cells
+    const int parts = hg.parts;
+    const int row_slots = hg.row_slots;                              // staged hits per row (and chunk group) before the slow path
+    const size_t per_batch = hg.per_batch, stage_per_batch = hg.stage_per_batch;
+    const int64_t nb_max = hg.nb_max;
     const int64_t sb = nb_max * batch;
     const int64_t rows_max = nb_max * Lout * parts;
     MOTIFS_HIP_CHECK(c->cnt.reserve((size_t)nb_max * per_batch));
-    bool compact = c->compact_cells;
-    {   // compact entries (a quarter of the cells' bytes) when the candidate kernel of this launch shape can write them
-        CandArgs a0{};
-        FillArgs f0{};
-        scan_args(c, bank, K, codes_dev, std::min<int64_t>(sb, N), L, Lout, batch, rpr, a0, f0);
-        compact = compact && cand_compact_ok(a0) && (size_t)nb_max * per_batch / 8 < ((size_t)1 << 32);   // 32-bit entry indices in the kernels
-    }
+    const bool compact = hg.compact;
     if (cand_mode != 0 && (!compact || sb < N)) {
         set_error("internal: a two-strand candidate launch needs compact entries and a single super-batch");
         return MOTIFS_ERR_INVALID;
@@ -421,7 +447,7 @@ static int scan_hits_mfma(motifs_ctx* c, const BankSlot& bank, int K, const uint
     }
     void* const cells_buf = cand_mode == 2 ? c->cnt2.p : c->cnt.p;
     void* const entries_buf = cand_mode == 2 ? c->centries2.p : c->centries.p;
-    MOTIFS_HIP_CHECK(c->tilesum.reserve((size_t)rows_max * 4));
+    MOTIFS_HIP_CHECK(c->tilesum.reserve((size_t)rows_max * hg.ncg * 4));
     MOTIFS_HIP_CHECK(c->off.reserve((size_t)((rows_max + 1023) / 1024) * 8));
     MOTIFS_HIP_CHECK(c->rowx.reserve((size_t)rows_max * 4));
     if (emit) MOTIFS_HIP_CHECK(c->staging.reserve((size_t)nb_max * stage_per_batch));
@@ -453,6 +479,8 @@ static int scan_hits_mfma(motifs_ctx* c, const BankSlot& bank, int K, const uint
         f.blk_base = (unsigned long long*)c->off.p;
         f.staging = (uint32_t*)c->staging.p;
         f.row_slots = row_slots;
+        f.cgc = hg.cgc;
+        f.ncg = hg.ncg;
         f.row_excl = (uint32_t*)c->rowx.p;
         f.base_in = launch_no == 0 ? nullptr : totals + (launch_no & 1);
         f.total = totals + ((launch_no + 1) & 1);
@@ -462,7 +490,7 @@ static int scan_hits_mfma(motifs_ctx* c, const BankSlot& bank, int K, const uint
         f.hit_scores = hit_scores_dev;
         f.pwm_counts = per_pwm_counts_dev;   // zeroed by the caller of this function; only bins k < K are ever touched
         f.n0 = n0 + s0;
-        f.hist_bins = (per_pwm_counts_dev && 2 * bank.KP <= FILL_HIST_MAX) ? 2 * bank.KP : 0;
+        f.hist_bins = (per_pwm_counts_dev && 2 * bank.KP <= FILL_HIST_MAX && !hg.cgc) ? 2 * bank.KP : 0;   // (chunk groups keep their own)
         if (ns < nb * batch && cand_mode != 2) {   // cells of reads the last batch does not have are never written by the scan
             if (compact) MOTIFS_HIP_CHECK(hipMemsetAsync((char*)c->centries.p + (size_t)(nb - 1) * (per_batch / 4), 0, per_batch / 4, c->stream));
             else MOTIFS_HIP_CHECK(hipMemsetAsync((char*)c->cnt.p + (size_t)(nb - 1) * per_batch, 0, per_batch, c->stream));
@@ -484,6 +512,7 @@ static int scan_hits_mfma(motifs_ctx* c, const BankSlot& bank, int K, const uint
             MOTIFS_HIP_CHECK(launch_emit_records(f, c->stream));
         }
     }
+    c->scan_plan[0] = compact, c->scan_plan[1] = hg.cgc, c->scan_plan[2] = hg.ncg, c->scan_plan[3] = launch_no;
     // records are written up to cap in any case; the total says whether they all fitted
     if (!finish) return MOTIFS_OK;
     MOTIFS_HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -534,6 +563,7 @@ int motifs_ctx_create(int device, motifs_ctx** out) {
     const char* ev = getenv("MOTIFS_SCAN_VALU");
     c->scan_valu = ev && ev[0] == '1';
     if (const char* nc = getenv("MOTIFS_DENSE_CELLS")) c->compact_cells = !(nc[0] == '1');   // A/B: the round-2 cell round trip
+    if (const char* cgv = getenv("MOTIFS_CG_CHUNKS")) c->cg_chunks = atoi(cgv);      // chunk groups: 0 = never, 1 / 2 / 4 = that size for every bank that can take it (tests, A/B)
     if (const char* nf = getenv("MOTIFS_NO_STRAND_FUSION")) c->fuse_strands = !(nf[0] == '1');  // A/B: one candidate launch per strand
     if (const char* wl = getenv("MOTIFS_WS_LIMIT_MB")) {       // experiments: the default of motifs_ctx_set_workspace_limit
         const long long mb = atoll(wl);
@@ -617,6 +647,15 @@ int motifs_ctx_reset_timing(motifs_ctx* c) {
         c->kernel_ms[i] = 0;
         c->kernel_launches[i] = 0;
     }
+    return MOTIFS_OK;
+}
+
+int motifs_ctx_scan_plan(motifs_ctx* c, int32_t plan[4]) {
+    if (!c || !plan) {
+        set_error("motifs_ctx_scan_plan: bad argument");
+        return MOTIFS_ERR_INVALID;
+    }
+    for (int i = 0; i < 4; i++) plan[i] = c->scan_plan[i];
     return MOTIFS_OK;
 }
 
@@ -931,9 +970,9 @@ int motifs_pwm_scan_hits_both_dev(motifs_ctx* c, const uint16_t* pwms_fp16, cons
         scan_args(c, *bs[0], K, codes_dev, N, L, Lout0, batch, rpr0, a0, f0);
         scan_args(c, *bs[1], K, codes_dev, N, L, Lout0, batch, rpr0, a1, f0);
         const bool emit = hits[0] != nullptr && cap > 0;
+        const HitGeom hg0 = hit_geom(c, *bs[0], K, Lout0, batch, emit, N, true);
         fuse = fuse && cand_two_strands_ok(a0) && cand_two_strands_ok(a1) && bs[0]->lenp == bs[1]->lenp && bs[0]->nch == bs[1]->nch &&
-               reads_per_launch(c, *bs[0], Lout0, batch, emit, N) >= N &&
-               (size_t)((N + batch - 1) / batch) * ((size_t)Lout0 * batch * bs[0]->nch * 16) / 8 < ((size_t)1 << 32);
+               hg0.compact && hg0.nb_max * batch >= N;
     }
     for (int rc = 0; rc < 2; rc++) {
         const int Lout = L - bs[rc]->minlen + 1;

@@ -78,6 +78,10 @@ struct FillArgs {
     const int64_t* base_in;       // records emitted before this super-batch (nullptr: none, the first one)
     int64_t* total_host;          // optional pinned host copy of *total (the host reads it after its stream wait)
     int64_t cap;                  // records the output arrays can hold
+    // chunk-group mode (banks whose re-scoring table does not fit the LDS; scan_mfma.hip "chunk groups"): cgc = chunks of 128 PWMs
+    // per group (1, 2 or 4; 0 = off), ncg = groups.  A row is then rpr = 512 / cgc reads x nch chunks, row_sum / staging are kept
+    // per (row, group): row_sum[row * ncg + cg], staging[(row * ncg + cg) * row_slots ...]
+    int cgc, ncg;
     struct {
         uint32_t d, m, s;
         __device__ uint32_t div(uint32_t n) const {
@@ -119,6 +123,10 @@ int dense_row_reads(int nch);                                              // th
 hipError_t launch_stage_hits(const FillArgs& a, int mode, hipStream_t st);
 hipError_t launch_row_scan(const FillArgs& a, hipStream_t st);             // row counts -> offsets; *total = *base_in + hits
 hipError_t launch_emit_records(const FillArgs& a, hipStream_t st);         // staged hits -> records
+// chunk groups: the largest group (chunks of 128 PWMs: 4, 2, 1) whose slice of the re-scoring table fits a block's LDS beside
+// the queues, 0 when the whole table fits (or the bank cannot take the mode); `want` > 0 forces a size (tests, A/B runs)
+int stage_cg_chunks(int K, int nch, int lenp, int tabk_stride, int want);
+size_t stage_cg_lds_bytes(int cgc, int tabk_stride);
 hipError_t launch_fill_scan(const FillArgs& a, hipStream_t st);            // exclusive scan of row_sum
 
 int scan_len_padded(int maxlen);

@@ -567,6 +567,7 @@ struct RowGeom {
     int l;
     int64_t bq, nrow0;            // nrow0 = index of the row's first read in the super-batch
     uint32_t row_cells;
+    uint32_t nreads;              // reads of the row (row_cells = nreads * nch)
     uint32_t nvalid;              // reads of the row that exist (the last batch may be short)
     const uint4* cells;
     size_t cell0;                 // index of the row's first cell in the cell array (compact entries: 2 per cell)
@@ -581,6 +582,7 @@ static __device__ __forceinline__ RowGeom row_geom(const FillArgs& a, int64_t r)
     const uint32_t n_lo = part * (uint32_t)a.rpr;
     const uint32_t nreads = (uint32_t)a.batch - n_lo < (uint32_t)a.rpr ? (uint32_t)a.batch - n_lo : (uint32_t)a.rpr;
     g.row_cells = nreads * (uint32_t)a.nch;
+    g.nreads = nreads;
     g.cell0 = (((size_t)g.bq * a.Lout + g.l) * a.batch + n_lo) * a.nch;
     g.cells = a.masks + g.cell0;
     g.nrow0 = g.bq * a.batch + n_lo;
@@ -630,25 +632,47 @@ static __device__ __forceinline__ void for_row_candidates(const RowGeom& g, uint
 // step of the wave - so the candidates still come out in cell order; there is no per-bit loop: an entry yields its candidates with
 // two predicated LDS stores.  The rare half cells with three or more candidates (1.4 % at BASELINE configs[1]) are fetched from
 // the cell array: the loads of a lane's first two are issued before the other entries are written out, the rest on demand.
-template <typename F>
-static __device__ __forceinline__ void for_row_candidates_c(const FillArgs& a, const RowGeom& g, uint16_t* queue, F&& fn) {
+//
+// CGC > 0 (chunk groups, stage_hits_cg): the walk covers only the cells of chunks [cg0, cg0 + CGC) of the row's reads - a "sub-row"
+// of nreads * CGC cells, numbered read-major (sub index i -> read i / CGC, chunk cg0 + i % CGC), which sit CGC dwords at a time,
+// nch dwords apart, in the row's entries; candidate words then carry the sub index.  row_cells = cells of the (sub-)row.
+template <int CGC, typename F>
+static __device__ __forceinline__ void for_row_candidates_c(const FillArgs& a, const RowGeom& g, uint32_t row_cells, uint32_t cg0, uint16_t* queue, F&& fn) {
     const int lane = threadIdx.x & 63;
     constexpr uint32_t CPLC = 8, STEP = 64 * CPLC;
+    constexpr uint32_t CGL = CGC == 4 ? 2 : CGC == 2 ? 1 : 0;
     uint32_t qlen = 0;                                                // wave-uniform
     const uint32_t* ent = (const uint32_t*)a.centries + g.cell0;      // one dword per cell
-    for (uint32_t i0 = 0; i0 < g.row_cells; i0 += STEP) {             // wave-uniform trip count (1 for rows of <= 512 cells)
+    const uint32_t nch = (uint32_t)a.nch;
+    // cell of the row that sub index i stands for
+    auto full = [&](uint32_t i) -> uint32_t { return CGC == 0 ? i : __umul24(i >> CGL, nch) + cg0 + (i & (uint32_t)(CGC - 1)); };
+    for (uint32_t i0 = 0; i0 < row_cells; i0 += STEP) {               // wave-uniform trip count (1 for rows of <= 512 cells)
         const uint32_t idx = i0 + lane * CPLC;
         uint32_t done = 0, tot = 0;                                   // wave-uniform
         // One turn unless the queue is short of room.  A turn starts from the entries in memory again (they come from L2 then), so
         // that nothing but a few scalars lives across the scoring calls of the drain below.
         do {
             uint32_t e[CPLC];
-            if (idx + CPLC <= g.row_cells) {
-                const uint4 v0 = *(const uint4*)(ent + idx), v1 = *(const uint4*)(ent + idx + 4);
-                e[0] = v0.x, e[1] = v0.y, e[2] = v0.z, e[3] = v0.w, e[4] = v1.x, e[5] = v1.y, e[6] = v1.z, e[7] = v1.w;
+            if (idx + CPLC <= row_cells) {
+                if constexpr (CGC == 0) {
+                    const uint4 v0 = *(const uint4*)(ent + idx), v1 = *(const uint4*)(ent + idx + 4);
+                    e[0] = v0.x, e[1] = v0.y, e[2] = v0.z, e[3] = v0.w, e[4] = v1.x, e[5] = v1.y, e[6] = v1.z, e[7] = v1.w;
+                } else if constexpr (CGC == 4) {
+                    const uint32_t* p0 = ent + full(idx);
+                    const uint4 v0 = *(const uint4*)p0, v1 = *(const uint4*)(p0 + nch);
+                    e[0] = v0.x, e[1] = v0.y, e[2] = v0.z, e[3] = v0.w, e[4] = v1.x, e[5] = v1.y, e[6] = v1.z, e[7] = v1.w;
+                } else if constexpr (CGC == 2) {
+                    const uint32_t* p0 = ent + full(idx);
+                    const uint2 v0 = *(const uint2*)p0, v1 = *(const uint2*)(p0 + nch), v2 = *(const uint2*)(p0 + 2 * nch), v3 = *(const uint2*)(p0 + 3 * nch);
+                    e[0] = v0.x, e[1] = v0.y, e[2] = v1.x, e[3] = v1.y, e[4] = v2.x, e[5] = v2.y, e[6] = v3.x, e[7] = v3.y;
+                } else {
+                    const uint32_t* p0 = ent + full(idx);
+#pragma unroll
+                    for (int c = 0; c < (int)CPLC; c++) e[c] = p0[(uint32_t)c * nch];
+                }
             } else {
 #pragma unroll
-                for (int c = 0; c < (int)CPLC; c++) e[c] = idx + c < g.row_cells ? ent[idx + c] : 0u;
+                for (int c = 0; c < (int)CPLC; c++) e[c] = idx + c < row_cells ? ent[full(idx + c)] : 0u;
             }
             // candidates of the lane: the two count fields of a dword are summed in packed form; a count of 3 stands for "popcount
             // in the low 12 bits" and is put right below
@@ -672,11 +696,11 @@ static __device__ __forceinline__ void for_row_candidates_c(const FillArgs& a, c
                 for (int j = 0; j < 2 * (int)CPLC; j++)
                     if ((ovf >> j) & 1u) pc += ((e[j >> 1] >> (16 * (j & 1))) & 0xfffu) - 3u;
                 j0 = (uint32_t)__builtin_ctz(ovf);
-                m0 = ((const uint2*)(g.cells + idx + (j0 >> 1)))[j0 & 1];
+                m0 = ((const uint2*)(g.cells + full(idx + (j0 >> 1))))[j0 & 1];
                 const uint32_t o1 = ovf & (ovf - 1u);
                 if (o1) {
                     j1 = (uint32_t)__builtin_ctz(o1);
-                    m1 = ((const uint2*)(g.cells + idx + (j1 >> 1)))[j1 & 1];
+                    m1 = ((const uint2*)(g.cells + full(idx + (j1 >> 1))))[j1 & 1];
                 }
             }
             const uint32_t inc = wave_incl_scan(pc);
@@ -726,10 +750,10 @@ static __device__ __forceinline__ void for_row_candidates_c(const FillArgs& a, c
                             o2 &= o2 - 1u;
                             uint32_t gq = inc - pc - done;            // the entries before j
                             for (uint32_t i = 0; i < j; i++) {
-                                const uint32_t f = (ent[idx + (i >> 1)] >> (16 * (i & 1))) & 0xffffu;
+                                const uint32_t f = (ent[full(idx + (i >> 1))] >> (16 * (i & 1))) & 0xffffu;
                                 gq += (f >> 12) == 3u ? (f & 0xfffu) : (f >> 12);
                             }
-                            spill(((const uint2*)(g.cells + idx + (j >> 1)))[j & 1], j, gq);
+                            spill(((const uint2*)(g.cells + full(idx + (j >> 1))))[j & 1], j, gq);
                         }
                     }
                 }
@@ -855,7 +879,7 @@ __global__ __launch_bounds__(VF_THREADS) __attribute__((amdgpu_waves_per_eu((LEN
         };
         // (mode 2 keeps the cells: its rows are 64 cells, 8 lanes' worth of entries - measured 0.49 of the HBM peak with entries
         // against 0.53 with cells on the same box)
-        if (MODE != 2 && a.centries) for_row_candidates_c(a, g, queue, on_cand);
+        if (MODE != 2 && a.centries) for_row_candidates_c<0>(a, g, g.row_cells, 0u, queue, on_cand);
         else for_row_candidates<(MODE == 2 ? 1 : 2)>(g, queue, on_cand);
         if (MODE == 2)
             while (win_lo < seg_len) flush();                         // the rest of the run
@@ -868,13 +892,112 @@ __global__ __launch_bounds__(VF_THREADS) __attribute__((amdgpu_waves_per_eu((LEN
     }
 }
 
+// ---- chunk groups: banks whose re-scoring table does not fit the LDS -------------------------------------------------------
+// The table of 512 PWMs of 20 positions is 104 KB, of 2048 PWMs 418 KB: stage_hits<LEN, false, .> gathered it from L2 (2.2x slower per
+// candidate than from LDS; 65 % of a BASELINE configs[4] step in round 3).  Here the bank is cut into GROUPS of CGC chunks of 128 PWMs
+// whose table slice (26 KB per chunk at 20 positions) does fit, and a block serves ONE group for its whole life: it stages the slice
+// once and walks the rows, visiting only its group's cells - CGC entry dwords per read, nch dwords apart.  Rows are 512 / CGC reads x
+// all chunks, so a (row, group) sub-row is 512 cells, one step of the walk.  What the groups of a row find is in the reference's order
+// only inside a group (read, PWM); the record order interleaves the groups read by read (findall's k runs fastest), and
+// emit_records_cg restores it from the staged words themselves.  Counts and staging slots are per (row, group).
+// Blocks -> (group, stripe of rows): the ncg blocks that walk the same rows are neighbours on ONE XCD (block b runs on XCD b % 8), so
+// the 128-byte lines of entries they share - every group reads CGC * 4 bytes of each read's nch * 4 - come from that XCD's L2.
+template <int LEN, int CGC>
+static __device__ __forceinline__ bool score_candidate_cg(const FillArgs& a, const RowGeom& g, const _Float16* tbl, uint32_t cg0, uint32_t cw, bool live,
+                                                          uint32_t& k, uint32_t& nin, uint16_t& sc) {
+    constexpr uint32_t CGL = CGC == 4 ? 2 : CGC == 2 ? 1 : 0;
+    const uint32_t idx = cw >> 7;
+    nin = idx >> CGL;
+    const uint32_t kl = ((idx & (uint32_t)(CGC - 1)) << 7) | (cw & 127u);     // PWM inside the group
+    k = (cg0 << 7) + kl;
+    sc = 0;
+    if (!(live && nin < g.nvalid && (int)k < a.K && (g.l <= a.lim_min || g.l <= a.lim[k]))) return false;
+    uint32_t W[LEN / 4 + 1];
+    const uint32_t* sw = (const uint32_t*)(g.codes + __umul24(nin, (uint32_t)a.pitch));
+#pragma unroll
+    for (int j = 0; j <= LEN / 4; j++) W[j] = sw[j];
+    sc = exact_score<LEN>(tbl + __umul24(kl, (uint32_t)a.tabk_stride), W, g.l);
+    return half_pos(sc);
+}
+
+// MODE: 0 = count the hits of every (row, group); 1 = count and stage them.  A (row, group)'s staging block is
+// [R / 2 dwords: hits per read, 16 bits each][row_slots staged words], R = 512 / CGC reads: the per-read counts are what
+// emit_records_cg needs to interleave the groups, and the wave that scores the hits has them for one LDS atomic each.
+template <int LEN, int CGC, int MODE>
+__global__ __launch_bounds__(VF_THREADS) __attribute__((amdgpu_waves_per_eu(CGC == 1 ? 8 : 4, 8))) void stage_hits_cg(FillArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    constexpr uint32_t R = 512 / CGC;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    uint16_t* queue = (uint16_t*)smem + wv * QN;                      // [VF_WAVES][QN]
+    uint32_t* hist = smem + VF_WAVES * QN / 2;                        // [CGC * 128]
+    uint32_t* rcnt = hist + CGC * 128 + wv * (R / 2);                 // [VF_WAVES][R / 2]: hits per read of the wave's sub-row
+    uint32_t* ltab = hist + CGC * 128 + VF_WAVES * (R / 2);
+    const uint32_t ncg = (uint32_t)a.ncg;
+    const uint32_t xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
+    const uint32_t cg = j % ncg, cg0 = cg * CGC;                      // first chunk of the block's group
+    const int64_t stripe = (int64_t)(j / ncg) * 8 + xcd, nstripes = gridDim.x / ncg;   // gridDim.x is a multiple of 8 * ncg
+    for (int i = tid; i < CGC * 128; i += VF_THREADS) hist[i] = 0;
+    {   // the group's slice of the table (rows of PWMs past K do not exist: the last group may be short)
+        const int k0 = (int)cg0 * 128;
+        const int nk = a.K - k0 < CGC * 128 ? a.K - k0 : CGC * 128;
+        const int ndw = nk > 0 ? nk * (a.tabk_stride / 2) : 0;
+        const uint32_t* src = (const uint32_t*)(a.tabk + (size_t)k0 * a.tabk_stride);
+        for (int i = tid; i < ndw; i += VF_THREADS) ltab[i] = src[i];
+    }
+    __syncthreads();
+    const _Float16* tbl = (const _Float16*)ltab;
+    const size_t sub_stride = (size_t)a.row_slots + R / 2;
+    for (int64_t r = (int64_t)wv * nstripes + stripe; r < a.nrows; r += nstripes * VF_WAVES) {
+        const RowGeom g = row_geom(a, r);
+        uint32_t* blk = MODE == 1 ? a.staging + ((size_t)r * ncg + cg) * sub_stride : nullptr;
+        uint32_t* slots = MODE == 1 ? blk + R / 2 : nullptr;
+        uint32_t nhit = 0;                                            // wave-uniform
+        if (MODE == 1) {
+            for (uint32_t i = lane; i < R / 2; i += 64) rcnt[i] = 0u;
+            wave_lds_sync();
+        }
+        auto on_cand = [&](const uint32_t cw, const bool live) {
+            uint32_t k, nin;
+            uint16_t sc;
+            const bool hit = score_candidate_cg<LEN, CGC>(a, g, tbl, cg0, cw, live, k, nin, sc);
+            const unsigned long long hb = __ballot(hit);
+            if (hit) {
+                if (MODE == 1) {
+                    const uint32_t at = nhit + (uint32_t)__builtin_popcountll(hb & ((1ull << lane) - 1ull));
+                    if (at < (uint32_t)a.row_slots) slots[at] = (cw << 16) | sc;
+                    atomicAdd(&rcnt[nin >> 1], 1u << (16 * (nin & 1u)));
+                }
+                if (a.pwm_counts) atomicAdd(&hist[k - (cg0 << 7)], 1u);
+            }
+            nhit += (uint32_t)__builtin_popcountll(hb);
+        };
+        for_row_candidates_c<CGC>(a, g, g.nreads * (uint32_t)CGC, cg0, queue, on_cand);
+        if (MODE == 1 && nhit) {                                      // (an empty group's counts are never read)
+            wave_lds_sync();
+            for (uint32_t i = lane; i < R / 2; i += 64) blk[i] = rcnt[i];
+        }
+        if (lane == 0) a.row_sum[(size_t)r * ncg + cg] = nhit;
+    }
+    if (a.pwm_counts) {
+        __syncthreads();
+        for (int i = tid; i < CGC * 128; i += VF_THREADS)
+            if (hist[i]) atomicAdd((unsigned long long*)&a.pwm_counts[cg0 * 128 + i], (unsigned long long)hist[i]);
+    }
+}
+
 // exclusive scan of the row counts in three small steps: per 1024 rows, over the block totals, (added back in emit_records)
+// (ncg > 1, chunk groups: a row's count is the sum of its groups')
 __global__ __launch_bounds__(1024) void row_scan_local(const uint32_t* __restrict__ row_sum, int64_t nrows, uint32_t* __restrict__ row_excl,
-                                                       unsigned long long* __restrict__ blk_total) {
+                                                       unsigned long long* __restrict__ blk_total, const int ncg) {
     __shared__ uint32_t wsum[16];
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: the row geometry stays on the scalar unit
     const int64_t i = (int64_t)blockIdx.x * 1024 + tid;
-    const uint32_t v = i < nrows ? row_sum[i] : 0u;
+    uint32_t v = 0u;
+    if (i < nrows) {
+        if (ncg <= 1) v = row_sum[i];
+        else
+            for (int c = 0; c < ncg; c++) v += row_sum[i * ncg + c];
+    }
     const uint32_t inc = wave_incl_scan(v);
     if (lane == 63) wsum[wv] = inc;
     __syncthreads();
@@ -884,7 +1007,7 @@ __global__ __launch_bounds__(1024) void row_scan_local(const uint32_t* __restric
         if (q < wv) wbase += wsum[q];
         tot += wsum[q];
     }
-    if (i < nrows) row_excl[i] = wbase + inc - v;                     // < 2^32: at most 1024 rows x 65536 candidates
+    if (i < nrows) row_excl[i] = wbase + inc - v;                     // < 2^32: at most 1024 rows x 65536 candidates (x 8 reads per row in chunk-group mode)
     if (tid == 0) blk_total[blockIdx.x] = tot;
 }
 __global__ __launch_bounds__(1024) void row_scan_blocks(unsigned long long* __restrict__ blk, int64_t nblk, const int64_t* __restrict__ base_in,
@@ -984,8 +1107,204 @@ __global__ __launch_bounds__(VF_THREADS) void emit_records(FillArgs a) {
                 if (hit) put(row_at + nhit + (uint32_t)__builtin_popcountll(hb & ((1ull << lane) - 1ull)), k, nin, sc);
                 nhit += (uint32_t)__builtin_popcountll(hb);
             };
-            if (a.centries) for_row_candidates_c(a, g, queue, on_cand);
+            if (a.centries) for_row_candidates_c<0>(a, g, g.row_cells, 0u, queue, on_cand);
             else for_row_candidates<2>(g, queue, on_cand);
+        }
+    }
+}
+
+// Chunk groups: staged words -> records.  One wave per row (512 / CGC reads x all chunks).  The groups of a row staged their hits apart,
+// each list in (read, PWM) order; the record order is (read, group, PWM).  With c[g][n] = hits of read n in group g (the headers
+// stage_hits_cg wrote), word j of group g - its read n known from the word - goes to D[n][g] + (j - S[g][n]), D = exclusive scan of c
+// in (n, g) order, S[g] = exclusive scan of c[g] over n.  The wave turns c into E = D - S in LDS (16-bit arithmetic mod 2^16: a row on
+// this path holds at most ncg * row_slots <= 16384 hits), so every word finds its place with one LDS read.
+// The places of consecutive words of a list are a read's worth of records apart, and a store whose 64 lanes go to 64 different lines
+// is 64 requests to the L2: writing the records straight from the lists ran at 1.2 TB/s (9-11 ms of a 33 ms BASELINE configs[4] step,
+// 0.6 ms with the stores taken out).  So the words of 32 reads at a time are first dropped into an LDS window at their places (a
+// 4-byte word + a 1-byte group), and the window then leaves as whole consecutive records, 64 lanes = 768 contiguous bytes, as
+// emit_records writes them.  A row with an overflowed group is re-scored from its entries in the reference's order, as emit_records
+// does it, 512 cells at a time with the table in L2 (rare: more than two hits per cell on average over 512 cells).
+constexpr uint32_t CG_WIN = 768;      // records per LDS window (32 reads x 2048 PWMs at a 1 % hit rate: ~650)
+template <int LEN, int CGC>
+__global__ __launch_bounds__(VF_THREADS) void emit_records_cg(FillArgs a, const int rpr_small) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    constexpr uint32_t R = 512 / CGC, CGL = CGC == 4 ? 2 : CGC == 2 ? 1 : 0, NH = R / 32;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t ncg = (uint32_t)a.ncg;
+    // per wave: the window (words, then group bytes; the slow path's queue shares it), E, the half-block starts
+    uint32_t* W = smem + (size_t)wv * (CG_WIN + CG_WIN / 4);
+    uint8_t* G = (uint8_t*)(W + CG_WIN);
+    uint16_t* queue = (uint16_t*)W;
+    uint32_t* M32 = smem + (size_t)VF_WAVES * (CG_WIN + CG_WIN / 4) + (size_t)wv * (R * ncg / 2);     // [ncg][R] 16-bit, two per dword
+    uint16_t* M = (uint16_t*)M32;
+    uint32_t* Sb = smem + (size_t)VF_WAVES * (CG_WIN + CG_WIN / 4) + (size_t)VF_WAVES * (R * ncg / 2) + (size_t)wv * ((NH + 1) * 17);   // [NH + 1][16 S + 1 D]
+    const _Float16* tb = (const _Float16*)a.tabk;
+    for (int64_t r = (int64_t)blockIdx.x * VF_WAVES + wv; r < a.nrows; r += (int64_t)gridDim.x * VF_WAVES) {
+        const uint32_t c_l = (uint32_t)lane < ncg ? a.row_sum[(size_t)r * ncg + lane] : 0u;
+        const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(c_l), 63);
+        if (tot == 0) continue;
+        const bool big = __ballot(c_l > (uint32_t)a.row_slots) != 0;
+        const RowGeom g = row_geom(a, r);
+        const int64_t row_at = (int64_t)a.blk_base[r >> 10] + a.row_excl[r];
+        const size_t sub_stride = (size_t)a.row_slots + R / 2;
+        const uint32_t* blk0 = a.staging + (size_t)r * ncg * sub_stride;
+        if (!big) {
+            for (uint32_t cg = 0; cg < ncg; cg++) {                   // c[g][n]: the headers stage_hits_cg wrote (zeros for a group without hits)
+                const uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)c_l, (int)cg);
+                const uint32_t* hdr = blk0 + (size_t)cg * sub_stride;
+                for (uint32_t i = lane; i < R / 2; i += 64) M32[cg * (R / 2) + i] = cnt ? hdr[i] : 0u;
+            }
+            wave_lds_sync();
+            uint32_t scar = 0, dcar = 0;                              // lane g: hits of group g in the reads before this block; hits before it
+            for (uint32_t b0 = 0; b0 < R; b0 += 64) {
+                const uint32_t n = b0 + lane;
+                uint32_t t = 0;
+                for (uint32_t cg = 0; cg < ncg; cg++) t += M[cg * R + n];
+                const uint32_t inc = wave_incl_scan(t);
+                uint32_t D = dcar + inc - t;
+                dcar += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+                if ((lane & 31) == 0) Sb[((b0 >> 5) + (lane >> 5)) * 17 + 16] = D;          // where the half block's records start
+                for (uint32_t cg = 0; cg < ncg; cg++) {
+                    const uint32_t c = M[cg * R + n];
+                    const uint32_t incg = wave_incl_scan(c);
+                    const uint32_t S = (uint32_t)__builtin_amdgcn_readlane((int)scar, (int)cg) + incg - c;
+                    if ((lane & 31) == 0) Sb[((b0 >> 5) + (lane >> 5)) * 17 + cg] = S;     // ... and its words in every group's list
+                    M[cg * R + n] = (uint16_t)(D - S);
+                    D += c;
+                    const uint32_t totg = (uint32_t)__builtin_amdgcn_readlane((int)incg, 63);
+                    if ((uint32_t)lane == cg) scar += totg;
+                }
+            }
+            if (lane < 16) Sb[NH * 17 + lane] = scar;
+            if (lane == 16) Sb[NH * 17 + 16] = dcar;
+            wave_lds_sync();
+            const int64_t room = a.cap - row_at;
+            HitRec* hrow = a.hits + row_at;
+            uint16_t* srow = a.hit_scores + row_at;
+            const uint32_t rec_n = (uint32_t)(g.nrow0 + a.n0 + 1), rec_l = (uint32_t)(g.l + 1);
+            auto sb = [&](uint32_t h, uint32_t col) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane((int)Sb[h * 17 + col]); };
+            auto drop = [&](const uint32_t w0, const uint32_t cg, const uint32_t j, const uint32_t ew) {
+                const uint32_t nin = (ew >> 23) >> CGL;
+                const uint32_t dl = ((((uint32_t)M[cg * R + nin] + j) & 0xffffu) - w0) & 0xffffu;
+#if defined(EXP_EMIT) && EXP_EMIT == 2
+                if (dl < CG_WIN && ew == 0x12345u) {                           // experiment: no LDS scatter
+#else
+                if (dl < CG_WIN) {
+#endif
+                    W[dl] = ew;
+                    G[dl] = (uint8_t)cg;
+                }
+            };
+            auto copy_out = [&](const uint32_t w0, const uint32_t nw) {       // window -> records, consecutive lanes = consecutive records
+#pragma unroll
+                for (uint32_t i = 0; i < CG_WIN / 64; i++) {                 // (a fixed trip count: the stores behind a prefetch can be counted)
+                    const uint32_t d = i * 64 + lane;
+                    if (d < nw) {
+                        const uint32_t ew = W[d], cg = G[d];
+                        const uint32_t idx = ew >> 23, nin = idx >> CGL;
+#if defined(EXP_EMIT) && EXP_EMIT == 1
+                        if ((int64_t)(w0 + d) < room && ew == 0x12345u) {      // experiment: no record stores
+#else
+                        if ((int64_t)(w0 + d) < room) {
+#endif
+                            hrow[w0 + d] = HitRec{cg * (CGC * 128) + 1 + ((idx & (uint32_t)(CGC - 1)) << 7) + ((ew >> 16) & 127u), rec_n + nin, rec_l};
+                            srow[w0 + d] = (uint16_t)ew;
+                        }
+                    }
+                }
+            };
+            // A window = as many consecutive half blocks (32 reads) as fit CG_WIN records: the whole row where hits are sparse (one trip
+            // to memory for all its words), one half block at BASELINE configs[4] density.  The words of the NEXT window are requested
+            // before this one is written out, so the trip overlaps the stores.
+            uint32_t hb = 0, he = 0, d_lo = 0, d_hi = 0;
+            uint32_t jlo[8], jhi[8], e[8][2];
+            auto plan = [&](const uint32_t h0) {
+                hb = h0;
+                d_lo = sb(h0, 16);
+                he = h0 + 1;
+                while (he < NH && sb(he + 1, 16) - d_lo <= CG_WIN) he++;
+                d_hi = sb(he, 16);
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const uint32_t cg = (uint32_t)u < ncg ? (uint32_t)u : 0u;
+                    jlo[u] = sb(hb, cg);
+                    jhi[u] = (uint32_t)u < ncg ? sb(he, cg) : jlo[u];
+                    const uint32_t* slots = blk0 + (size_t)cg * sub_stride + R / 2;
+#pragma unroll
+                    for (int v = 0; v < 2; v++) {
+                        const uint32_t j = jlo[u] + 64 * v + lane;
+                        e[u][v] = j < jhi[u] ? slots[j] : 0u;
+                    }
+                }
+            };
+#if defined(EXP_EMIT) && EXP_EMIT == 3
+            if (room > -1000000000) continue;                                  // experiment: nothing after the scans
+#endif
+            plan(0);
+            while (true) {
+                const uint32_t c_hb = hb, c_he = he, c_lo = d_lo, c_hi = d_hi;
+                if (c_hi - c_lo <= CG_WIN) {
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+#pragma unroll
+                        for (int v = 0; v < 2; v++) {
+                            const uint32_t j = jlo[u] + 64 * v + lane;
+                            if (j < jhi[u]) drop(c_lo, (uint32_t)u, j, e[u][v]);
+                        }
+                    }
+                    for (uint32_t cg = 0; cg < ncg; cg++) {          // what the 16 prefetched loads did not cover (wave-uniform, rare)
+                        const uint32_t lo = sb(c_hb, cg) + (cg < 8 ? 128u : 0u), hi = sb(c_he, cg);
+                        if (lo < hi) {
+                            const uint32_t* slots = blk0 + (size_t)cg * sub_stride + R / 2;
+                            for (uint32_t j = lo + lane; j < hi; j += 64) drop(c_lo, cg, j, slots[j]);
+                        }
+                    }
+                    if (c_he < NH) plan(c_he);
+                    wave_lds_sync();
+                    copy_out(c_lo, c_hi - c_lo);
+                    wave_lds_sync();
+                } else {                                             // 32 reads with more than CG_WIN hits: window by window, every word re-read per window
+                    for (uint32_t w0 = c_lo; w0 < c_hi; w0 += CG_WIN) {
+                        for (uint32_t cg = 0; cg < ncg; cg++) {
+                            const uint32_t lo = sb(c_hb, cg), hi = sb(c_he, cg);
+                            const uint32_t* slots = blk0 + (size_t)cg * sub_stride + R / 2;
+                            for (uint32_t j = lo + lane; j < hi; j += 64) drop(w0, cg, j, slots[j]);
+                        }
+                        wave_lds_sync();
+                        copy_out(w0, c_hi - w0 < CG_WIN ? c_hi - w0 : CG_WIN);
+                        wave_lds_sync();
+                    }
+                    if (c_he < NH) plan(c_he);
+                }
+                if (c_he >= NH) break;
+            }
+        } else {
+            uint32_t nhit = 0;
+            for (uint32_t n_off = 0; n_off < g.nreads; n_off += (uint32_t)rpr_small) {       // wave-uniform
+                RowGeom g2 = g;
+                g2.nreads = g.nreads - n_off < (uint32_t)rpr_small ? g.nreads - n_off : (uint32_t)rpr_small;
+                g2.row_cells = g2.nreads * (uint32_t)a.nch;
+                g2.nrow0 = g.nrow0 + n_off;
+                g2.cell0 = g.cell0 + (size_t)n_off * a.nch;
+                g2.cells = a.masks + g2.cell0;
+                g2.nvalid = g.nvalid > n_off ? (g.nvalid - n_off < g2.nreads ? g.nvalid - n_off : g2.nreads) : 0u;
+                g2.codes = g.codes + (size_t)n_off * a.pitch;
+                auto on_cand = [&](const uint32_t cw, const bool live) {
+                    uint32_t k, nin;
+                    uint16_t sc;
+                    const bool hit = score_candidate<LEN>(a, g2, tb, cw, live, k, nin, sc);
+                    const unsigned long long hb = __ballot(hit);
+                    if (hit) {
+                        const int64_t at = row_at + nhit + (uint32_t)__builtin_popcountll(hb & ((1ull << lane) - 1ull));
+                        if (at < a.cap) {
+                            a.hits[at] = HitRec{k + 1, (uint32_t)(g2.nrow0 + nin + a.n0 + 1), (uint32_t)(g.l + 1)};
+                            a.hit_scores[at] = sc;
+                        }
+                    }
+                    nhit += (uint32_t)__builtin_popcountll(hb);
+                };
+                for_row_candidates_c<0>(a, g2, g2.row_cells, 0u, queue, on_cand);
+            }
         }
     }
 }
@@ -1113,6 +1432,79 @@ static hipError_t launch_emit_len(const FillArgs& a, hipStream_t st) {
     return hipGetLastError();
 }
 
+// ---- chunk-group launchers
+size_t stage_cg_lds_bytes(int cgc, int tabk_stride) {
+    return (size_t)VF_WAVES * QN * 2 + (size_t)cgc * 128 * 4 + (size_t)VF_WAVES * (512 / cgc) * 2 + (((size_t)cgc * 128 * tabk_stride * 2 + 3) & ~(size_t)3);
+}
+int stage_cg_chunks(int K, int nch, int lenp, int tabk_stride, int want) {
+    if (lenp > 20 || lenp % 4 != 0) return 0;                          // compact entries exist for PWMs of up to 20 positions
+    auto ok = [&](int cgc) {
+        // the slice beside the queues in the LDS a CU has; emit_records_cg's count matrix (512 / cgc reads x groups, 16-bit) at most 4 KB per wave
+        return nch % cgc == 0 && stage_cg_lds_bytes(cgc, tabk_stride) <= 160 * 1024 - 1024 && (512 / cgc) * ((nch + cgc - 1) / cgc) <= 2048;
+    };
+    if (want > 0) return (want == 1 || want == 2 || want == 4) && ok(want) ? want : 0;
+    const size_t whole = (size_t)VF_WAVES * QN * 2 + (size_t)2 * nch * 64 * 4 + (((size_t)K * tabk_stride * 2 + 3) & ~(size_t)3);
+    if (whole <= 64 * 1024) return 0;                                  // stage_hits<LEN, true, .> holds the whole table
+    for (int cgc : {2, 1, 4})
+        if (ok(cgc) && (cgc == 4 || stage_cg_lds_bytes(cgc, tabk_stride) <= 64 * 1024)) return cgc;
+    return 0;
+}
+template <int LEN, int CGC>
+static hipError_t launch_stage_cg_t(const FillArgs& a, int mode, hipStream_t st) {
+    const size_t lds = stage_cg_lds_bytes(CGC, a.tabk_stride);
+    const int bpc = (int)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / (lds + 512)));     // blocks a CU holds
+    const int64_t unit = 8 * (int64_t)a.ncg;                            // one block per (XCD, group)
+    int64_t grid = std::max<int64_t>(1, (256 * (int64_t)bpc) / unit) * unit;
+    const int64_t need = ((a.nrows + VF_WAVES - 1) / VF_WAVES + 7) / 8 * unit;     // stripes that have a row, in whole units
+    grid = std::max<int64_t>(unit, std::min(grid, need));
+    if (a.nrows >= (int64_t)1 << 31) return hipErrorInvalidValue;
+    auto k0 = stage_hits_cg<LEN, CGC, 0>;
+    auto k1 = stage_hits_cg<LEN, CGC, 1>;
+    if (lds > 64 * 1024) {
+        (void)hipFuncSetAttribute((const void*)k0, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
+    if (mode == 0) hipLaunchKernelGGL(k0, dim3((unsigned)grid), dim3(VF_THREADS), lds, st, a);
+    else hipLaunchKernelGGL(k1, dim3((unsigned)grid), dim3(VF_THREADS), lds, st, a);
+    return hipGetLastError();
+}
+template <int LEN>
+static hipError_t launch_stage_cg_len(const FillArgs& a, int mode, hipStream_t st) {
+    return a.cgc == 1 ? launch_stage_cg_t<LEN, 1>(a, mode, st) : a.cgc == 2 ? launch_stage_cg_t<LEN, 2>(a, mode, st) : launch_stage_cg_t<LEN, 4>(a, mode, st);
+}
+template <int LEN, int CGC>
+static hipError_t launch_emit_cg_t(const FillArgs& a, hipStream_t st) {
+    const size_t lds = (size_t)VF_WAVES * (CG_WIN + CG_WIN / 4) * 4 + (size_t)VF_WAVES * (512 / CGC) * a.ncg * 2 + (size_t)VF_WAVES * (512 / CGC / 32 + 1) * 17 * 4;
+    if (lds > 160 * 1024 - 1024 || a.ncg > 16) return hipErrorInvalidValue;
+    const unsigned grid = (unsigned)std::min<int64_t>((a.nrows + VF_WAVES - 1) / VF_WAVES, 256 * 8);
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)emit_records_cg<LEN, CGC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((emit_records_cg<LEN, CGC>), dim3(grid), dim3(VF_THREADS), lds, st, a, stage_row_reads(a.nch));
+    return hipGetLastError();
+}
+template <int LEN>
+static hipError_t launch_emit_cg_len(const FillArgs& a, hipStream_t st) {
+    return a.cgc == 1 ? launch_emit_cg_t<LEN, 1>(a, st) : a.cgc == 2 ? launch_emit_cg_t<LEN, 2>(a, st) : launch_emit_cg_t<LEN, 4>(a, st);
+}
+static hipError_t launch_stage_cg(const FillArgs& a, int mode, hipStream_t st) {
+    if (mode > 1 || !a.centries) return hipErrorInvalidValue;
+    switch (a.lenp) {
+        case 8: return launch_stage_cg_len<8>(a, mode, st);
+        case 12: return launch_stage_cg_len<12>(a, mode, st);
+        case 16: return launch_stage_cg_len<16>(a, mode, st);
+        case 20: return launch_stage_cg_len<20>(a, mode, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+static hipError_t launch_emit_cg(const FillArgs& a, hipStream_t st) {
+    switch (a.lenp) {
+        case 8: return launch_emit_cg_len<8>(a, st);
+        case 12: return launch_emit_cg_len<12>(a, st);
+        case 16: return launch_emit_cg_len<16>(a, st);
+        case 20: return launch_emit_cg_len<20>(a, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
 #define MOTIFS_LEN_SWITCH(lenp, CALL)       \
     switch (lenp) {                         \
         case 8: return CALL(8);             \
@@ -1128,17 +1520,19 @@ static hipError_t launch_emit_len(const FillArgs& a, hipStream_t st) {
     }
 
 hipError_t launch_stage_hits(const FillArgs& a, int mode, hipStream_t st) {
+    if (a.cgc) return launch_stage_cg(a, mode, st);
 #define CALL(LEN) launch_stage_len<LEN>(a, mode, st)
     MOTIFS_LEN_SWITCH(a.lenp, CALL)
 #undef CALL
 }
 hipError_t launch_row_scan(const FillArgs& a, hipStream_t st) {
     const int64_t nblk = (a.nrows + 1023) / 1024;
-    hipLaunchKernelGGL(row_scan_local, dim3((unsigned)nblk), dim3(1024), 0, st, a.row_sum, a.nrows, a.row_excl, a.blk_base);
+    hipLaunchKernelGGL(row_scan_local, dim3((unsigned)nblk), dim3(1024), 0, st, a.row_sum, a.nrows, a.row_excl, a.blk_base, a.cgc ? a.ncg : 1);
     hipLaunchKernelGGL(row_scan_blocks, dim3(1), dim3(1024), 0, st, a.blk_base, nblk, a.base_in, a.total, a.total_host);
     return hipGetLastError();
 }
 hipError_t launch_emit_records(const FillArgs& a, hipStream_t st) {
+    if (a.cgc) return launch_emit_cg(a, st);
 #define CALL(LEN) launch_emit_len<LEN>(a, st)
     MOTIFS_LEN_SWITCH(a.lenp, CALL)
 #undef CALL

@@ -1,0 +1,181 @@
+"""GPU tests added in round 4 (through the C ABI).
+
+Chunk groups: banks whose binary16 re-scoring table does not fit one block's LDS (512 PWMs of 20 positions = 104 KB,
+2048 PWMs = 418 KB) are re-scored group by group (1, 2 or 4 chunks of 128 PWMs per group, each block holding one group's
+slice of the table in LDS) and the record order (findall's: start l, read, PWM; _h3_1_alignment.jl:82) is restored from the
+staged words.  `MOTIFS_CG_CHUNKS=c` forces that path on banks of any size, so every group size meets the oracle on the
+shapes the other scan tests use; the default (`auto`) is checked at the BASELINE configs[3] / configs[4] bank shapes."""
+import numpy as np
+import pytest
+
+from test_round2_gpu import fast_oracle_hits
+from test_scan_gpu import dev_scan_hits, oracle_hits
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    return torch
+
+
+@pytest.fixture(scope="module", params=[1, 2, 4])
+def cg_ctx(request, pkg):
+    """A context whose hit-record scans take the chunk-group path with groups of `param` chunks wherever a bank can."""
+    import os
+
+    old = os.environ.get("MOTIFS_CG_CHUNKS")
+    os.environ["MOTIFS_CG_CHUNKS"] = str(request.param)
+    try:
+        c = pkg._lib.Context(0)
+    finally:
+        if old is None:
+            del os.environ["MOTIFS_CG_CHUNKS"]
+        else:
+            os.environ["MOTIFS_CG_CHUNKS"] = old
+    c.cg_param = request.param
+    yield c
+    c.close()
+
+
+def _expect_cg(c, nch):
+    """The group size the forced context must have used for a bank of `nch` chunks (0: the bank cannot take it)."""
+    g = c.cg_param
+    return g if nch % g == 0 and (512 // g) * (-(-nch // g)) <= 2048 else 0
+
+
+# K -> chunks of 128 PWMs: 100 -> 1, 200 -> 2, 300 -> 3, 500 -> 4, 700 -> 6, 1000 -> 8
+@pytest.mark.parametrize("N,L,K,lo,hi,batch,alpha", [
+    (70, 64, 100, 8, 12, 16, 0.4),
+    (300, 100, 200, 12, 12, 64, 0.35),
+    (41, 90, 300, 6, 16, 5000, 0.5),
+    (230, 120, 500, 14, 20, 100, 0.3),      # rows of 100 reads: partial rows, several parts per batch
+    (1100, 60, 700, 8, 20, 600, 0.4),       # 600-read batches: rows of 512 / 256 / 128 reads + a short one
+    (97, 77, 1000, 8, 8, 33, 0.45),
+])
+def test_forced_chunk_groups_match_the_oracle(torch_cuda, cg_ctx, pkg, N, L, K, lo, hi, batch, alpha):
+    sy = pkg.synth
+    codes = sy.gen_codes(N, L, 4100 + K, n_plant=3, k=min(10, L))
+    codes[N // 2, L // 3] = 4
+    pwms, lens = sy.gen_pwm_bank(K, 4200 + K, len_lo=lo, len_hi=hi, alpha=alpha)
+    bank = sy.pad_bank(pwms, lens)
+    nch = -(-K // 128)
+    for rc in (False, True):
+        h, s, counts = dev_scan_hits(torch_cuda, cg_ctx, pkg, bank, lens, codes, rc, batch, want_counts=True)
+        plan = cg_ctx.scan_plan()
+        assert plan["cg_chunks"] == _expect_cg(cg_ctx, nch), plan
+        if plan["cg_chunks"]:
+            assert plan["compact"] and plan["cg_groups"] == -(-nch // plan["cg_chunks"])
+        oh, os_ = fast_oracle_hits(bank, lens, codes, rc, batch)
+        assert len(oh) > 200
+        assert np.array_equal(h, oh) and np.array_equal(s, os_)
+        assert np.array_equal(counts, np.bincount(oh[:, 0] - 1, minlength=K))
+
+
+def test_forced_chunk_groups_overflowing_rows(torch_cuda, cg_ctx, pkg):
+    """Every other PWM strictly positive: each of its windows is a hit, far more per (row, group) than the staging slots
+    hold, so those rows are re-scored in record order by emit_records_cg's slow path; sparse PWMs share the bank."""
+    sy = pkg.synth
+    N, L, K = 130, 50, 512
+    codes = sy.gen_codes(N, L, 77, n_plant=2, k=8)
+    codes[3, 10] = 4
+    pwms, lens = sy.gen_pwm_bank(K, 78, len_lo=6, len_hi=12, alpha=0.4)
+    rng = np.random.default_rng(5)
+    for k in range(0, K, 2):
+        pwms[k] = np.abs(pwms[k]) + rng.uniform(0.01, 0.5, size=pwms[k].shape).astype(pwms[k].dtype)
+    bank = sy.pad_bank(pwms, lens)
+    for rc in (False, True):
+        h, s, counts = dev_scan_hits(torch_cuda, cg_ctx, pkg, bank, lens, codes, rc, 64, want_counts=True)
+        assert cg_ctx.scan_plan()["cg_chunks"] == cg_ctx.cg_param
+        oh, os_ = fast_oracle_hits(bank, lens, codes, rc, 64)
+        assert len(oh) > N * 20 * (K // 2)
+        assert np.array_equal(h, oh) and np.array_equal(s, os_)
+        assert np.array_equal(counts, np.bincount(oh[:, 0] - 1, minlength=K))
+
+
+def test_forced_chunk_groups_short_buffer_and_super_batches(torch_cuda, cg_ctx, pkg):
+    """cap below the record count: the needed count comes back and nothing is written past cap; a workspace bound that
+    forces several launches gives the single-launch records."""
+    sy, lib, torch = pkg.synth, pkg._lib, torch_cuda
+    N, L, K = 900, 60, 512
+    codes = sy.gen_codes(N, L, 9, n_plant=2, k=8)
+    pwms, lens = sy.gen_pwm_bank(K, 10, len_lo=8, len_hi=16, alpha=0.45)
+    bank = sy.pad_bank(pwms, lens)
+    h, s = dev_scan_hits(torch, cg_ctx, pkg, bank, lens, codes, False, 100)
+    n = len(h)
+    assert n > 5000 and cg_ctx.scan_plan()["launches"] == 1
+    oh, os_ = fast_oracle_hits(bank, lens, codes, False, 100)
+    assert np.array_equal(h, oh) and np.array_equal(s, os_)
+    raw = torch.from_numpy(codes).cuda()
+    dcodes = torch.zeros(lib.Context.codes_bytes(N, L), dtype=torch.uint8, device="cuda")
+    cg_ctx.encode_dev(raw.data_ptr(), lib.DATA_CODES_U8, N, L, dcodes.data_ptr())
+    cap = n // 2
+    hits = torch.zeros((n, 3), dtype=torch.int32, device="cuda")
+    sc = torch.zeros(n, dtype=torch.int16, device="cuda")
+    with pytest.raises(lib.MotifsError) as ei:
+        cg_ctx.pwm_scan_hits_dev(bank, lens, dcodes.data_ptr(), N, L, False, hits.data_ptr(), sc.data_ptr(), cap, batch=100)
+    assert ei.value.code == lib.ERR_BUFFER_TOO_SMALL
+    needed = cg_ctx.pwm_scan_hits_dev(bank, lens, dcodes.data_ptr(), N, L, False, hits.data_ptr(), sc.data_ptr(), cap, batch=100,
+                                      allow_small=True)
+    assert needed == n
+    cg_ctx.synchronize()
+    assert not hits[cap:].any() and not sc[cap:].any(), "records past cap were written"
+    assert np.array_equal(hits[:cap].cpu().numpy().astype(np.uint32), oh[:cap])
+    try:
+        per_batch = (L - 8 + 1) * 100 * 4 * 16
+        cg_ctx.set_workspace_limit(3 * per_batch)          # cells + entries + staged words of ~2 batches per launch
+        h2, s2 = dev_scan_hits(torch, cg_ctx, pkg, bank, lens, codes, False, 100)
+        assert cg_ctx.scan_plan()["launches"] >= 4
+        assert np.array_equal(h2, oh) and np.array_equal(s2, os_)
+    finally:
+        cg_ctx.set_workspace_limit(0)
+
+
+def test_both_strands_entry_with_forced_chunk_groups(torch_cuda, cg_ctx, pkg):
+    sy, lib, torch = pkg.synth, pkg._lib, torch_cuda
+    N, L, K = 600, 100, 256
+    codes = sy.gen_codes(N, L, 31, n_plant=3, k=10)
+    pwms, lens = sy.gen_pwm_bank(K, 32, len_lo=10, len_hi=12, alpha=0.35)
+    bank = sy.pad_bank(pwms, lens)
+    raw = torch.from_numpy(codes).cuda()
+    dcodes = torch.zeros(lib.Context.codes_bytes(N, L), dtype=torch.uint8, device="cuda")
+    cg_ctx.encode_dev(raw.data_ptr(), lib.DATA_CODES_U8, N, L, dcodes.data_ptr())
+    need = cg_ctx.pwm_scan_hits_both_dev(bank, lens, dcodes.data_ptr(), N, L, None, None, 0, batch=250)
+    cap = max(need)
+    hits = [torch.zeros((cap, 3), dtype=torch.int32, device="cuda") for _ in range(2)]
+    scs = [torch.zeros(cap, dtype=torch.int16, device="cuda") for _ in range(2)]
+    cnt = torch.zeros((2, K), dtype=torch.int64, device="cuda")
+    got = cg_ctx.pwm_scan_hits_both_dev(bank, lens, dcodes.data_ptr(), N, L, [t.data_ptr() for t in hits], [t.data_ptr() for t in scs],
+                                        cap, batch=250, counts_ptr=cnt.data_ptr())
+    cg_ctx.synchronize()
+    assert got == need and cg_ctx.scan_plan()["cg_chunks"] == _expect_cg(cg_ctx, 2)
+    for rc in (0, 1):
+        oh, os_ = fast_oracle_hits(bank, lens, codes, bool(rc), 250)
+        assert np.array_equal(hits[rc][:got[rc]].cpu().numpy().astype(np.uint32), oh)
+        assert np.array_equal(scs[rc][:got[rc]].cpu().numpy().view(np.uint16), os_)
+        assert np.array_equal(cnt[rc].cpu().numpy(), np.bincount(oh[:, 0] - 1, minlength=K))
+
+
+@pytest.mark.parametrize("K,L,lo,hi,N,batch", [(512, 500, 20, 20, 300, 5000), (2048, 1000, 8, 20, 40, 16)])
+def test_large_banks_take_chunk_groups_by_default(torch_cuda, ctx, pkg, K, L, lo, hi, N, batch):
+    """BASELINE configs[3] / configs[4] bank shapes on the default context: the table does not fit the LDS, the scan goes
+    group by group, and the records are the CPU port's (and, on the first reads, the literal restatement's)."""
+    sy = pkg.synth
+    codes = sy.gen_codes(N, L, 50400 + K, n_plant=5, k=20)
+    pwms, lens = sy.gen_pwm_bank(K, 50400 + K, len_lo=lo, len_hi=hi, alpha=0.3)
+    bank = sy.pad_bank(pwms, lens)
+    for rc in (False, True):
+        h, s, counts = dev_scan_hits(torch_cuda, ctx, pkg, bank, lens, codes, rc, batch, want_counts=True)
+        plan = ctx.scan_plan()
+        assert plan["compact"] and plan["cg_chunks"] in (1, 2, 4) and plan["cg_groups"] == (K // 128) // plan["cg_chunks"], plan
+        oh, os_ = fast_oracle_hits(bank, lens, codes, rc, batch)
+        assert len(oh) > 20000
+        assert np.array_equal(h, oh) and np.array_equal(s, os_)
+        assert np.array_equal(counts, np.bincount(oh[:, 0] - 1, minlength=K))
+    lh, ls = oracle_hits(pkg, bank, lens, codes[:3], True, batch)
+    keep = h[:, 1] <= 3
+    order = np.lexsort((h[keep][:, 0], h[keep][:, 1], h[keep][:, 2]))
+    assert np.array_equal(h[keep][order], lh) and np.array_equal(s[keep][order], ls)
