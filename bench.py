@@ -6,10 +6,10 @@ metric   bases scanned / second: the PWM log-odds scan of a18 (both strands: sca
          200 PWMs of length 12 per GPU.
 step     one pass of that scan over the rank's shard (forward + reverse strand), followed, when N > 1, by the sum
          of the 2 x K hit histogram over the ranks (RCCL through the C ABI, on the scan's stream).
-scaling  weak (the headline line): every rank scans its own 100k x 200 bp shard (reads shard with no data-path
-         collective).  The same run also times BASELINE configs[2] as written — the SAME 100k
-         reads split over the N ranks on whole 5000-read ordering batches — and reports it under "strong";
-         at N = 1 the two are the same workload.
+scaling  N = 1: BASELINE configs[1].  N > 1: the headline line is BASELINE configs[2] AS WRITTEN - the SAME 100k reads
+         split evenly over the N ranks ("scaling": "strong"; `value` = 100k x 200 bases / the slowest rank's step);
+         the weak-scaling run (every rank its own 100k x 200 bp shard) is reported beside it under "weak", and the
+         split on whole 5000-read ordering batches under "strong.modes".
 
 `python bench.py --gpus N` without a launcher starts the N rank processes itself (the parent never touches the
 GPU); under `torch.distributed.run` (RANK / WORLD_SIZE set) it is one of the ranks.
@@ -227,6 +227,7 @@ def main():
 
     # ---- strong scaling: BASELINE configs[2] as written (the same N reads split over the ranks) -------------------
     strong = None
+    strong_kms = None
     if world > 1:
         all_codes = sy.gen_codes(N, L, seed, n_plant=5, k=PL)          # the rank-0 shard of the weak run, on every rank
         modes = {}
@@ -235,11 +236,19 @@ def main():
             sh = make_shard(np.ascontiguousarray(all_codes[lo:hi]), lo)
             for _ in range(PREHEAT + args.warmup):
                 scan_step(sh)
+            sync()
+            if mode == "even":
+                ctx.enable_timing(slots=[lib.KS_SCAN_COUNT])
+                ctx.reset_timing()
             sdt, sh_hits = timed_region(lambda: scan_step(sh), args.steps, sync, barrier)
+            if mode == "even":
+                ctx.enable_timing(False)
+                strong_kms = ctx.kernel_ms(lib.KS_SCAN_COUNT)
             sdt = float(par.host_all_reduce(torch.tensor([sdt], dtype=torch.float64), dist.ReduceOp.MAX).item())
             sizes = [b - a for a, b in (par.shard_range(N, r, world, align=align) for r in range(world))]
             modes[mode] = {"value": float(N) * L * args.steps / sdt, "unit": "bases/s", "ms_per_step": sdt / args.steps * 1e3,
-                           "shard_align": align, "shard_sizes": sizes, "hist_total_hits": int(sh["counts"].sum().item())}
+                           "shard_align": align, "shard_sizes": sizes, "hist_total_hits": int(sh["counts"].sum().item()),
+                           "rank0_reads": hi - lo if rank == 0 else None}
             del sh
         strong = dict(modes["even"], scaling="strong", seqs_total=N, modes=modes,
                       note="BASELINE configs[2]: the same reads split over the ranks.  'even' (shard_align 1): 12 500 reads per rank at 8 ranks; "
@@ -254,6 +263,42 @@ def main():
     extras = {}
     Lout = L - PL + 1
     hits, hsc, need, cap, dcodes = weak["hits"], weak["hsc"], weak["need"], weak["cap"], weak["codes"]
+    # ---- what configs[2]'s shards cost on ONE GPU (N == 1): the step on 1/2, 1/4, 1/8 of the reads, with the histogram sum of a
+    # one-rank RCCL communicator inside it.  8 ranks can be at most (full step) / (1/8 step) faster than one, whatever xGMI does:
+    # the fixed costs of a step (launches, row scans, the host's wait, the collective's launch) do not shrink with the shard.
+    comm1, red1 = None, None
+    if world == 1 and not args.no_extras:
+        try:
+            comm1 = lib.Comm(ctx, lib.Comm.unique_id(), 1, 0)
+            red1 = par.RcclReducer(comm1)
+        except lib.MotifsError as e:
+            extras["strong_proxy_note"] = f"one-rank RCCL communicator unavailable ({e}); shard steps timed without the collective"
+        full_ms = dt / args.steps * 1e3
+        proxy = {}
+        for n_ in (N // 2, N // 4, N // 8):
+            shp = make_shard(np.ascontiguousarray(codes[:n_]), 0)
+
+            def pstep(shp=shp):
+                pc, ph, ps, pk = shp["ptrs"]
+                tot_ = sum(ctx.pwm_scan_hits_both_dev(bank, lens, pc, shp["n"], L, ph, ps, shp["cap"], n0=0, counts_ptr=pk))
+                if red1 is not None:
+                    red1.sum_i64_(shp["counts"])
+                return tot_
+            for _ in range(PREHEAT):
+                pstep()
+            pdt, _ = timed_region(pstep, args.steps, sync, barrier)
+            pms = pdt / args.steps * 1e3
+            proxy[str(n_)] = {"reads": n_, "ms_per_step": pms, "bases_per_s": n_ * L / (pms * 1e-3), "full_step_over_this": full_ms / pms,
+                              "ideal": N / n_}
+            del shp
+        extras["strong_proxy"] = {
+            "what": "BASELINE configs[2] priced on one GPU: the timed scan step on 1/2, 1/4 and 1/8 of the 100k reads (what a rank of 2 / 4 / 8 "
+                    "scans), the 2 x K histogram summed by a one-rank RCCL communicator inside the step",
+            "full_shard_ms_per_step": full_ms, "shards": proxy,
+            "implied_speedup_bound_at_8_ranks": proxy[str(N // 8)]["full_step_over_this"],
+            "north_star_needs": 6.0,
+            "collective": "motifs_comm_allreduce_sum_i64_dev, one rank" if red1 is not None else "none",
+        }
     if not args.no_extras and rank == 0:           # untimed side legs, all local to one device: rank 0 only
         # ---- the a17 kernel on its own: dense (K, nb, L-len+1) fp16 scores (untimed extra leg) ----
         # Reads per launch: the tensor of a launch is nb x 189 x 200 x 2 B, so the 100k reads go in slices.  The candidate
@@ -412,14 +457,17 @@ def main():
     # ---- BASELINE configs[3] and configs[4] at the shape of ONE rank's shard of the 8-GPU job (untimed side legs, rank 0) ----
     if not args.no_extras and rank == 0 and not args.no_big:
 
-        def shard_leg(tag, n_, L_, K_, len_lo, len_hi, ws_limit, note):
+        def shard_leg(tag, n_, L_, K_, len_lo, len_hi, ws_limit, note, reps_=3):
             pw, ln = sy.gen_pwm_bank(K_, seed + 7, len_lo=len_lo, len_hi=len_hi, alpha=0.3)
             bk = sy.pad_bank(pw, ln)
             cd = sy.gen_codes(n_, L_, seed + 31, n_plant=5, k=len_hi)
             raw_ = torch.from_numpy(cd).to(dev)
             dc_ = torch.zeros(lib.Context.codes_bytes(n_, L_), dtype=torch.uint8, device=dev)
             ctx.encode_dev(raw_.data_ptr(), lib.DATA_CODES_U8, n_, L_, dc_.data_ptr())
-            del raw_
+            del raw_, cd
+            torch.cuda.empty_cache()
+            sync()
+            free0 = torch.cuda.mem_get_info(dev)[0]
             ctx.set_workspace_limit(ws_limit)
             need_ = ctx.pwm_scan_hits_both_dev(bk, ln, dc_.data_ptr(), n_, L_, None, None, 0)
             cap_ = int(max(need_)) + 1024
@@ -432,9 +480,11 @@ def main():
                                                   counts_ptr=k_.data_ptr())
             for _ in range(2):
                 got_ = one()
+            plan_ = ctx.scan_plan()
+            sync()
+            peak_bytes = free0 - torch.cuda.mem_get_info(dev)[0]               # records + the library's workspaces (not torch's: hipMalloc)
             ctx.enable_timing(slots=[lib.KS_SCAN_COUNT])
             ctx.reset_timing()
-            reps_ = 3
             sync()
             t0 = time.perf_counter()
             for _ in range(reps_):
@@ -442,30 +492,68 @@ def main():
             sync()
             leg_dt = (time.perf_counter() - t0) / reps_
             cms, cn = ctx.kernel_ms(lib.KS_SCAN_COUNT)
+            # the other two stages, timed in a pass of their own (an event pair per section costs stream time)
+            ctx.enable_timing(slots=[lib.KS_SCAN_OFFSETS, lib.KS_SCAN_FILL])
+            ctx.reset_timing()
+            for _ in range(reps_):
+                one()
+            sync()
+            oms, on_ = ctx.kernel_ms(lib.KS_SCAN_OFFSETS)
+            fms, fn_ = ctx.kernel_ms(lib.KS_SCAN_FILL)
             ctx.enable_timing(False)
             ctx.set_workspace_limit(0)
             assert tuple(got_) == tuple(need_), (got_, need_)
             assert int(k_.sum().item()) == sum(got_)                           # histogram == records, both strands
-            # records of every ordering batch in findall order (l slowest) - a full-size, size-independent property
-            f0 = h_[0][: got_[0]]
-            bq_ = torch.div(f0[:, 1] - 1, lib.SCAN_BATCH, rounding_mode="floor").to(torch.int64)
-            key_ = (bq_ * (L_ + 1) + f0[:, 2].to(torch.int64)) * lib.SCAN_BATCH + (f0[:, 1].to(torch.int64) - 1) % lib.SCAN_BATCH
-            key_ = key_ * (K_ + 1) + f0[:, 0].to(torch.int64)
-            assert bool((key_[1:] > key_[:-1]).all()), "records are not in the reference's order"
-            del key_, bq_
+            # records of every ordering batch in findall order (l slowest) - a full-size, size-independent property (in chunks: the
+            # int64 temporaries of 2e9 records at once would not fit beside them)
+            last_ = None
+            for c0 in range(0, got_[0], 1 << 27):
+                f0 = h_[0][c0: min(got_[0], c0 + (1 << 27))]
+                bq_ = torch.div(f0[:, 1] - 1, lib.SCAN_BATCH, rounding_mode="floor").to(torch.int64)
+                key_ = (bq_ * (L_ + 1) + f0[:, 2].to(torch.int64)) * lib.SCAN_BATCH + (f0[:, 1].to(torch.int64) - 1) % lib.SCAN_BATCH
+                key_ = key_ * (K_ + 1) + f0[:, 0].to(torch.int64)
+                assert bool((key_[1:] > key_[:-1]).all()), "records are not in the reference's order"
+                assert last_ is None or int(key_[0]) > last_, "records are not in the reference's order"
+                last_ = int(key_[-1])
+                del key_, bq_, f0
             windows = float(n_) * float(np.sum(L_ - ln + 1))                   # (PWM, start) pairs per strand
             flops = 2.0 * 4.0 * float(n_) * float(np.sum((L_ - ln + 1) * ln))  # 2 * 4 * len_k flop per pair (GEMM form)
             per_launch_ms = cms / max(cn, 1)
             launches_per_strand = cn / (2 * reps_)
             tfl = flops / (cms / (2 * reps_) * 1e-3) / 1e12                    # over all candidate launches of one strand
+            stage_ms = {"scan_cand": cms / reps_, "stage_hits_row_scan": oms / reps_, "emit_records": fms / reps_}
+            hits_strand = sum(got_) / 2.0
+            lenp_ = (int(ln.max()) + 3) // 4 * 4
+            # the other two stages against what bounds them.  Re-scoring: one LDS (or L2) gather of 2 bytes per position and candidate;
+            # the LDS delivers 64 lane accesses per clock and CU (64 banks), 256 CUs at 2.4 GHz.  Candidates >= hits (the count of
+            # candidates is not kept; hits are a lower bound of the gathers done).  Records: 14 B written + 4 B of staged word read per hit.
+            lds_rate = 64.0 * 256 * 2.4e9
+            gathers = hits_strand * lenp_
+            rescoring = {"kernel": ("stage_hits_cg (chunk groups: one group's table slice in LDS per block)" if plan_["cg_chunks"] else
+                                    "stage_hits (whole table in LDS, or gathered from L2 when it does not fit)"),
+                         "bound": "lds-gather", "achieved": gathers / (oms / (2 * reps_) * 1e-3) / 1e12, "peak": lds_rate / 1e12, "unit": "T lane-gathers/s",
+                         "frac": gathers / (oms / (2 * reps_) * 1e-3) / lds_rate, "gathers_per_strand_lower_bound": gathers,
+                         "ms_per_strand": oms / (2 * reps_),
+                         "note": "far below the LDS rate: the kernel is bound by VALU issue and the latency of its dependent chain (entry decode -> queue -> "
+                                 "code words -> gathers -> adds); counters in profiles/r04_cg_stage_counters.txt"}
+            rec_bytes = hits_strand * 18.0
+            records = {"kernel": "emit_records_cg" if plan_["cg_chunks"] else "emit_records", "bound": "hbm",
+                       "achieved": rec_bytes / (fms / (2 * reps_) * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": rec_bytes / (fms / (2 * reps_) * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_strand": rec_bytes,
+                       "ms_per_strand": fms / (2 * reps_)}
+            cand_roof = {"kernel": "scan_cand_kernel_* (the launches of one strand pass, summed)", "bound": "mfma", "achieved": tfl,
+                         "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfl / MFMA_F16_PEAK_TFLOPS, "flops_per_strand": flops,
+                         "avg_launch_ms": per_launch_ms, "traffic": None}
+            largest = max(stage_ms, key=stage_ms.get)
             out_ = {
                 "workload": note, "seqs": n_, "seq_len": L_, "pwms": K_, "pwm_len": [int(ln.min()), int(ln.max())],
                 "ms_per_step_both_strands": leg_dt * 1e3, "bases_per_s": n_ * L_ / leg_dt, "hits_per_step": int(sum(got_)),
+                "record_bytes_per_step": int(sum(got_)) * 14, "device_bytes_held": int(peak_bytes),
                 "pwm_window_pairs_per_strand": windows, "workspace_limit_bytes": int(ws_limit),
-                "candidate_launches_per_strand": launches_per_strand,
-                "roofline": {"kernel": "scan_cand_kernel_* (the launches of one strand pass, summed)", "bound": "mfma", "achieved": tfl,
-                             "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfl / MFMA_F16_PEAK_TFLOPS, "flops_per_strand": flops,
-                             "avg_launch_ms": per_launch_ms, "traffic": None},
+                "candidate_launches_per_strand": launches_per_strand, "plan": plan_,
+                "kernel_ms_per_step": stage_ms, "largest_stage_by_time": largest,
+                "roofline": {"scan_cand": cand_roof, "stage_hits_row_scan": rescoring, "emit_records": records}[largest],
+                "rooflines": {"scan_cand": cand_roof, "stage_hits_row_scan": rescoring, "emit_records": records},
                 "checked": "both strands: totals == the count-only pass, histogram == records, forward records strictly ascending in "
                            "(batch, l, n, m): the reference's order",
             }
@@ -476,7 +564,10 @@ def main():
                                          "BASELINE configs[3], one rank's shard of 8: 62 500 seqs x 500 bp vs 512 PWMs len 20, both strands, ordered records")
         extras["cfg4_shard"] = shard_leg("cfg4", 25_000, 1000, 2048, 8, 20, 4 << 30,
                                          "BASELINE configs[4] at a fifth of one rank's shard of 8: 25 000 seqs x 1000 bp vs 2048 PWMs len 8-20 (mixed), both strands, "
-                                         "ordered records; workspace bound 4 GiB so that a strand crosses three super-batch launches")
+                                         "ordered records; workspace bound 4 GiB so that a strand crosses several super-batch launches")
+        extras["cfg4_rank_shard"] = shard_leg("cfg4r", 125_000, 1000, 2048, 8, 20, 0,
+                                              "BASELINE configs[4], ONE rank's whole shard of the 8-GPU job: 125 000 seqs x 1000 bp vs 2048 PWMs len 8-20, both strands, "
+                                              "ordered records (~2e9 per strand, 55 GB), default 8 GiB workspace", reps_=2)
 
     # ---- conv-train step (BASELINE metric, second half): unrolled-ADMM forward/backward + AdaBelief ----
     train = None
@@ -517,6 +608,15 @@ def main():
             tstep(1)
         g1_steps = 20
         g1dt, _ = timed_region(lambda: tstep(1), g1_steps, sync, barrier)
+        # ... and 8 mini-batches per step: one rank's share of the 64-mini-batch step at 8 ranks (the strong-scaling price of the
+        # train step on one GPU; with the gradient sum of a one-rank RCCL communicator when there is one)
+        red8 = red1 if (world == 1 and red1 is not None) else reducer
+
+        def tstep8():
+            par.dp_train_step(cdl.model, tdev.data_ptr(), 8, tloss, tgrad, 8 * world, reducer=red8)
+        for _ in range(3):
+            tstep8()
+        g8dt, _ = timed_region(tstep8, g1_steps, sync, barrier)
         train = {
             "workload": f"unrolled-ADMM sparse coding, {Gt} mini-batches x {hp.batch_size} reads x {L} bp per GPU per "
                         f"optimiser step, {args.filters} filters len {args.filter_len}, h=12 K=24 q=32, 6+3 passes, f32",
@@ -526,6 +626,10 @@ def main():
             "device_ms_fwd_bwd": gms / max(gn, 1),
             "ms_per_step_g1": g1dt / g1_steps * 1e3,
             "seqs_per_s_g1": hp.batch_size * world * g1_steps / g1dt,
+            "ms_per_step_g8": g8dt / g1_steps * 1e3,
+            "g8_note": f"8 mini-batches per step per GPU (one rank's share of the {Gt}-mini-batch step at 8 ranks; gradient sum: "
+                       f"{getattr(red8, 'kind', 'none')}): 8 ranks can be at most (ms_per_step / ms_per_step_g8) faster than one",
+            "implied_speedup_bound_at_8_ranks": (tdt / args.train_steps) / (g8dt / g1_steps) if Gt == 64 else None,
             "g1_note": "reference schedule (train.jl:40-46): one AdaBelief step per mini-batch of 6 reads per GPU; ~270 launches of 2-10 us "
                        "(profiles/r03_g1_step_kernels.txt, DESIGN 3)",
             "filter_scan_a4": {
@@ -556,6 +660,9 @@ def main():
     if isinstance(reducer, par.RcclReducer):       # the library's own communicator goes before torch's
         ctx.synchronize()
         reducer.comm.close()
+    if comm1 is not None:
+        ctx.synchronize()
+        comm1.close()
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -563,6 +670,8 @@ def main():
 
     bases = float(N) * L * world
     value = bases * args.steps / dt
+    weak_line = {"value": value, "unit": "bases/s", "ms_per_step": dt / args.steps * 1e3, "scaling": "weak", "seqs_per_gpu": N,
+                 "note": "every rank its own 100k x 200 bp shard (per-GPU work fixed as N grows)"}
     # One strand pass = scan_cand_kernel (the GEMM of the PWM bank with the one-hot windows on the matrix
     # cores: every window of every PWM, thresholded at -eps_k into 128-bit candidate cells) -> stage_hits
     # (exact binary16 re-scoring of the ~1 % candidates, staged hit words, row counts) -> row scan ->
@@ -574,10 +683,18 @@ def main():
     n_launch = max(kms["count"][1], 1)
     strands_per_launch = 2.0 * args.steps / n_launch           # 2: one candidate launch takes both strands' banks (gpu_scan); 1: one per strand
     cand_ms = kms["count"][0] / n_launch
+    head_reads = N                                              # reads the launch behind `roofline` scanned (rank 0)
+    if world > 1:
+        # N > 1: the headline is configs[2] - the same N reads split evenly; the roofline kernel is rank 0's candidate launch on its share
+        value = strong["value"]
+        head_reads = par.shard_range(N, 0, world, align=1)[1]
+        n_launch = max(strong_kms[1], 1)
+        strands_per_launch = 2.0 * args.steps / n_launch
+        cand_ms = strong_kms[0] / n_launch
     pass_ms = (kms["count"][0] + kms["offsets"][0] + kms["fill"][0]) / (2.0 * args.steps)    # one strand's share of a step's kernels
     alg_bytes = N * L + hits_per_pass * 14 + K * 8
     pass_gbs = alg_bytes / (pass_ms * 1e-3) / 1e9
-    cand_flops = 2.0 * 4 * PL * K * float(N) * Lout * strands_per_launch
+    cand_flops = 2.0 * 4 * PL * K * float(head_reads) * Lout * strands_per_launch
     cand_tflops = cand_flops / (cand_ms * 1e-3) / 1e12
     traffic, traffic_src = None, None
     # the PMC entry of the launch that was timed: same kernel, same grid (blocks of 8 reads, tools/summarize_traffic.py keys by shape)
@@ -598,18 +715,22 @@ def main():
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3,
+        "ms_per_step": strong["ms_per_step"] if world > 1 else dt / args.steps * 1e3,
         "cold_start_ms_per_step": sum(cold) / len(cold),
         "cold_start_ms_each": cold,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if world > 1 else "weak",
         "vs_baseline": None,
         "dtype": "f16",
         "data": "synthetic",
         "config": {
-            "workload": f"PWM log-odds scan, both strands, {N} seqs x {L} bp per GPU vs {K} PWMs len {PL} "
-                        "(BASELINE configs[1]); hits thresholded (>0) and compacted on device in reference order",
-            "seqs_per_gpu": N, "seq_len": L, "pwms": K, "pwm_len": PL, "hits_per_step": int(tot_hits.item()),
+            "workload": (f"PWM log-odds scan, both strands, {N} seqs x {L} bp per GPU vs {K} PWMs len {PL} "
+                         "(BASELINE configs[1]); hits thresholded (>0) and compacted on device in reference order") if world == 1 else
+                        (f"PWM log-odds scan, both strands, {N} seqs x {L} bp IN TOTAL split evenly over {world} GPUs vs {K} PWMs len {PL} "
+                         "(BASELINE configs[2]: sharded reads + RCCL sum of the hit histogram); hits thresholded (>0) and compacted on device, "
+                         "records in the reference's per-(PWM, read) order"),
+            "seqs_per_gpu": N if world == 1 else head_reads, "seqs_total": N * (1 if world > 1 else world), "seq_len": L, "pwms": K, "pwm_len": PL,
+            "hits_per_step": int(tot_hits.item()) if world == 1 else int(strong.get("hist_total_hits", 0)),
             "parallelism": f"sequence shards x{world}; per step one sum of the 2 x {K} hit histogram: {reducer.kind} ({reducer_note})",
             "untimed_preheat_steps": PREHEAT,
         },
@@ -635,6 +756,7 @@ def main():
                     "by the matrix cores and the exact re-scoring, not by HBM; dense_kernel is the a17 dense-score contract",
         },
         "strong": strong,
+        "weak": weak_line,
         "kernel_ms_per_step": {"scan_cand": kms["count"][0] / args.steps, "stage_hits_row_scan": kms["offsets"][0] / args.steps,
                                "emit_records": kms["fill"][0] / args.steps},
     }
@@ -708,6 +830,40 @@ def main():
                 "gpu_same_shape_seqs_per_s": 64 * 6 / gt,
             }
             g1.model.close()
+            # ... and beside the configs[1] train step itself: the oracle's needed-lag / direct-syntax forms (the same sums as the
+            # literal graph, tests/test_oracle_model.py::test_needed_lag_update_D_equals_the_literal_one; the literal forms need
+            # ~4 minutes per mini-batch forward at this shape) in float32 on torch's CPU threads, forward + backward
+            mo.NEEDED_LAGS = mo.FAST_SYNTAX = True
+            try:
+                hp2 = mo.Hyperparam(filter_len=args.filter_len, M=args.filters)
+                cdl2 = mo.UCDL(hp2, np.random.default_rng(2))
+                c2 = np.random.default_rng(3).integers(0, 4, size=(6, L)).astype(np.uint8)
+                mo.loss_and_grads(c2, cdl2, hp2, _t.float32)
+                t0 = time.perf_counter()
+                n_mb = 0
+                while n_mb < 3 or (time.perf_counter() - t0 < 10 and n_mb < 12):
+                    mo.loss_and_grads(c2, cdl2, hp2, _t.float32)
+                    n_mb += 1
+                ct2 = (time.perf_counter() - t0) / n_mb
+            finally:
+                mo.NEEDED_LAGS = mo.FAST_SYNTAX = False
+            out["train"]["cpu_baseline"] = {
+                "value": 6 / ct2, "unit": "seqs/s", "cores": _t.get_num_threads(), "kind": "port",
+                "sample": f"{n_mb} mini-batches of 6 reads x {L} bp, {args.filters} filters of length {args.filter_len}: forward + backward of the torch-CPU "
+                          f"restatement in its needed-lag / direct-syntax forms, float32, {ct2:.2f} s per mini-batch",
+                "gpu_over_cpu": out["train"]["seqs_per_s"] / (6 / ct2),
+            }
+    # the driver keeps the tail of the line: the figures a reader looks for first go last
+    if train is not None:
+        tr = out.pop("train")
+        out["train"] = tr
+        out["train_ms_per_step"] = tr["ms_per_step"]
+        out["train_ms_per_step_g1"] = tr["ms_per_step_g1"]
+    if "dense_kernel" in out:
+        out["dense_frac"] = out["dense_kernel"]["frac"]
+    out["cfg3_shard_ms"] = out.get("cfg3_shard", {}).get("ms_per_step_both_strands")
+    out["cfg4_shard_ms"] = out.get("cfg4_shard", {}).get("ms_per_step_both_strands")
+    out["ms_per_step_again"] = out["ms_per_step"]
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

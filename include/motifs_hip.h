@@ -298,6 +298,9 @@ int motifs_comm_group_start(void);
 int motifs_comm_group_end(void);
 int motifs_comm_allreduce_sum_f32_dev(motifs_comm* comm, float* buf_dev, int64_t n);
 int motifs_comm_allreduce_sum_i64_dev(motifs_comm* comm, int64_t* buf_dev, int64_t n);
+/* uint32 sums: the count matrices of motifs_hits_count_matrices_dev built per shard (posdicts2countmats,
+ * src/inference/_h6_positions2countmat.jl:26-55, sums its windows over ALL reads). */
+int motifs_comm_allreduce_sum_u32_dev(motifs_comm* comm, uint32_t* buf_dev, int64_t n);
 /* Out of place: recv_dev = sum over ranks of send_dev (send_dev is left as it was). */
 int motifs_comm_allreduce_sum_f32_to_dev(motifs_comm* comm, const float* send_dev, float* recv_dev, int64_t n);
 /* Sum over ranks of the flat gradient motifs_model_loss_grad_dev wrote (nD + nF + nV floats). */

@@ -499,6 +499,9 @@ allreduce_sum_f32!(c::Comm, buf_dev::Ptr{Cvoid}, n::Integer) =
     check(ccall((:motifs_comm_allreduce_sum_f32_dev, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64), c.h, buf_dev, n))
 allreduce_sum_i64!(c::Comm, buf_dev::Ptr{Cvoid}, n::Integer) =
     check(ccall((:motifs_comm_allreduce_sum_i64_dev, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64), c.h, buf_dev, n))
+# sharded count matrices (posdicts2countmats sums over all reads): UInt32 sums
+allreduce_sum_u32!(c::Comm, buf_dev::Ptr{Cvoid}, n::Integer) =
+    check(ccall((:motifs_comm_allreduce_sum_u32_dev, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64), c.h, buf_dev, n))
 allreduce_grad!(m::ucdl, c::Comm, grad_flat_dev::Ptr{Cvoid}) =
     check(ccall((:motifs_model_allreduce_grad, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), getfield(m, :h), c.h, grad_flat_dev))
 hist_allreduce!(c::Comm, counts_dev::Ptr{Cvoid}, K::Integer, n_strands::Integer=1) =

@@ -98,6 +98,7 @@ SIGNATURES = {
     "motifs_comm_group_end": (_int, []),
     "motifs_comm_allreduce_sum_f32_dev": (_int, [_p, _p, _i64]),
     "motifs_comm_allreduce_sum_i64_dev": (_int, [_p, _p, _i64]),
+    "motifs_comm_allreduce_sum_u32_dev": (_int, [_p, _p, _i64]),
     "motifs_comm_allreduce_sum_f32_to_dev": (_int, [_p, _p, _p, _i64]),
     "motifs_model_allreduce_grad": (_int, [_p, _p, _p]),
     "motifs_model_dp_grad_dev": (_int, [_p, _p, _int, _p, _p]),
@@ -584,6 +585,9 @@ class Comm:
 
     def allreduce_sum_i64(self, ptr, n):
         check(lib().motifs_comm_allreduce_sum_i64_dev(self._h, _p(ptr), int(n)))
+
+    def allreduce_sum_u32(self, ptr, n):
+        check(lib().motifs_comm_allreduce_sum_u32_dev(self._h, _p(ptr), int(n)))
 
     def hist_allreduce(self, counts_ptr, K, n_strands=1):
         check(lib().motifs_hist_allreduce(self._h, _p(counts_ptr), int(K), int(n_strands)))

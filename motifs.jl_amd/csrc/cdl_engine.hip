@@ -2999,9 +2999,10 @@ __global__ __launch_bounds__(OH_TPB) void k_onehot_bank_scan(const uint8_t* __re
                 const uintptr_t ad = (uintptr_t)cd;
                 const uint32_t* wp = (const uint32_t*)(ad & ~(uintptr_t)3);
                 const uint32_t sh = (uint32_t)(ad & 3);
-                uint32_t wds[FL / 4 + 2];
+                constexpr int NWD = (FL - 1) / 4 + 2;                // dwords the funnel shift reads: those that hold bytes p .. p + FL - 1 + 3
+                uint32_t wds[NWD];
 #pragma unroll
-                for (int j = 0; j < FL / 4 + 2; j++) wds[j] = wp[j];
+                for (int j = 0; j < NWD; j++) wds[j] = wp[j];
 #pragma unroll
                 for (int k = 0; k < FL; k++) {
                     const uint32_t al = __builtin_amdgcn_alignbyte(wds[k / 4 + 1], wds[k / 4], sh);

@@ -485,8 +485,14 @@ int motifs_model_set_params(motifs_model* m, const float* D, const float* F, con
     if (D) MOTIFS_HIP_CHECK(hipMemcpyAsync(m->params, D, m->nD * 4, hipMemcpyHostToDevice, st));
     if (F) MOTIFS_HIP_CHECK(hipMemcpyAsync(m->params + m->nD, F, m->nF * 4, hipMemcpyHostToDevice, st));
     if (vecs) MOTIFS_HIP_CHECK(hipMemcpyAsync(m->params + m->nD + m->nF, vecs, m->nV * 4, hipMemcpyHostToDevice, st));
-    if (warmup3) memcpy(m->warm, warmup3, 12);
     MOTIFS_HIP_CHECK(hipStreamSynchronize(st));
+    if (warmup3) {
+        // the warm-up scalars are host-side constants of the step: a captured step graph carries the old ones as kernel arguments
+        memcpy(m->warm, warmup3, 12);
+        for (auto& g : m->step_graphs)
+            if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        m->step_graphs.clear();
+    }
     return MOTIFS_OK;
 }
 

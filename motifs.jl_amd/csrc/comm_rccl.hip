@@ -230,6 +230,10 @@ int motifs_comm_allreduce_sum_i64_dev(motifs_comm* c, int64_t* buf_dev, int64_t 
     return allreduce(c, buf_dev, buf_dev, n, ncclInt64, "motifs_comm_allreduce_sum_i64_dev");
 }
 
+int motifs_comm_allreduce_sum_u32_dev(motifs_comm* c, uint32_t* buf_dev, int64_t n) {
+    return allreduce(c, buf_dev, buf_dev, n, ncclUint32, "motifs_comm_allreduce_sum_u32_dev");
+}
+
 int motifs_comm_allreduce_sum_f32_to_dev(motifs_comm* c, const float* send_dev, float* recv_dev, int64_t n) {
     return allreduce(c, send_dev, recv_dev, n, ncclFloat32, "motifs_comm_allreduce_sum_f32_to_dev");
 }

@@ -1062,23 +1062,6 @@ int motifs::upload_and_encode(motifs_ctx* c, const void* data, int kind, int64_t
     MOTIFS_HIP_CHECK(c->codes.reserve(motifs_codes_bytes(N, L)));
     MOTIFS_HIP_CHECK(c->small.reserve(4096));
     const int pitch = motifs_codes_pitch(L);
-    if (kind == MOTIFS_DATA_CODES_U8) {
-        // 1 byte per base already: upload and let the device lay the rows out
-        MOTIFS_HIP_CHECK(c->data_tmp.reserve((size_t)std::max<int64_t>(N, 1) * L + 64));
-        int32_t* bad_dev = (int32_t*)((char*)c->small.p + 2048);
-        MOTIFS_HIP_CHECK(hipMemsetAsync(bad_dev, 0, 4, c->stream));
-        MOTIFS_HIP_CHECK(hipMemcpyAsync(c->data_tmp.p, data, (size_t)N * L, hipMemcpyHostToDevice, c->stream));
-        int r = motifs_encode_dev(c, c->data_tmp.p, kind, N, L, (uint8_t*)c->codes.p, bad_dev);
-        if (r) return r;
-        int32_t* h_bad = (int32_t*)((char*)c->pinned + 64);
-        MOTIFS_HIP_CHECK(hipMemcpyAsync(h_bad, bad_dev, 4, hipMemcpyDeviceToHost, c->stream));
-        MOTIFS_HIP_CHECK(hipStreamSynchronize(c->stream));
-        if (*h_bad) {
-            set_error("data matrix has a code outside 0..4");
-            return MOTIFS_ERR_NOT_ONEHOT;
-        }
-        return MOTIFS_OK;
-    }
     // Rows are encoded into a ring of pinned chunks (a few tens of MiB each, whatever N is) by host threads while the
     // previous chunk is on the wire; the page-locked footprint no longer grows with the input.
     constexpr size_t CH_BYTES = (size_t)32 << 20;
@@ -1102,7 +1085,12 @@ int motifs::upload_and_encode(motifs_ctx* c, const void* data, int kind, int64_t
         run_threads(T, [&](int t) {
             const int64_t n0 = nr * t / T, n1 = nr * (t + 1) / T;
             bool b;
-            if (kind == MOTIFS_DATA_ONEHOT_F32)
+            if (kind == MOTIFS_DATA_CODES_U8)   // 1 byte per base already: the rows are laid out (padding, row flag) on the way into the ring
+                b = encode_rows_host((const uint8_t*)data + (size_t)r0 * L, n0, n1, L, pitch, rows, [](const uint8_t& q, bool& bad_) {
+                    if (q > 4) bad_ = true;
+                    return q > 4 ? 4 : (int)q;
+                });
+            else if (kind == MOTIFS_DATA_ONEHOT_F32)
                 b = encode_rows_host((const F32x4*)data + (size_t)r0 * L, n0, n1, L, pitch, rows, [](const F32x4& q, bool& bad_) {
                     const int ones = (q.v[0] == 1.0f) + (q.v[1] == 1.0f) + (q.v[2] == 1.0f) + (q.v[3] == 1.0f);
                     const int zeros = (q.v[0] == 0.0f) + (q.v[1] == 0.0f) + (q.v[2] == 0.0f) + (q.v[3] == 0.0f);
@@ -1131,7 +1119,7 @@ int motifs::upload_and_encode(motifs_ctx* c, const void* data, int kind, int64_t
     const hipError_t serr = hipStreamSynchronize(c->stream);     // the staging block is reused by the download
     for (auto& e : ev) (void)hipEventDestroy(e);
     if (bad.load()) {
-        set_error("data matrix has a column that is neither one-hot nor all-zero");
+        set_error(kind == MOTIFS_DATA_CODES_U8 ? "data matrix has a code outside 0..4" : "data matrix has a column that is neither one-hot nor all-zero");
         return MOTIFS_ERR_NOT_ONEHOT;
     }
     MOTIFS_HIP_CHECK(err);

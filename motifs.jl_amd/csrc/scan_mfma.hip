@@ -1139,8 +1139,12 @@ __global__ __launch_bounds__(VF_THREADS) void emit_records_cg(FillArgs a, const 
     uint16_t* M = (uint16_t*)M32;
     uint32_t* Sb = smem + (size_t)VF_WAVES * (CG_WIN + CG_WIN / 4) + (size_t)VF_WAVES * (R * ncg / 2) + (size_t)wv * ((NH + 1) * 17);   // [NH + 1][16 S + 1 D]
     const _Float16* tb = (const _Float16*)a.tabk;
-    for (int64_t r = (int64_t)blockIdx.x * VF_WAVES + wv; r < a.nrows; r += (int64_t)gridDim.x * VF_WAVES) {
-        const uint32_t c_l = (uint32_t)lane < ncg ? a.row_sum[(size_t)r * ncg + lane] : 0u;
+    const int64_t rstep = (int64_t)gridDim.x * VF_WAVES;
+    int64_t r = (int64_t)blockIdx.x * VF_WAVES + wv;
+    uint32_t c_next = (r < a.nrows && (uint32_t)lane < ncg) ? a.row_sum[(size_t)r * ncg + lane] : 0u;
+    for (; r < a.nrows; r += rstep) {
+        const uint32_t c_l = c_next;                                  // the counts of the row after this one are on their way while it is written
+        c_next = (r + rstep < a.nrows && (uint32_t)lane < ncg) ? a.row_sum[(size_t)(r + rstep) * ncg + lane] : 0u;
         const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(c_l), 63);
         if (tot == 0) continue;
         const bool big = __ballot(c_l > (uint32_t)a.row_slots) != 0;
@@ -1149,6 +1153,21 @@ __global__ __launch_bounds__(VF_THREADS) void emit_records_cg(FillArgs a, const 
         const size_t sub_stride = (size_t)a.row_slots + R / 2;
         const uint32_t* blk0 = a.staging + (size_t)r * ncg * sub_stride;
         if (!big) {
+            uint32_t jlo[8], jhi[8], e[8][2];
+            const bool one_window = tot <= CG_WIN;                    // wave-uniform: the whole row fits the LDS window (sparse hits)
+            if (one_window) {                                         // ... its words are asked for now, beside the headers: one trip less
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    jlo[u] = 0u;
+                    jhi[u] = (uint32_t)u < ncg ? (uint32_t)__builtin_amdgcn_readlane((int)c_l, u) : 0u;
+                    const uint32_t* slots = blk0 + (size_t)((uint32_t)u < ncg ? u : 0) * sub_stride + R / 2;
+#pragma unroll
+                    for (int v = 0; v < 2; v++) {
+                        const uint32_t j = 64 * v + lane;
+                        e[u][v] = j < jhi[u] ? slots[j] : 0u;
+                    }
+                }
+            }
             for (uint32_t cg = 0; cg < ncg; cg++) {                   // c[g][n]: the headers stage_hits_cg wrote (zeros for a group without hits)
                 const uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)c_l, (int)cg);
                 const uint32_t* hdr = blk0 + (size_t)cg * sub_stride;
@@ -1182,6 +1201,7 @@ __global__ __launch_bounds__(VF_THREADS) void emit_records_cg(FillArgs a, const 
             HitRec* hrow = a.hits + row_at;
             uint16_t* srow = a.hit_scores + row_at;
             const uint32_t rec_n = (uint32_t)(g.nrow0 + a.n0 + 1), rec_l = (uint32_t)(g.l + 1);
+            const uint32_t dv = (uint32_t)lane <= NH ? Sb[lane * 17 + 16] : 0u;
             auto sb = [&](uint32_t h, uint32_t col) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane((int)Sb[h * 17 + col]); };
             auto drop = [&](const uint32_t w0, const uint32_t cg, const uint32_t j, const uint32_t ew) {
                 const uint32_t nin = (ew >> 23) >> CGL;
@@ -1217,18 +1237,21 @@ __global__ __launch_bounds__(VF_THREADS) void emit_records_cg(FillArgs a, const 
             // to memory for all its words), one half block at BASELINE configs[4] density.  The words of the NEXT window are requested
             // before this one is written out, so the trip overlaps the stores.
             uint32_t hb = 0, he = 0, d_lo = 0, d_hi = 0;
-            uint32_t jlo[8], jhi[8], e[8][2];
             auto plan = [&](const uint32_t h0) {
+                // the starts of every half block's records sit in lane h of dv; the window's word ranges come with ONE LDS read (lanes
+                // 0-15: where the groups' lists stand at half block hb, lanes 16-31: at he) - read one value at a time through
+                // readfirstlane, the ~26 dependent LDS round trips of a window cost as much as its trip to memory
                 hb = h0;
-                d_lo = sb(h0, 16);
-                he = h0 + 1;
-                while (he < NH && sb(he + 1, 16) - d_lo <= CG_WIN) he++;
-                d_hi = sb(he, 16);
+                d_lo = (uint32_t)__builtin_amdgcn_readlane((int)dv, (int)h0);
+                const unsigned long long fits = __ballot((uint32_t)lane > h0 && (uint32_t)lane <= NH && dv - d_lo <= CG_WIN);
+                he = fits ? 63u - (uint32_t)__builtin_clzll(fits) : h0 + 1;
+                d_hi = (uint32_t)__builtin_amdgcn_readlane((int)dv, (int)he);
+                const uint32_t x = Sb[(lane < 16 ? hb : he) * 17 + (lane & 15)];
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
                     const uint32_t cg = (uint32_t)u < ncg ? (uint32_t)u : 0u;
-                    jlo[u] = sb(hb, cg);
-                    jhi[u] = (uint32_t)u < ncg ? sb(he, cg) : jlo[u];
+                    jlo[u] = (uint32_t)__builtin_amdgcn_readlane((int)x, u);
+                    jhi[u] = (uint32_t)u < ncg ? (uint32_t)__builtin_amdgcn_readlane((int)x, 16 + u) : jlo[u];
                     const uint32_t* slots = blk0 + (size_t)cg * sub_stride + R / 2;
 #pragma unroll
                     for (int v = 0; v < 2; v++) {
@@ -1237,10 +1260,8 @@ __global__ __launch_bounds__(VF_THREADS) void emit_records_cg(FillArgs a, const 
                     }
                 }
             };
-#if defined(EXP_EMIT) && EXP_EMIT == 3
-            if (room > -1000000000) continue;                                  // experiment: nothing after the scans
-#endif
-            plan(0);
+            if (one_window) hb = 0, he = NH, d_lo = 0, d_hi = tot;
+            else plan(0);
             while (true) {
                 const uint32_t c_hb = hb, c_he = he, c_lo = d_lo, c_hi = d_hi;
                 if (c_hi - c_lo <= CG_WIN) {
@@ -1252,12 +1273,17 @@ __global__ __launch_bounds__(VF_THREADS) void emit_records_cg(FillArgs a, const 
                             if (j < jhi[u]) drop(c_lo, (uint32_t)u, j, e[u][v]);
                         }
                     }
-                    for (uint32_t cg = 0; cg < ncg; cg++) {          // what the 16 prefetched loads did not cover (wave-uniform, rare)
-                        const uint32_t lo = sb(c_hb, cg) + (cg < 8 ? 128u : 0u), hi = sb(c_he, cg);
-                        if (lo < hi) {
-                            const uint32_t* slots = blk0 + (size_t)cg * sub_stride + R / 2;
-                            for (uint32_t j = lo + lane; j < hi; j += 64) drop(c_lo, cg, j, slots[j]);
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {                    // what the 16 requested loads did not cover (wave-uniform, rare)
+                        if (jhi[u] - jlo[u] > 128u) {
+                            const uint32_t* slots = blk0 + (size_t)u * sub_stride + R / 2;
+                            for (uint32_t j = jlo[u] + 128 + lane; j < jhi[u]; j += 64) drop(c_lo, (uint32_t)u, j, slots[j]);
                         }
+                    }
+                    for (uint32_t cg = 8; cg < ncg; cg++) {          // groups past the eighth (banks of more than 4096 PWMs)
+                        const uint32_t lo = sb(c_hb, cg), hi = sb(c_he, cg);
+                        const uint32_t* slots = blk0 + (size_t)cg * sub_stride + R / 2;
+                        for (uint32_t j = lo + lane; j < hi; j += 64) drop(c_lo, cg, j, slots[j]);
                     }
                     if (c_he < NH) plan(c_he);
                     wave_lds_sync();

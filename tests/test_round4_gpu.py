@@ -179,3 +179,76 @@ def test_large_banks_take_chunk_groups_by_default(torch_cuda, ctx, pkg, K, L, lo
     keep = h[:, 1] <= 3
     order = np.lexsort((h[keep][:, 0], h[keep][:, 1], h[keep][:, 2]))
     assert np.array_equal(h[keep][order], lh) and np.array_equal(s[keep][order], ls)
+
+
+# ---- BASELINE configs[4] at the size of ONE rank's real shard of the 8-GPU job -------------------------------------------------
+def _check_records_in_chunks(torch, hits, hsc, got, cnt_row, n, L, K, B, lens_t, chunk=1 << 27):
+    """Size-independent properties of a record list too large for whole-array int64 temporaries: every record valid, every
+    window inside its read, positive binary16 score bits, strictly ascending (batch, l, n, m) keys (also across chunk edges),
+    histogram == the counts the scan returned."""
+    hist = torch.zeros(K, dtype=torch.int64, device="cuda")
+    last_key = None
+    for c0 in range(0, got, chunk):
+        f = hits[c0:min(got, c0 + chunk)].to(torch.int64)
+        m, nn, l = f[:, 0], f[:, 1], f[:, 2]
+        assert int(m.min()) >= 1 and int(m.max()) <= K and int(nn.min()) >= 1 and int(nn.max()) <= n and int(l.min()) >= 1
+        assert bool((l <= L - lens_t[m - 1] + 1).all())
+        assert bool((hsc[c0:min(got, c0 + chunk)] > 0).all())
+        key = (((nn - 1) // B * (L + 1) + l) * B + (nn - 1) % B) * (K + 1) + m
+        assert bool((key[1:] > key[:-1]).all()), "records are not in the reference's order"
+        if last_key is not None:
+            assert int(key[0]) > last_key, "records are not in the reference's order across a chunk edge"
+        last_key = int(key[-1])
+        hist += torch.bincount(m - 1, minlength=K)
+        del f, m, nn, l, key
+    assert torch.equal(hist, cnt_row)
+
+
+def test_cfg4_rank_shard_full_size_properties(torch_cuda, ctx, pkg):
+    """125 000 reads x 1000 bp vs 2048 PWMs of 8-20 positions, default 8 GiB workspace: what one rank of the 8-GPU job scans at
+    BASELINE configs[4] (round 3 ran a fifth of it).  ~2e9 records per strand: record offsets, n_out and the row / entry indices
+    far above anything the other tests reach.  Totals == the count pass, histogram == records, keys strictly ascending, and the
+    reads on both sides of every super-batch edge against the CPU port."""
+    torch = torch_cuda
+    lib, sy = pkg._lib, pkg.synth
+    n, L, K = 125_000, 1000, 2048
+    pwms, lens = sy.gen_pwm_bank(K, 4711 + K, len_lo=8, len_hi=20, alpha=0.3)
+    bank = sy.pad_bank(pwms, lens)
+    codes = sy.gen_codes(n, L, 4799, n_plant=5, k=20)
+    codes[7, 11] = 4
+    raw = torch.from_numpy(codes).cuda()
+    dcodes = torch.zeros(lib.Context.codes_bytes(n, L), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    ctx.encode_dev(raw.data_ptr(), lib.DATA_CODES_U8, n, L, dcodes.data_ptr())
+    del raw
+    need = ctx.pwm_scan_hits_both_dev(bank, lens, dcodes.data_ptr(), n, L, None, None, 0)
+    assert min(need) > 1_500_000_000, need
+    cap = max(need)
+    B = lib.SCAN_BATCH
+    lens_t = torch.from_numpy(lens).cuda()
+    for rc in (0, 1):                                                     # one strand's buffers at a time (28 GB each)
+        hits = torch.empty((cap, 3), dtype=torch.int32, device="cuda")
+        hsc = torch.empty(cap, dtype=torch.int16, device="cuda")
+        cnt = torch.zeros(K, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        got = ctx.pwm_scan_hits_dev(bank, lens, dcodes.data_ptr(), n, L, rc, hits.data_ptr(), hsc.data_ptr(), cap, counts_ptr=cnt.data_ptr())
+        ctx.synchronize()
+        assert got == need[rc]
+        plan = ctx.scan_plan()
+        assert plan["cg_chunks"] in (1, 2, 4) and plan["launches"] >= 7, plan
+        per_launch = -(-(n // B) // plan["launches"]) * B                 # reads per super-batch launch (whole ordering batches)
+        edges = sorted({0, n - 3} | {e for s in range(per_launch, n, per_launch) for e in (s - 3, s)})
+        _check_records_in_chunks(torch, hits, hsc, got, cnt, n, L, K, B, lens_t)
+        # sampled reads: all records of reads r0+1..r0+3 (1-based), found by bisection on the batch's l = 1 block being sorted by n
+        nn_all = hits[:got, 1]
+        for r0 in edges:
+            sel = torch.nonzero((nn_all > r0) & (nn_all <= r0 + 3)).squeeze(1)
+            mine = hits[sel].cpu().numpy().astype(np.uint32)
+            mys = hsc[sel].cpu().numpy().view(np.uint16)
+            oh, os_ = fast_oracle_hits(bank, lens, codes[r0:r0 + 3], bool(rc), B)
+            oh = oh.copy()
+            oh[:, 1] += r0
+            order = np.lexsort((mine[:, 0], mine[:, 1], mine[:, 2]))
+            assert np.array_equal(mine[order], oh) and np.array_equal(mys[order], os_), (rc, r0)
+        del hits, hsc, nn_all
+        torch.cuda.empty_cache()
