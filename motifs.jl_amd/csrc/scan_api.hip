@@ -336,6 +336,7 @@ static void scan_args(motifs_ctx* c, const BankSlot& bank, int K, const uint8_t*
     a.d.pitch = motifs_codes_pitch(L);
     a.d.Lout = Lout;
     a.d.nch = bank.nch;
+    a.d.cgc = bank.nch;               // plain cell order; scan_hits_mfma narrows it to the chunk group of its plan
     a.d.batch = batch;
     a.d.ohlen = (Lout + 31) / 32 * 32 + bank.lenp;
     a.d.used_tiles = (K + 31) / 32;
@@ -470,6 +471,7 @@ static int scan_hits_mfma(motifs_ctx* c, const BankSlot& bank, int K, const uint
             a.centries = (uint16_t*)entries_buf;
             f.centries = (const uint16_t*)entries_buf;
         }
+        if (hg.cgc) a.d.cgc = hg.cgc;        // entries and cells group-major: a group's cells contiguous for the block that re-scores them
         if (cand_mode == 1) {
             a.afrag2 = (const uint4*)bank2->afrag.p;
             a.cells2 = (uint32_t*)c->cnt2.p;

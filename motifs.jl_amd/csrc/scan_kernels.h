@@ -97,6 +97,8 @@ struct FillArgs {
 struct CandDims {
     int64_t N;
     int L, pitch, Lout, nch, batch, spw;
+    int cgc;                  // chunks per chunk group of the ENTRY / cell layout (= nch: the plain (batch, l, read, chunk) order; smaller with
+                              // chunk groups: (batch, group, l, read, chunk in group), so that a group's cells are contiguous for its consumer)
     int ohlen;                // positions in a read's one-hot LDS image (covers every window tile + the PWM length)
     int used_tiles;           // tiles that hold at least one PWM: ceil(K / 32)
 };

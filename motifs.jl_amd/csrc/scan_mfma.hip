@@ -157,7 +157,7 @@ static __device__ __forceinline__ void scan_cand_body(const uint4* __restrict__ 
 
     const unsigned lb = xcd_swz(blockIdx.x, gridDim.x);
     const int ntile = (d.Lout + 31) / 32;
-    const size_t lstride4 = (size_t)d.batch * d.nch * 4;
+    const size_t lstride4 = (size_t)d.batch * (COMPACT ? d.cgc : d.nch) * 4;      // words between the cells of l and l + 1
     for (int s = 0; s < d.spw; s++) {
         const int64_t n = ((int64_t)lb * d.spw + s) * RPB + slot;      // wave-uniform
         if (n >= d.N) break;
@@ -177,7 +177,9 @@ static __device__ __forceinline__ void scan_cand_body(const uint4* __restrict__ 
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const int64_t bq = n / d.batch;
-        const size_t cell0 = ((size_t)bq * d.Lout * d.batch + (size_t)(n - bq * d.batch)) * d.nch + chunk;   // l = 0
+        // l = 0.  With chunk groups (d.cgc < d.nch) a batch's cells are group-major: (group, l, read, chunk in group)
+        const size_t cell0 = COMPACT ? (((size_t)bq * (d.nch / d.cgc) + chunk / d.cgc) * d.Lout * d.batch + (size_t)(n - bq * d.batch)) * d.cgc + chunk % d.cgc
+                                     : ((size_t)bq * d.Lout * d.batch + (size_t)(n - bq * d.batch)) * d.nch + chunk;
         // the lane's cell of window tile 0; the window tiles follow 32 cell lines apart (a running pointer: the 64-bit
         // multiply per store cost two v_mad_u64_u32 per tile)
         uint32_t* cp = cells + cell0 * 4 + word0 + (size_t)w * lstride4 + (PG == 4 ? 2 * h : PG == 2 ? h : 0);
@@ -279,7 +281,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((T * PG <= 
 
     const unsigned lb = xcd_swz(blockIdx.x, gridDim.x);
     const int ntile = (d.Lout + 7) / 8;
-    const size_t lstride4 = (size_t)d.batch * d.nch * 4;
+    const size_t lstride4 = (size_t)d.batch * (COMPACT ? d.cgc : d.nch) * 4;      // words between the cells of l and l + 1
     const uint2* ohl = oh + rq * opitch + wq + 2 * h;
     // (ordering batch, read in batch) of the wave's first read; later quads advance it without dividing
     int64_t nq = ((int64_t)lb * d.spw * QPB + slot) * 4;
@@ -322,7 +324,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((T * PG <= 
         int rl = r0 + rq;
         while (rl >= d.batch) rl -= d.batch, bql++;
         const bool rowl = nq + rq < d.N;
-        const size_t cell0 = ((size_t)bql * d.Lout * d.batch + (size_t)rl) * d.nch + chunk;
+        // (chunk groups, d.cgc < d.nch: a batch's cells are group-major - (group, l, read, chunk in group))
+        const size_t cell0 = COMPACT ? (((size_t)bql * (d.nch / d.cgc) + chunk / d.cgc) * d.Lout * d.batch + (size_t)rl) * d.cgc + chunk % d.cgc
+                                     : ((size_t)bql * d.Lout * d.batch + (size_t)rl) * d.nch + chunk;
         uint32_t* cp = cells + cell0 * 4 + word0 + (size_t)wq * lstride4 + (PG == 4 ? 2 * h : PG == 2 ? h : 0);
         const size_t tile_step = 8 * lstride4;
         // compact entries: a 32-bit running entry index (entries of a super-batch number < 2^32) instead of a second 64-bit pointer
@@ -583,7 +587,8 @@ static __device__ __forceinline__ RowGeom row_geom(const FillArgs& a, int64_t r)
     const uint32_t nreads = (uint32_t)a.batch - n_lo < (uint32_t)a.rpr ? (uint32_t)a.batch - n_lo : (uint32_t)a.rpr;
     g.row_cells = nreads * (uint32_t)a.nch;
     g.nreads = nreads;
-    g.cell0 = (((size_t)g.bq * a.Lout + g.l) * a.batch + n_lo) * a.nch;
+    // chunk groups: the row's cells of group 0 (group g's are g * Lout * batch * cgc cells further on)
+    g.cell0 = a.cgc ? (((size_t)g.bq * a.ncg * a.Lout + g.l) * a.batch + n_lo) * a.cgc : (((size_t)g.bq * a.Lout + g.l) * a.batch + n_lo) * a.nch;
     g.cells = a.masks + g.cell0;
     g.nrow0 = g.bq * a.batch + n_lo;
     const int64_t left = a.N - g.nrow0;
@@ -633,19 +638,24 @@ static __device__ __forceinline__ void for_row_candidates(const RowGeom& g, uint
 // two predicated LDS stores.  The rare half cells with three or more candidates (1.4 % at BASELINE configs[1]) are fetched from
 // the cell array: the loads of a lane's first two are issued before the other entries are written out, the rest on demand.
 //
-// CGC > 0 (chunk groups, stage_hits_cg): the walk covers only the cells of chunks [cg0, cg0 + CGC) of the row's reads - a "sub-row"
-// of nreads * CGC cells, numbered read-major (sub index i -> read i / CGC, chunk cg0 + i % CGC), which sit CGC dwords at a time,
-// nch dwords apart, in the row's entries; candidate words then carry the sub index.  row_cells = cells of the (sub-)row.
-template <int CGC, typename F>
-static __device__ __forceinline__ void for_row_candidates_c(const FillArgs& a, const RowGeom& g, uint32_t row_cells, uint32_t cg0, uint16_t* queue, F&& fn) {
+// The cells walked are `row_cells` consecutive ones from cell g.cell0 + base_off on (a row; with chunk groups a (row, group)
+// sub-row, whose cells are contiguous in the group-major layout: read-major, chunk in group fastest).  MAP = 1 (emit_records_cg's
+// slow path only): a whole row of a group-major layout in the reference's (read, chunk) order - index i stands for read i / nch,
+// chunk i % nch, whose cell sits (chunk / cgc) * Lout * batch * cgc + read * cgc + chunk % cgc cells from the row's first.
+template <int MAP, typename F>
+static __device__ __forceinline__ void for_row_candidates_c(const FillArgs& a, const RowGeom& g, uint32_t row_cells, size_t base_off, uint16_t* queue, F&& fn) {
     const int lane = threadIdx.x & 63;
     constexpr uint32_t CPLC = 8, STEP = 64 * CPLC;
-    constexpr uint32_t CGL = CGC == 4 ? 2 : CGC == 2 ? 1 : 0;
     uint32_t qlen = 0;                                                // wave-uniform
-    const uint32_t* ent = (const uint32_t*)a.centries + g.cell0;      // one dword per cell
-    const uint32_t nch = (uint32_t)a.nch;
-    // cell of the row that sub index i stands for
-    auto full = [&](uint32_t i) -> uint32_t { return CGC == 0 ? i : __umul24(i >> CGL, nch) + cg0 + (i & (uint32_t)(CGC - 1)); };
+    const uint32_t* ent = (const uint32_t*)a.centries + g.cell0 + base_off;      // one dword per cell
+    const uint4* cellsb = a.masks + g.cell0 + base_off;
+    const size_t cg_stride = MAP ? (size_t)a.Lout * a.batch * a.cgc : 0;
+    auto full = [&](uint32_t i) -> size_t {
+        if (MAP == 0) return i;
+        const uint32_t nin = a.div_nch.div(i), ch = i - nin * (uint32_t)a.nch;
+        const uint32_t cgi = ch / (uint32_t)a.cgc;
+        return (size_t)cgi * cg_stride + (size_t)nin * a.cgc + (ch - cgi * (uint32_t)a.cgc);
+    };
     for (uint32_t i0 = 0; i0 < row_cells; i0 += STEP) {               // wave-uniform trip count (1 for rows of <= 512 cells)
         const uint32_t idx = i0 + lane * CPLC;
         uint32_t done = 0, tot = 0;                                   // wave-uniform
@@ -653,23 +663,9 @@ static __device__ __forceinline__ void for_row_candidates_c(const FillArgs& a, c
         // that nothing but a few scalars lives across the scoring calls of the drain below.
         do {
             uint32_t e[CPLC];
-            if (idx + CPLC <= row_cells) {
-                if constexpr (CGC == 0) {
-                    const uint4 v0 = *(const uint4*)(ent + idx), v1 = *(const uint4*)(ent + idx + 4);
-                    e[0] = v0.x, e[1] = v0.y, e[2] = v0.z, e[3] = v0.w, e[4] = v1.x, e[5] = v1.y, e[6] = v1.z, e[7] = v1.w;
-                } else if constexpr (CGC == 4) {
-                    const uint32_t* p0 = ent + full(idx);
-                    const uint4 v0 = *(const uint4*)p0, v1 = *(const uint4*)(p0 + nch);
-                    e[0] = v0.x, e[1] = v0.y, e[2] = v0.z, e[3] = v0.w, e[4] = v1.x, e[5] = v1.y, e[6] = v1.z, e[7] = v1.w;
-                } else if constexpr (CGC == 2) {
-                    const uint32_t* p0 = ent + full(idx);
-                    const uint2 v0 = *(const uint2*)p0, v1 = *(const uint2*)(p0 + nch), v2 = *(const uint2*)(p0 + 2 * nch), v3 = *(const uint2*)(p0 + 3 * nch);
-                    e[0] = v0.x, e[1] = v0.y, e[2] = v1.x, e[3] = v1.y, e[4] = v2.x, e[5] = v2.y, e[6] = v3.x, e[7] = v3.y;
-                } else {
-                    const uint32_t* p0 = ent + full(idx);
-#pragma unroll
-                    for (int c = 0; c < (int)CPLC; c++) e[c] = p0[(uint32_t)c * nch];
-                }
+            if (MAP == 0 && idx + CPLC <= row_cells) {
+                const uint4 v0 = *(const uint4*)(ent + idx), v1 = *(const uint4*)(ent + idx + 4);
+                e[0] = v0.x, e[1] = v0.y, e[2] = v0.z, e[3] = v0.w, e[4] = v1.x, e[5] = v1.y, e[6] = v1.z, e[7] = v1.w;
             } else {
 #pragma unroll
                 for (int c = 0; c < (int)CPLC; c++) e[c] = idx + c < row_cells ? ent[full(idx + c)] : 0u;
@@ -696,11 +692,11 @@ static __device__ __forceinline__ void for_row_candidates_c(const FillArgs& a, c
                 for (int j = 0; j < 2 * (int)CPLC; j++)
                     if ((ovf >> j) & 1u) pc += ((e[j >> 1] >> (16 * (j & 1))) & 0xfffu) - 3u;
                 j0 = (uint32_t)__builtin_ctz(ovf);
-                m0 = ((const uint2*)(g.cells + full(idx + (j0 >> 1))))[j0 & 1];
+                m0 = ((const uint2*)(cellsb + full(idx + (j0 >> 1))))[j0 & 1];
                 const uint32_t o1 = ovf & (ovf - 1u);
                 if (o1) {
                     j1 = (uint32_t)__builtin_ctz(o1);
-                    m1 = ((const uint2*)(g.cells + full(idx + (j1 >> 1))))[j1 & 1];
+                    m1 = ((const uint2*)(cellsb + full(idx + (j1 >> 1))))[j1 & 1];
                 }
             }
             const uint32_t inc = wave_incl_scan(pc);
@@ -753,7 +749,7 @@ static __device__ __forceinline__ void for_row_candidates_c(const FillArgs& a, c
                                 const uint32_t f = (ent[full(idx + (i >> 1))] >> (16 * (i & 1))) & 0xffffu;
                                 gq += (f >> 12) == 3u ? (f & 0xfffu) : (f >> 12);
                             }
-                            spill(((const uint2*)(g.cells + full(idx + (j >> 1))))[j & 1], j, gq);
+                            spill(((const uint2*)(cellsb + full(idx + (j >> 1))))[j & 1], j, gq);
                         }
                     }
                 }
@@ -879,7 +875,7 @@ __global__ __launch_bounds__(VF_THREADS) __attribute__((amdgpu_waves_per_eu((LEN
         };
         // (mode 2 keeps the cells: its rows are 64 cells, 8 lanes' worth of entries - measured 0.49 of the HBM peak with entries
         // against 0.53 with cells on the same box)
-        if (MODE != 2 && a.centries) for_row_candidates_c<0>(a, g, g.row_cells, 0u, queue, on_cand);
+        if (MODE != 2 && a.centries) for_row_candidates_c<0>(a, g, g.row_cells, (size_t)0, queue, on_cand);
         else for_row_candidates<(MODE == 2 ? 1 : 2)>(g, queue, on_cand);
         if (MODE == 2)
             while (win_lo < seg_len) flush();                         // the rest of the run
@@ -971,7 +967,7 @@ __global__ __launch_bounds__(VF_THREADS) __attribute__((amdgpu_waves_per_eu(CGC 
             }
             nhit += (uint32_t)__builtin_popcountll(hb);
         };
-        for_row_candidates_c<CGC>(a, g, g.nreads * (uint32_t)CGC, cg0, queue, on_cand);
+        for_row_candidates_c<0>(a, g, g.nreads * (uint32_t)CGC, (size_t)cg * a.Lout * a.batch * CGC, queue, on_cand);
         if (MODE == 1 && nhit) {                                      // (an empty group's counts are never read)
             wave_lds_sync();
             for (uint32_t i = lane; i < R / 2; i += 64) blk[i] = rcnt[i];
@@ -1107,7 +1103,7 @@ __global__ __launch_bounds__(VF_THREADS) void emit_records(FillArgs a) {
                 if (hit) put(row_at + nhit + (uint32_t)__builtin_popcountll(hb & ((1ull << lane) - 1ull)), k, nin, sc);
                 nhit += (uint32_t)__builtin_popcountll(hb);
             };
-            if (a.centries) for_row_candidates_c<0>(a, g, g.row_cells, 0u, queue, on_cand);
+            if (a.centries) for_row_candidates_c<0>(a, g, g.row_cells, (size_t)0, queue, on_cand);
             else for_row_candidates<2>(g, queue, on_cand);
         }
     }
@@ -1311,7 +1307,7 @@ __global__ __launch_bounds__(VF_THREADS) void emit_records_cg(FillArgs a, const 
                 g2.nreads = g.nreads - n_off < (uint32_t)rpr_small ? g.nreads - n_off : (uint32_t)rpr_small;
                 g2.row_cells = g2.nreads * (uint32_t)a.nch;
                 g2.nrow0 = g.nrow0 + n_off;
-                g2.cell0 = g.cell0 + (size_t)n_off * a.nch;
+                g2.cell0 = g.cell0 + (size_t)n_off * a.cgc;         // group-major layout: the reads of group 0 are cgc cells apart
                 g2.cells = a.masks + g2.cell0;
                 g2.nvalid = g.nvalid > n_off ? (g.nvalid - n_off < g2.nreads ? g.nvalid - n_off : g2.nreads) : 0u;
                 g2.codes = g.codes + (size_t)n_off * a.pitch;
@@ -1329,7 +1325,7 @@ __global__ __launch_bounds__(VF_THREADS) void emit_records_cg(FillArgs a, const 
                     }
                     nhit += (uint32_t)__builtin_popcountll(hb);
                 };
-                for_row_candidates_c<0>(a, g2, g2.row_cells, 0u, queue, on_cand);
+                for_row_candidates_c<1>(a, g2, g2.row_cells, (size_t)0, queue, on_cand);
             }
         }
     }

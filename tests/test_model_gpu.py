@@ -1,7 +1,9 @@
 """Parity of the HIP sparse-coding engine (motifs_model_* through the C ABI) against the CPU oracle
 (oracle/model_oracle.py, a restatement of src/model.jl + train.jl + _1_code_retrieval.jl).
-Tolerance: BASELINE.json north_star asks 1e-5 relative for float32 values; gradients are compared
-relative to the largest entry of each array."""
+Tolerance: BASELINE.json north_star asks 1e-5 relative for float32 values.  The tolerances here are set from the ACHIEVED errors
+(tools/parity_errors.py, three runs of every golden on one MI355X; profiles/r04_parity_errors.json): losses 2.5e-7,
+gradients 5.8e-7 of the largest entry of their array, 1.5e-4 element-wise on the entries above 1e-3 of the largest (float32
+cancellation in the D gradient), ZY / X intermediates 1.8e-7 - each bound below is 2-4x its achieved value."""
 import os
 
 import numpy as np
@@ -12,7 +14,11 @@ from oracle import model_oracle as mo
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
-RTOL = 1e-5
+RTOL = 1e-5            # north_star's bar (kept for the GPU-against-GPU comparisons further down)
+LOSS_RTOL = 1e-6       # achieved 2.5e-7
+GRAD_INF = 2e-6        # |got - want|_inf / |want|_inf per array; achieved 5.8e-7
+GRAD_ELEM = 3e-4       # element-wise relative, entries above 1e-3 of the largest; achieved 1.5e-4
+INTER_INF = 1e-6       # ZY / X intermediates; achieved 1.8e-7
 NAMES = ["lambda_sparsity", "kappa_sparsity", "lambda_stepsize", "omega_stepsize", "kappa_stepsize", "D", "F",
          "penalty_xyz", "mu"]
 
@@ -69,6 +75,18 @@ def rel_inf(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
 
 
+def rel_elem(a, b, floor=1e-3):
+    """Largest element-wise relative error over the entries of b above `floor` of its largest."""
+    a, b = np.asarray(a, np.float64).ravel(), np.asarray(b, np.float64).ravel()
+    big = np.abs(b) > floor * max(np.abs(b).max(), 1e-300)
+    return float((np.abs(a - b)[big] / np.abs(b)[big]).max()) if big.any() else 0.0
+
+
+def assert_grad(got, want, name):
+    assert rel_inf(got, want) <= GRAD_INF, (name, rel_inf(got, want))
+    assert rel_elem(got, want) <= GRAD_ELEM, (name, rel_elem(got, want))
+
+
 def tiny(seed, G=2, B=3, Lbp=30):
     hp = mo.Hyperparam(filter_len=4, M=5, h=3, K=4, q=6, batch_size=B, num_pass_xyz=2, num_pass_df=2)
     rng = np.random.default_rng(seed)
@@ -89,7 +107,7 @@ def test_tiny_loss_grads_and_intermediates(ctx, pkg, seed):
     want = {n: 0.0 for n in NAMES}
     for g in range(G):
         val, grads = mo.loss_and_grads(codes[g * B:(g + 1) * B], cdl_o, hp, torch.float64)
-        assert abs(loss[g] - val.item()) <= RTOL * abs(val.item()), (g, loss[g], val.item())
+        assert abs(loss[g] - val.item()) <= LOSS_RTOL * abs(val.item()), (g, loss[g], val.item())
         for n, gr in zip(NAMES, grads):
             want[n] = want[n] + gr.numpy()
         # intermediates of this mini-batch
@@ -98,11 +116,11 @@ def test_tiny_loss_grads_and_intermediates(ctx, pkg, seed):
             _, Z, Y, X = mo.retrieve_code(S, cdl_o.to(torch.float64), hp, ln, projs)
         zy = torch.cat((Z[..., 0::4], Y[..., 0::4]), dim=1).permute(0, 2, 1).numpy()      # [B][c][2M]
         gzy = cdl.model.dump("ZY").reshape(G, B, ln.c, hp.twoM)[g]
-        assert rel_inf(gzy, zy) <= RTOL
+        assert rel_inf(gzy, zy) <= INTER_INF
         gx = cdl.model.dump("X").reshape(G, B, ln.l, hp.K)[g]
-        assert rel_inf(gx, X[:, :, 0, :].permute(0, 2, 1).numpy()) <= RTOL
+        assert rel_inf(gx, X[:, :, 0, :].permute(0, 2, 1).numpy()) <= INTER_INF
     for n in NAMES:                      # the flat gradient is the SUM over the mini-batches
-        assert rel_inf(got[n], want[n]) <= 5 * RTOL, (n, rel_inf(got[n], want[n]))
+        assert_grad(got[n], want[n], n)
 
 
 @pytest.mark.parametrize("i", [0, 1, 2])
@@ -122,10 +140,10 @@ def test_mid_shapes_golden(ctx, pkg, i):
     loss, flat = gpu_loss_grad(pkg, ctx, cdl, g[f"s{i}_codes"], G)
     got = split_grad(cdl, flat)
     for k in range(G):
-        assert abs(loss[k] - g[f"s{i}_loss{k}"]) <= RTOL * g[f"s{i}_loss{k}"]
+        assert abs(loss[k] - g[f"s{i}_loss{k}"]) <= LOSS_RTOL * g[f"s{i}_loss{k}"]
     for n in NAMES:
         want = g[f"s{i}_grad_{n}"].astype(np.float64)
-        assert rel_inf(got[n], want) <= 5 * RTOL, (n, rel_inf(got[n], want))
+        assert_grad(got[n], want, n)
     cdl.model.close()
 
 
@@ -141,15 +159,15 @@ def test_cfg1_golden(ctx, pkg):
     loss, flat = gpu_loss_grad(pkg, ctx, cdl, codes, 2)
     got = split_grad(cdl, flat)
     for k in range(2):
-        assert abs(loss[k] - g[f"loss{k}"]) <= RTOL * g[f"loss{k}"]
+        assert abs(loss[k] - g[f"loss{k}"]) <= LOSS_RTOL * g[f"loss{k}"]
     for n in NAMES:
         want = g[f"grad0_{n}"] + g[f"grad1_{n}"]
-        assert rel_inf(got[n], want) <= 5 * RTOL, (n, rel_inf(got[n], want))
+        assert_grad(got[n], want, n)
     # code retrieval: positions / filters / sequence numbers exact, magnitudes to one fp16 ulp
     rec = pkg.model.code_retrieval(codes, cdl)
     assert np.array_equal(np.stack([rec["position"], rec["fil"], rec["seq"]], 1).astype(np.int64), g["codes_rec"])
     d = np.abs(rec["mag"].view(np.uint16).astype(np.int64) - g["codes_mag"].astype(np.int64))
-    assert d.max() <= 1
+    assert d.max() <= 1 and (d == 1).sum() <= max(1, len(d) // 100)      # achieved: 0 of 384 magnitudes differ (r04_parity_errors.json)
 
 
 def test_cfg2_golden(ctx, pkg):
@@ -164,9 +182,9 @@ def test_cfg2_golden(ctx, pkg):
     cdl = to_model(pkg, ctx, hp, 200, cdl_o)
     loss, flat = gpu_loss_grad(pkg, ctx, cdl, g["codes"], 1)
     got = split_grad(cdl, flat)
-    assert abs(loss[0] - g["loss0"]) <= RTOL * g["loss0"]
+    assert abs(loss[0] - g["loss0"]) <= LOSS_RTOL * g["loss0"]
     for n in NAMES:
-        assert rel_inf(got[n], g[f"grad0_{n}"].astype(np.float64)) <= 5 * RTOL, (n, rel_inf(got[n], g[f"grad0_{n}"]))
+        assert_grad(got[n], g[f"grad0_{n}"].astype(np.float64), n)
     cdl.model.close()
 
 
@@ -185,15 +203,15 @@ def test_cfg3_golden(ctx, pkg):
     try:
         loss, flat = gpu_loss_grad(pkg, ctx, cdl, g["codes"], 1)
         got = split_grad(cdl, flat)
-        assert abs(loss[0] - g["loss0"]) <= RTOL * g["loss0"], (loss[0], g["loss0"])
+        assert abs(loss[0] - g["loss0"]) <= LOSS_RTOL * g["loss0"], (loss[0], g["loss0"])
         for n in NAMES:
             if n == "F":
                 continue
-            assert rel_inf(got[n], g[f"grad0_{n}"].astype(np.float64)) <= 5 * RTOL, (n, rel_inf(got[n], g[f"grad0_{n}"]))
+            assert_grad(got[n], g[f"grad0_{n}"].astype(np.float64), n)
         gf = got["F"].astype(np.float64)
         stride = int(g["grad0_F_sample_stride"])
-        assert np.abs(gf[::stride] - g["grad0_F_sample"].astype(np.float64)).max() <= 5 * RTOL * g["grad0_F_absmax"]
-        assert abs(np.abs(gf).max() - g["grad0_F_absmax"]) <= 5 * RTOL * g["grad0_F_absmax"]
+        assert np.abs(gf[::stride] - g["grad0_F_sample"].astype(np.float64)).max() <= GRAD_INF * g["grad0_F_absmax"]
+        assert abs(np.abs(gf).max() - g["grad0_F_absmax"]) <= GRAD_INF * g["grad0_F_absmax"]
         assert abs((gf * gf).sum() - g["grad0_F_sumsq"]) <= 1e-3 * g["grad0_F_sumsq"]
     finally:
         cdl.model.close()
@@ -217,7 +235,7 @@ def test_cfg2_groups_are_independent(ctx, pkg):
         l1, f1 = gpu_loss_grad(pkg, ctx, cdl, codes[k * B:(k + 1) * B], 1)
         assert abs(l1[0] - loss[k]) <= 1e-6 * abs(loss[k])
         acc += f1
-    assert abs(loss[0] - g["loss0"]) <= RTOL * g["loss0"]
+    assert abs(loss[0] - g["loss0"]) <= LOSS_RTOL * g["loss0"]
     assert rel_inf(flat, acc) <= 1e-5
     cdl.model.close()
 
@@ -238,7 +256,7 @@ def test_tiny_other_pass_counts(ctx, pkg, passes):
     want = {n: 0.0 for n in NAMES}
     for g in range(G):
         val, grads = mo.loss_and_grads(codes[g * B:(g + 1) * B], cdl_o, hp, torch.float64)
-        assert abs(loss[g] - val.item()) <= RTOL * abs(val.item()), (g, loss[g], val.item())
+        assert abs(loss[g] - val.item()) <= LOSS_RTOL * abs(val.item()), (g, loss[g], val.item())
         for n, gr in zip(NAMES, grads):
             want[n] = want[n] + gr.numpy()
     for n in NAMES:
@@ -289,12 +307,12 @@ def test_fused_forms_equal_the_separate_launches(ctx, pkg, tmp_path):
     assert rel_inf(outs["fused"]["flat"], outs["poisoned"]["flat"]) <= 1e-5
 
 
-@pytest.mark.parametrize("G", [16, 40])
+@pytest.mark.parametrize("G", [16, 40, 64])
 def test_step_sizes_take_different_kernels_and_agree(ctx, pkg, G):
     """The engine picks its kernel forms by step size (per-read sparse gradients to 24 mini-batches, 2-row synthesis blocks and
     split row walks below 192 reads, the fused tall form to ~100 reads, fused bank forms for small banks, ...).  The one-mini-batch
     forms are held against the float64 oracle (test_cfg2_golden); here a launch of G mini-batches at the configs[1] shape - 16: the
-    middle forms, 40: the large-step forms - against G launches of one: the same losses, and the sum of the gradients."""
+    middle forms, 40: the large-step forms, 64: the step bench.py times - against G launches of one: the same losses, and the sum of the gradients."""
     md, sy = pkg.model, pkg.synth
     hp = md.Hyperparam(filter_len=12, M=200)
     L = 200
