@@ -19,6 +19,7 @@ EXTRA = {
     # keep MFMA accumulators in VGPRs: the candidate kernel reads every accumulator with VALU right after the
     # chain, and the AGPR form costs one v_accvgpr_read per register (16 extra VALU per 32x32 tile)
     "scan_mfma.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
+    "scan_dense.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
 }
 
 

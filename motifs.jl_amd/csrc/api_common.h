@@ -89,6 +89,7 @@ struct motifs_ctx {
     bool compact_cells = true;      // MOTIFS_DENSE_CELLS=1 turns them off (the round-2 round trip through the 128-bit cells)
     motifs::DevBuf cnt2, centries2; // the reverse strand's cells / entries when one candidate launch serves both strands of gpu_scan
     int cg_chunks = -1;             // chunk groups of the re-scoring (scan_mfma.hip): -1 = when the table does not fit the LDS; MOTIFS_CG_CHUNKS overrides
+    bool dense_fused = true;        // a17's tensor in one kernel (scan_dense.hip); MOTIFS_DENSE_FUSED=0: candidate kernel + stage_hits<.., 2>
     int32_t scan_plan[4] = {0, 0, 0, 0};   // motifs_ctx_scan_plan
     bool fuse_strands = true;       // MOTIFS_NO_STRAND_FUSION=1: one candidate launch per strand
     motifs::BankSlot bank_slot[2];  // [rc]

@@ -565,6 +565,7 @@ int motifs_ctx_create(int device, motifs_ctx** out) {
     const char* ev = getenv("MOTIFS_SCAN_VALU");
     c->scan_valu = ev && ev[0] == '1';
     if (const char* nc = getenv("MOTIFS_DENSE_CELLS")) c->compact_cells = !(nc[0] == '1');   // A/B: the round-2 cell round trip
+    if (const char* dfv = getenv("MOTIFS_DENSE_FUSED")) c->dense_fused = !(dfv[0] == '0');   // A/B: the two-kernel dense form
     if (const char* cgv = getenv("MOTIFS_CG_CHUNKS")) c->cg_chunks = atoi(cgv);      // chunk groups: 0 = never, 1 / 2 / 4 = that size for every bank that can take it (tests, A/B)
     if (const char* nf = getenv("MOTIFS_NO_STRAND_FUSION")) c->fuse_strands = !(nf[0] == '1');  // A/B: one candidate launch per strand
     if (const char* wl = getenv("MOTIFS_WS_LIMIT_MB")) {       // experiments: the default of motifs_ctx_set_workspace_limit
@@ -715,6 +716,26 @@ int motifs_pwm_scan_dense_dev(motifs_ctx* c, const uint16_t* pwms_fp16, const in
             if (ld_l > lo)  // the l-planes no window reaches (the reference pre-zeroes the tensor, :75)
                 MOTIFS_HIP_CHECK(hipMemsetAsync(scores_dev + (size_t)K * N * lo, 0, (size_t)K * N * (ld_l - lo) * 2, c->stream));
             if (Lout <= 0) return MOTIFS_OK;
+            if (c->dense_fused) {          // filter, exact re-scoring and the write stream in one kernel, when the bank fits its LDS plan
+                DenseFusedArgs d{};
+                d.afrag = (const uint4*)bs->afrag.p;
+                d.tabk = (const uint16_t*)bs->tabk.p;
+                d.lim = (const int32_t*)bs->lim.p;
+                d.codes = codes_dev;
+                d.out = scores_dev;
+                d.N = N;
+                d.L = L;
+                d.pitch = motifs_codes_pitch(L);
+                d.Lout = Lout;
+                d.K = K;
+                d.lim_min = L - bs->maxlen_true;
+                d.ntiles = (K + 31) / 32;
+                d.tabk_stride = bs->tabk_stride;
+                if (dense_fused_plan(d, bs->lenp, bs->uniform_eps)) {
+                    MOTIFS_HIP_CHECK(launch_dense_fused(d, bs->lenp, c->stream));
+                    return MOTIFS_OK;
+                }
+            }
             MOTIFS_HIP_CHECK(c->cnt.reserve(cells_bytes));
             CandArgs a{};
             FillArgs f{};

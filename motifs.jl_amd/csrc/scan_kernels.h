@@ -131,6 +131,21 @@ int stage_cg_chunks(int K, int nch, int lenp, int tabk_stride, int want);
 size_t stage_cg_lds_bytes(int cgc, int tabk_stride);
 hipError_t launch_fill_scan(const FillArgs& a, hipStream_t st);            // exclusive scan of row_sum
 
+// ---- a17's dense tensor in one kernel (scan_dense.hip)
+struct DenseFusedArgs {
+    const uint4* afrag;       // [tiles][T][64] PWM fragments of a bank scaled to one slack (pack_mfma, uniform_eps)
+    const uint16_t* tabk;     // [K][tabk_stride] binary16 re-scoring table
+    const int32_t* lim;       // last valid start per PWM
+    const uint8_t* codes;
+    uint16_t* out;            // (K, N, ld_l) tensor
+    int64_t N;
+    int L, pitch, Lout, K, lim_min, ntiles, tabk_stride;
+    int ohlen, opitch, cpitch;   // derived by dense_fused_plan
+    int l_per_block;             // starts per block (set by the launch: grid.y splits the starts)
+};
+bool dense_fused_plan(DenseFusedArgs& a, int lenp, int uniform_eps);
+hipError_t launch_dense_fused(const DenseFusedArgs& a, int lenp, hipStream_t st);
+
 int scan_len_padded(int maxlen);
 // positions per mask row for windows 0..Lout-1 of padded length lenp
 int scan_lout_padded(int Lout, int lenp);
