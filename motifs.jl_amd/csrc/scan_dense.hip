@@ -27,7 +27,7 @@ namespace motifs {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int DF_READS = 32, DF_WAVES = 4, DF_MAXT = 8;      // reads per block, waves per block, tiles of 32 PWMs a wave may carry
+constexpr int DF_READS = 32, DF_MAXT = 8;      // reads per block, tiles of 32 PWMs a wave may carry (waves per block: 8, or 4 when the LDS is short)
 
 static __device__ __forceinline__ void df_wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -67,16 +67,21 @@ static __device__ __forceinline__ uint32_t df_incl_scan(uint32_t x) {
     return v;
 }
 
-// NT = tiles of 32 PWMs the wave carries (>= the bank's: tiles past it hold zero fragments and are masked off)
-template <int T, int NT>
-__global__ __launch_bounds__(64 * DF_WAVES) __attribute__((amdgpu_waves_per_eu(1, 1))) void scan_dense_fused(const DenseFusedArgs a) {
+// NT = tiles of 32 PWMs the wave carries (>= the bank's: tiles past it hold zero fragments and are masked off); NW = waves per block.
+// The B operand (the one-hot of two positions: 8 binary16 values) comes from a 25-entry table in LDS indexed by the two base codes, which
+// the lane takes from its read's code row: one-hot IMAGES of the 32 reads (57 KB) would leave room for only one 4-wave block per CU, and
+// with one wave per SIMD nothing hides the LDS round trips of a span (measured: 37 % of the wave cycles waiting); without them 8 waves
+// share the code rows and the bank's table, two per SIMD.
+template <int T, int NT, int NW>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4))) void scan_dense_fused(const DenseFusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     constexpr int LEN = 4 * T;
+    constexpr int DF_WAVES = NW;
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
-    // LDS: [images: 32 x opitch x 8 B][code rows: 32 x cpitch B][table: K x stride halves][queues: 4 x DF_QCAP x 2 B][windows: 4 x 32 x K halves]
-    uint2* oh = (uint2*)smem;
-    uint8_t* crow = (uint8_t*)(oh + (size_t)DF_READS * a.opitch);
+    // LDS: [pair table: 25 x 16 B][code rows: 32 x cpitch B][table: K x stride halves][queues: NW x DF_QCAP x 2 B][windows: NW x 32 x K halves]
+    uint4* lut = (uint4*)smem;
+    uint8_t* crow = (uint8_t*)(lut + 32);
     _Float16* tb = (_Float16*)(crow + (size_t)DF_READS * a.cpitch);
     uint16_t* qbase = (uint16_t*)(tb + (((size_t)a.K * a.tabk_stride + 7) & ~(size_t)7));
     uint16_t* queue = qbase + (size_t)wv * DF_QCAP;
@@ -85,12 +90,11 @@ __global__ __launch_bounds__(64 * DF_WAVES) __attribute__((amdgpu_waves_per_eu(1
     const int64_t n0 = (int64_t)blockIdx.x * DF_READS;
     const int nvalid = (int)(a.N - n0 < DF_READS ? a.N - n0 : DF_READS);
 
-    // ---- stage: images + code rows of the block's reads, the table, zeroed windows
+    // ---- stage: the code rows of the block's reads (padding = code 4), the pair table, the bank's table, zeroed windows
     for (int rr = wv; rr < DF_READS; rr += DF_WAVES) {
         const bool row = rr < nvalid;
         const uint32_t* srow = (const uint32_t*)(a.codes + (n0 + rr) * a.pitch);
-        const int pend = a.opitch > a.cpitch ? a.opitch : a.cpitch;    // positions to lay out: the image's and the code row's (padding = code 4)
-        for (int p4 = lane; p4 * 4 < pend; p4 += 64) {
+        for (int p4 = lane; p4 * 4 < a.cpitch; p4 += 64) {
             const int keep = a.L - p4 * 4;
             uint32_t wd = 0x04040404u;
             if (row && keep > 0) {
@@ -100,15 +104,13 @@ __global__ __launch_bounds__(64 * DF_WAVES) __attribute__((amdgpu_waves_per_eu(1
                     wd = (wd & mk) | (0x04040404u & ~mk);
                 }
             }
-            if (p4 * 4 < a.cpitch) *(uint32_t*)(crow + (size_t)rr * a.cpitch + p4 * 4) = wd;
-            const uint32_t sh = wd << 4;             // 16 * code per byte; code 4 -> shift 63: the 1.0 leaves the word
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const uint32_t su = (sh >> (8 * u)) & 0xffu;
-                const uint64_t one = (uint64_t)0x3c00u << (su < 63u ? su : 63u);
-                if (p4 * 4 + u < a.opitch) oh[(size_t)rr * a.opitch + p4 * 4 + u] = make_uint2((uint32_t)one, (uint32_t)(one >> 32));
-            }
+            *(uint32_t*)(crow + (size_t)rr * a.cpitch + p4 * 4) = wd;
         }
+    }
+    if (tid < 25) {                                                    // entry c0 + 5 c1: the one-hot columns of codes c0, c1 (code 4: all zero)
+        const int c0 = tid % 5, c1 = tid / 5;
+        const uint64_t o0 = c0 < 4 ? (uint64_t)0x3c00u << (16 * c0) : 0ull, o1 = c1 < 4 ? (uint64_t)0x3c00u << (16 * c1) : 0ull;
+        lut[tid] = make_uint4((uint32_t)o0, (uint32_t)(o0 >> 32), (uint32_t)o1, (uint32_t)(o1 >> 32));
     }
     {
         const int ndw = (a.K * a.tabk_stride + 1) / 2;
@@ -137,47 +139,76 @@ __global__ __launch_bounds__(64 * DF_WAVES) __attribute__((amdgpu_waves_per_eu(1
     }
     __syncthreads();
 
-    const uint2* ohl = oh + (size_t)j * a.opitch + 2 * h;
+    const uint8_t* cj = crow + (size_t)j * a.cpitch;
     const uint32_t span = (uint32_t)nvalid * (uint32_t)a.K;          // halves of the tensor this block owns per start l
-    // The slack constants of the chains, -4 / 2^(g % 4) (pack_mfma scales tile g by 2^(e - g % 4)), as registers that live through the
-    // loop: with more than four chains the constants repeat, the compiler then shares one splat between two chains and, short of
-    // inline-constant slots, rebuilt every splat inside the loop (16 v_readlane + 8 v_mov_b64 each, ~100 instructions per span).
-    f32x16 cs[NT < 4 ? NT : 4];
+    // The slack constants -4, -2, -1 of the chains as registers that live through the loop (-0.5, used by fewer chains, stays an inline
+    // constant): more than four chains share constants, and a shared splat the compiler parks in lanes of a spare register and rebuilds
+    // for every span (16 v_readlane + 8 v_mov_b64 each: ~70 instructions per span, seen in the ISA).
+    f32x16 cs[3];
 #pragma unroll
-    for (int q = 0; q < (NT < 4 ? NT : 4); q++) {
-        const float cv = q == 0 ? -4.0f : q == 1 ? -2.0f : q == 2 ? -1.0f : -0.5f;
+    for (int q = 0; q < 3; q++) {
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            float x = cv;
-            asm volatile("" : "+v"(x));                                // opaque: a value in a VGPR, not a constant to re-materialise
+            float x = q == 0 ? -4.0f : q == 1 ? -2.0f : -1.0f;
+            asm volatile("" : "+v"(x));
             cs[q][r] = x;
         }
     }
     const int l_lo = blockIdx.y * a.l_per_block, l_hi = l_lo + a.l_per_block < a.Lout ? l_lo + a.l_per_block : a.Lout;
     for (int l = l_lo + wv; l < l_hi; l += DF_WAVES) {
+        // B operand: lane (read j, half h) needs the one-hot columns of positions l + 4 t + 2 h, + 1 of its read
         f16x8 B[T];
+        {
+            uint32_t Wj[T + 1];
+            const uint32_t* sw = (const uint32_t*)(cj + (l & ~3));
 #pragma unroll
-        for (int t = 0; t < T; t++) {
-            const uint2 a0 = ohl[l + 4 * t], a1 = ohl[l + 4 * t + 1];
-            B[t] = __builtin_bit_cast(f16x8, make_uint4(a0.x, a0.y, a1.x, a1.y));
+            for (int q = 0; q <= T; q++) Wj[q] = sw[q];
+#pragma unroll
+            for (int t = 0; t < T; t++) {
+                const uint32_t al = __builtin_amdgcn_alignbyte(Wj[t + 1], Wj[t], (uint32_t)(l & 3)) >> (16 * h);   // codes of l + 4 t + 2 h, + 1 in the low bytes
+                const uint32_t e = (al & 0xffu) + 5u * ((al >> 8) & 0xffu);
+                B[t] = __builtin_bit_cast(f16x8, lut[e]);
+            }
         }
-        // all chains of the wave interleaved (branch-free): the matrix pipe works on one tile while the VALU packs another's signs
-        f32x16 acc[NT];
-#pragma unroll
-        for (int g = 0; g < NT; g++) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[g][0], B[0], cs[g & 3], 0, 0, 0);
-#pragma unroll
-        for (int t = 1; t < T; t++)
-#pragma unroll
-            for (int g = 0; g < NT; g++) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[g][t], B[t], acc[g], 0, 0, 0);
+        // The chains go in groups of four, interleaved inside a group (branch-free): the matrix pipe works on one tile while the VALU packs
+        // another's signs.  Four at a time because each chain of a group then has a slack constant of its own, -4 / 2^(g % 4) (pack_mfma
+        // scales tile g by 2^(e - g % 4)), which the instruction takes as an INLINE constant; and 64 accumulator registers live, not 32 NT.
         uint32_t m[NT];
         uint32_t pc = 0;
 #pragma unroll
-        for (int g = 0; g < NT; g++) {
-            uint32_t mm = 0;
+        for (int g0 = 0; g0 < NT; g0 += 4) {
+            constexpr int dummy = 0;
+            (void)dummy;
+            f32x16 acc[4];
 #pragma unroll
-            for (int r = 15; r >= 0; r--) mm = __builtin_amdgcn_alignbit(mm, __float_as_uint(acc[g][r]), 31);
-            m[g] = mm & vm[g];
-            pc += (uint32_t)__builtin_popcount(m[g]);
+            for (int u = 0; u < 4; u++) {
+                if (g0 + u < NT) {
+                    if (u < 3) {
+                        acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[g0 + u][0], B[0], cs[u], 0, 0, 0);
+                    } else {
+                        f32x16 c;
+#pragma unroll
+                        for (int r = 0; r < 16; r++) c[r] = -0.5f;
+                        acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[g0 + u][0], B[0], c, 0, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int t = 1; t < T; t++)
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (g0 + u < NT) acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[g0 + u][t], B[t], acc[u], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (g0 + u < NT) {
+                    uint32_t mm = 0;
+#pragma unroll
+                    for (int r = 15; r >= 0; r--) mm = __builtin_amdgcn_alignbit(mm, __float_as_uint(acc[u][r]), 31);
+                    m[g0 + u] = mm & vm[g0 + u];
+                    pc += (uint32_t)__builtin_popcount(m[g0 + u]);
+                }
+            }
+            if (g0 + 4 < NT) __builtin_amdgcn_sched_barrier(0);       // (keeps the second group's constants from being shared with the first's)
         }
         // candidates -> a queue in LDS (read j << 8 | PWM), so that the exact scores are formed 64 at a time with every lane busy
         const uint32_t inc = df_incl_scan(pc);
@@ -287,44 +318,52 @@ __global__ __launch_bounds__(64 * DF_WAVES) __attribute__((amdgpu_waves_per_eu(1
     }
 }
 
-size_t dense_fused_lds(const DenseFusedArgs& a) {
-    return (size_t)DF_READS * a.opitch * 8 + (size_t)DF_READS * a.cpitch + ((((size_t)a.K * a.tabk_stride + 7) & ~(size_t)7) * 2) +
-           (size_t)DF_WAVES * DF_QCAP * 2 + (size_t)DF_WAVES * DF_READS * a.K * 2;
+static size_t dense_fused_lds_w(const DenseFusedArgs& a, int nw) {
+    return 32 * 16 + (size_t)DF_READS * a.cpitch + ((((size_t)a.K * a.tabk_stride + 7) & ~(size_t)7) * 2) + (size_t)nw * DF_QCAP * 2 +
+           (size_t)nw * DF_READS * a.K * 2;
 }
+size_t dense_fused_lds(const DenseFusedArgs& a) { return dense_fused_lds_w(a, a.nwaves); }
 
-// the geometry fields the launch derives (ohlen, opitch, cpitch); false if the bank / reads cannot take this kernel
+// the geometry fields the launch derives (cpitch, waves per block); false if the bank / reads cannot take this kernel
 bool dense_fused_plan(DenseFusedArgs& a, int lenp, int uniform_eps) {
     if (!uniform_eps || lenp > 20 || lenp % 4 != 0 || a.K % 8 != 0 || a.ntiles > DF_MAXT || a.K > 32 * DF_MAXT) return false;
-    a.ohlen = a.Lout + lenp;                                     // positions a window tile may touch: l + 4 t + 2 h + 1 <= Lout + lenp - 2
-    a.opitch = ((a.ohlen - 1 + 31) & ~31) + 1;                   // 1 (mod 32) positions = 8 (mod 256) bytes: 32 lanes x 8 B cover the 64 banks once
-    int cp = ((a.L + 3) & ~3) + 4 * ((lenp / 4) + 1);            // the exact re-scoring reads lenp / 4 + 1 dwords from the dword of l
+    a.ohlen = a.Lout + lenp;
+    a.opitch = 0;
+    int cp = ((a.L + 3) & ~3) + 4 * ((lenp / 4) + 1);            // the operand build and the exact re-scoring read lenp / 4 + 1 dwords from the dword of l
     if ((cp / 4) % 2 == 0) cp += 4;                              // an odd number of dwords: the 32 rows start in 32 different banks
     a.cpitch = cp;
-    return dense_fused_lds(a) <= 160 * 1024 - 2048;
+    for (int nw : {8, 4}) {
+        if (nw == 8 && a.ntiles > 4 && lenp >= 16) continue;       // 7-8 tiles of 16-20 positions: the fragments do not fit 256 VGPRs (two waves per SIMD)
+        a.nwaves = nw;
+        if (dense_fused_lds_w(a, nw) <= 160 * 1024 - 1024) return true;
+    }
+    return false;
 }
 
 hipError_t launch_dense_fused(const DenseFusedArgs& a0, int lenp, hipStream_t st) {
     DenseFusedArgs a = a0;
     const size_t lds = dense_fused_lds(a);
     const unsigned gx = (unsigned)((a.N + DF_READS - 1) / DF_READS);
-    // one block per CU at a time: split the starts over grid.y until the launch is at least ~4 rounds of blocks (a block's set-up - 32
-    // images, the table - is ~5 % of a whole read's worth of spans, so halves and quarters are still cheap), so that the last round
-    // is a small share of the launch
+    // one block per CU at a time: split the starts over grid.y until the launch is at least ~4 rounds of blocks (a block's set-up - the
+    // code rows, the table - is a few per cent of a whole read's worth of spans), so that the last round is a small share of the launch
     int ly = 1;
-    while (ly < 8 && (int64_t)gx * ly < 4 * 256 && a.Lout / (ly * 2) >= 4 * DF_WAVES) ly *= 2;
-    a.l_per_block = ((a.Lout + ly - 1) / ly + DF_WAVES - 1) / DF_WAVES * DF_WAVES;
+    while (ly < 8 && (int64_t)gx * ly < 4 * 256 && a.Lout / (ly * 2) >= 4 * a.nwaves) ly *= 2;
+    a.l_per_block = ((a.Lout + ly - 1) / ly + a.nwaves - 1) / a.nwaves * a.nwaves;
     ly = (a.Lout + a.l_per_block - 1) / a.l_per_block;
     const dim3 grid(gx, (unsigned)ly, 1);
-#define DF_LAUNCH(TT, NN)                                                                                                            \
-    {                                                                                                                                \
-        (void)hipFuncSetAttribute((const void*)scan_dense_fused<TT, NN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
-        hipLaunchKernelGGL((scan_dense_fused<TT, NN>), grid, dim3(64 * DF_WAVES), lds, st, a);                                       \
+#define DF_LAUNCH(TT, NN, WW)                                                                                                            \
+    {                                                                                                                                    \
+        (void)hipFuncSetAttribute((const void*)scan_dense_fused<TT, NN, WW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
+        hipLaunchKernelGGL((scan_dense_fused<TT, NN, WW>), grid, dim3(64 * WW), lds, st, a);                                             \
     }
-#define DF_TILES(TT)                                        \
-    if (a.ntiles <= 2) DF_LAUNCH(TT, 2)                     \
-    else if (a.ntiles <= 4) DF_LAUNCH(TT, 4)                \
-    else if (a.ntiles <= 7) DF_LAUNCH(TT, 7)                \
-    else DF_LAUNCH(TT, 8)
+#define DF_WAVESEL(TT, NN)                  \
+    if (a.nwaves == 8) DF_LAUNCH(TT, NN, 8) \
+    else DF_LAUNCH(TT, NN, 4)
+#define DF_TILES(TT)                                         \
+    if (a.ntiles <= 2) DF_WAVESEL(TT, 2)                     \
+    else if (a.ntiles <= 4) DF_WAVESEL(TT, 4)                \
+    else if (a.ntiles <= 7) DF_WAVESEL(TT, 7)                \
+    else DF_WAVESEL(TT, 8)
     switch (lenp) {
         case 8: DF_TILES(2) break;
         case 12: DF_TILES(3) break;
@@ -333,6 +372,7 @@ hipError_t launch_dense_fused(const DenseFusedArgs& a0, int lenp, hipStream_t st
         default: return hipErrorInvalidValue;
     }
 #undef DF_TILES
+#undef DF_WAVESEL
 #undef DF_LAUNCH
     return hipGetLastError();
 }

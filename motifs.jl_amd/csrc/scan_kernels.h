@@ -142,6 +142,7 @@ struct DenseFusedArgs {
     int L, pitch, Lout, K, lim_min, ntiles, tabk_stride;
     int ohlen, opitch, cpitch;   // derived by dense_fused_plan
     int l_per_block;             // starts per block (set by the launch: grid.y splits the starts)
+    int nwaves;                  // waves per block (8, or 4 when the LDS is short: dense_fused_plan)
 };
 bool dense_fused_plan(DenseFusedArgs& a, int lenp, int uniform_eps);
 hipError_t launch_dense_fused(const DenseFusedArgs& a, int lenp, hipStream_t st);
