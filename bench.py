@@ -35,7 +35,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 
 MFMA_F16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak (no sparsity)
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32-input matrix peak (= vector peak), v_mfma_f32_32x32x2_f32
 # PMC traffic per (kernel, launch shape), written by tools/summarize_traffic.py from the passes of tools/profile_round.sh
-TRAFFIC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r03_scan_hbm_traffic.json", "r02_scan_hbm_traffic_by_shape.json")]
+TRAFFIC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r04_scan_hbm_traffic.json", "r03_scan_hbm_traffic.json", "r02_scan_hbm_traffic_by_shape.json")]
+TRAIN_PMC_FILE = os.path.join(ROOT, "profiles", "r04_train_kernels_pmc.json")   # tools/summarize_train_pmc.py
 
 
 def parse():
@@ -392,7 +393,9 @@ def main():
         hbm_copy_gbs = _rate(lambda: hy.copy_(hx), 2 * hx.numel() * 2)
         del hx, hy
         extras["dense_kernel"] = {
-            "kernel": "scan_cand_kernel_q<3,4,2> + stage_hits<12,.,2> (a17 greedy_search! drop-in, writes (K,nb,L-len+1) fp16: zeros + exact scores of the hits, every byte once)",
+            "kernel": "scan_dense_fused<3,7,8> (a17 greedy_search! drop-in in one kernel: MFMA tiles of 32 consecutive reads at one start, candidates re-scored from LDS, "
+                      "the contiguous 32 x K span streamed out of an LDS window: (K,nb,L-len+1) fp16, zeros + exact scores of the hits, every byte once; "
+                      "MOTIFS_DENSE_FUSED=0: scan_cand_kernel_q + stage_hits<12,.,2>)",
             "checked": "positive entries == hit records of the same reads, score checksums equal",
             "bound": "hbm", "achieved": dense_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": dense_gbs / HBM_PEAK_GBS, "frac_of_measured_fill": dense_gbs / hbm_fill_gbs,
@@ -400,7 +403,7 @@ def main():
             "timing": "8 untimed launches, 5 groups of 8 timed (HIP events around each launch); the median group is quoted",
             "groups_gbs_fastest_to_slowest": dense_grp,
             "bases_per_s_one_strand": nb * L / (dense_ms / dense_n * 1e-3),
-            "launch_size_note": "24576 reads = three full rounds of candidate blocks (8 reads per block, 1024 blocks resident)",
+            "launch_size_note": "24576 reads = 768 blocks of 32 reads x 2 halves of the starts = six rounds of one block per CU",
             "at_20k_reads_per_launch": {"achieved": gbs20, "frac": gbs20 / HBM_PEAK_GBS, "avg_launch_ms": ms20 / n20, "seqs_per_launch": nb20,
                                         "groups_gbs_fastest_to_slowest": grp20},
         }
@@ -617,6 +620,19 @@ def main():
         for _ in range(3):
             tstep8()
         g8dt, _ = timed_region(tstep8, g1_steps, sync, barrier)
+        # counter evidence of the step (PMC passes over the same 64-mini-batch step, tools/profile_r04.sh train): HBM bytes of the roofline
+        # kernel per launch, and of the whole step against its time here
+        a7_traffic, step_hbm = None, None
+        if os.path.exists(TRAIN_PMC_FILE) and (Gt, L, args.filters, args.filter_len) == (64, 200, 200, 12):
+            with open(TRAIN_PMC_FILE) as fh:
+                tp = json.load(fh)
+            for e in tp["kernels"]:
+                if e["kernel"].startswith("k_ana_lds") and e["blocks"] > 1000:
+                    a7_traffic = (e["hbm_read_bytes"] + e["hbm_write_bytes"]) / e["launches"]
+            step_hbm = {"bound": "hbm", "bytes_per_step_by_pmc": tp["step"]["hbm_bytes"], "achieved": tp["step"]["hbm_bytes"] / (tdt / args.train_steps) / 1e9,
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": tp["step"]["hbm_bytes"] / (tdt / args.train_steps) / 1e9 / HBM_PEAK_GBS,
+                        "launches_per_step": tp["step"]["launches"], "source": {"file": os.path.relpath(TRAIN_PMC_FILE, ROOT), "commit": tp.get("commit")},
+                        "note": "counter bytes of one step (2 x FETCH_SIZE + WRITE_SIZE over every kernel of the step) / the step time measured here"}
         train = {
             "workload": f"unrolled-ADMM sparse coding, {Gt} mini-batches x {hp.batch_size} reads x {L} bp per GPU per "
                         f"optimiser step, {args.filters} filters len {args.filter_len}, h=12 K=24 q=32, 6+3 passes, f32",
@@ -644,9 +660,12 @@ def main():
                           "reduction = h * 2M)",
                 "bound": "mfma", "achieved": a7_flops / (a7_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": a7_flops / (a7_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, "avg_launch_ms": a7_ms, "flops_per_launch": a7_flops,
-                "reads_per_launch": St, "traffic": None,
+                "reads_per_launch": St, "traffic": a7_traffic,
                 "note": "algorithmic flops 2 * l * K * h * 2M per read (SURVEY 8d); the kernel pads K 24 -> 32 and l 178 -> 192",
             },
+            "step_hbm": step_hbm,
+            "arena_peak_bytes": cdl.model.arena_peak(),
+            "arena_peak_GiB_per_mini_batch": cdl.model.arena_peak() / Gt / 2**30,
             "loss_first_group": float(tloss[0].item()),
             "grad_allreduce_floats": int(cdl.model.nP) if world > 1 else 0,
             "reference_schedule_equivalent": f"{Gt * world} reference steps (batch 6) worth of reads per step",

@@ -269,6 +269,9 @@ int motifs_model_time_filter_scan(motifs_model* m, const uint8_t* codes_dev, int
  * conv(ZY, F, flipped=true) of model.jl:214,251: rows = reads x l, columns = K, reduction = h * 2M, 2 * l * K * h * 2M flop per
  * read -- launched `reps` times for n_groups mini-batches; *ms_out = average device time per launch. */
 int motifs_model_time_syntax_conv(motifs_model* m, const uint8_t* codes_dev, int n_groups, int reps, float* ms_out);
+/* Bytes of the engine arena the steps so far have used at most (intermediates + tape of the largest step): what `arena_bytes`
+ * of motifs_model_create has to cover. */
+int motifs_model_arena_peak(motifs_model* m, size_t* bytes);
 /* Test hook: a named intermediate of the last loss_grad call made with keep_intermediates != 0. */
 int motifs_model_dump(motifs_model* m, const char* name, float* out, int64_t cap, int64_t* n);
 

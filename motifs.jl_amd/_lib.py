@@ -66,6 +66,7 @@ SIGNATURES = {
     "motifs_ctx_reset_timing": (_int, [_p]),
     "motifs_ctx_kernel_ms": (_int, [_p, _int, C.POINTER(C.c_double), C.POINTER(_i64)]),
     "motifs_ctx_scan_plan": (_int, [_p, C.POINTER(C.c_int32)]),
+    "motifs_model_arena_peak": (_int, [_p, C.POINTER(C.c_size_t)]),
     "motifs_codes_bytes": (C.c_size_t, [_i64, _int]),
     "motifs_codes_pitch": (_int, [_int]),
     "motifs_encode_dev": (_int, [_p, _p, _int, _i64, _int, _p, _p]),
@@ -531,6 +532,12 @@ class Model:
         ms = C.c_float(0)
         check(lib().motifs_model_time_syntax_conv(self._h, _p(codes_ptr), int(n_groups), int(reps), C.byref(ms)))
         return ms.value
+
+    def arena_peak(self):
+        """Bytes of the engine arena the steps so far have used at most."""
+        v = C.c_size_t(0)
+        check(lib().motifs_model_arena_peak(self._h, C.byref(v)))
+        return int(v.value)
 
     def dump(self, name):
         n = _i64(0)

@@ -496,6 +496,17 @@ int motifs_model_set_params(motifs_model* m, const float* D, const float* F, con
     return MOTIFS_OK;
 }
 
+int motifs_model_arena_peak(motifs_model* m, size_t* bytes) {
+    int r = check_model(m, "motifs_model_arena_peak");
+    if (r) return r;
+    if (!bytes) {
+        set_error("motifs_model_arena_peak: bytes is NULL");
+        return MOTIFS_ERR_INVALID;
+    }
+    *bytes = m->eng.arena.peak;
+    return MOTIFS_OK;
+}
+
 int motifs_model_get_params(motifs_model* m, float* D, float* F, float* warmup3, float* vecs) {
     int r = check_model(m, "motifs_model_get_params");
     if (r) return r;
