@@ -91,6 +91,7 @@ struct motifs_ctx {
     int cg_chunks = -1;             // chunk groups of the re-scoring (scan_mfma.hip): -1 = when the table does not fit the LDS; MOTIFS_CG_CHUNKS overrides
     bool dense_fused = true;        // a17's tensor in one kernel (scan_dense.hip); MOTIFS_DENSE_FUSED=0: candidate kernel + stage_hits<.., 2>
     int32_t scan_plan[4] = {0, 0, 0, 0};   // motifs_ctx_scan_plan
+    bool pair_launches = true;      // both strands in one launch of stage_hits / row scans / emit_records too (MOTIFS_NO_PAIR_LAUNCHES=1: per strand)
     bool fuse_strands = true;       // MOTIFS_NO_STRAND_FUSION=1: one candidate launch per strand
     motifs::BankSlot bank_slot[2];  // [rc]
     void* pinned = nullptr;  // small pinned host block for totals / flags

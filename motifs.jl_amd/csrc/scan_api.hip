@@ -493,11 +493,9 @@ static int scan_hits_mfma(motifs_ctx* c, const BankSlot& bank, int K, const uint
         f.pwm_counts = per_pwm_counts_dev;   // zeroed by the caller of this function; only bins k < K are ever touched
         f.n0 = n0 + s0;
         f.hist_bins = (per_pwm_counts_dev && 2 * bank.KP <= FILL_HIST_MAX && !hg.cgc) ? 2 * bank.KP : 0;   // (chunk groups keep their own)
-        if (ns < nb * batch && cand_mode != 2) {   // cells of reads the last batch does not have are never written by the scan
-            if (compact) MOTIFS_HIP_CHECK(hipMemsetAsync((char*)c->centries.p + (size_t)(nb - 1) * (per_batch / 4), 0, per_batch / 4, c->stream));
-            else MOTIFS_HIP_CHECK(hipMemsetAsync((char*)c->cnt.p + (size_t)(nb - 1) * per_batch, 0, per_batch, c->stream));
-            if (cand_mode == 1) MOTIFS_HIP_CHECK(hipMemsetAsync((char*)c->centries2.p + (size_t)(nb - 1) * (per_batch / 4), 0, per_batch / 4, c->stream));
-        }
+        // cells of reads a short last batch does not have are never written by the scan: the walk over compact entries stops at the
+        // reads that exist (row_geom's nvalid); the 128-bit cells are cleared
+        if (ns < nb * batch && !compact) MOTIFS_HIP_CHECK(hipMemsetAsync((char*)c->cnt.p + (size_t)(nb - 1) * per_batch, 0, per_batch, c->stream));
         if (cand_mode != 2) {
             KernelTimer t(c, KS_SCAN_COUNT, true);
             const hipError_t le = launch_cand(a, c->stream, t.e0, t.e1);
@@ -525,6 +523,69 @@ static int scan_hits_mfma(motifs_ctx* c, const BankSlot& bank, int K, const uint
         set_error("hit buffer too small: need %lld records, cap %lld", (long long)emitted, (long long)cap);
         return MOTIFS_ERR_BUFFER_TOO_SMALL;
     }
+    return MOTIFS_OK;
+}
+
+// gpu_scan's two strands through ONE launch of every stage (single super-batch, compact entries, no chunk groups: what
+// motifs_pwm_scan_hits_both_dev checks): candidates of both banks (scan_cand_kernel_q with afrag2), then stage_hits, the row scans and
+// emit_records with the strand as blockIdx.y - 5 launches instead of 9 and no fill in front of them.  A step on a rank's 12 500 reads
+// of BASELINE configs[2] is 0.26 ms, of which the launches' gaps were a tenth (bench.py strong_proxy).
+static int scan_hits_pair(motifs_ctx* c, BankSlot* const bs[2], int K, const uint8_t* codes_dev, int64_t N, int L, int Lout, int64_t n0, int batch,
+                          motifs_hit* const hits[2], uint16_t* const scores[2], int64_t cap, int64_t* counts2_dev) {
+    const bool emit = hits[0] != nullptr && cap > 0;
+    const HitGeom hg = hit_geom(c, *bs[0], K, Lout, batch, emit, N, true);
+    const int64_t nb = (N + batch - 1) / batch;
+    const int64_t rows = nb * Lout * hg.parts, nblk = (rows + 1023) / 1024;
+    const size_t stage_words = (size_t)nb * hg.stage_per_batch / 4;
+    MOTIFS_HIP_CHECK(c->cnt.reserve((size_t)nb * hg.per_batch));
+    MOTIFS_HIP_CHECK(c->cnt2.reserve((size_t)nb * hg.per_batch));
+    MOTIFS_HIP_CHECK(c->centries.reserve((size_t)nb * hg.per_batch / 4));
+    MOTIFS_HIP_CHECK(c->centries2.reserve((size_t)nb * hg.per_batch / 4));
+    MOTIFS_HIP_CHECK(c->tilesum.reserve((size_t)rows * 4 * 2));
+    MOTIFS_HIP_CHECK(c->off.reserve((size_t)nblk * 8 * 2));
+    MOTIFS_HIP_CHECK(c->rowx.reserve((size_t)rows * 4 * 2));
+    if (emit) MOTIFS_HIP_CHECK(c->staging.reserve(stage_words * 4 * 2));
+    MOTIFS_HIP_CHECK(c->small.reserve(64));
+    CandArgs a[2]{};
+    FillArgs f[2]{};
+    for (int rc = 0; rc < 2; rc++) {
+        scan_args(c, *bs[rc], K, codes_dev, N, L, Lout, batch, hg.rpr, a[rc], f[rc], rc ? c->cnt2.p : c->cnt.p);
+        f[rc].centries = (const uint16_t*)(rc ? c->centries2.p : c->centries.p);
+        f[rc].row_sum = (uint32_t*)c->tilesum.p + (size_t)rc * rows;
+        f[rc].blk_base = (unsigned long long*)c->off.p + (size_t)rc * nblk;
+        f[rc].staging = (uint32_t*)c->staging.p + (size_t)rc * stage_words;
+        f[rc].row_slots = hg.row_slots;
+        f[rc].row_excl = (uint32_t*)c->rowx.p + (size_t)rc * rows;
+        f[rc].base_in = nullptr;
+        f[rc].total = (int64_t*)c->small.p + 2 * rc + 1;
+        f[rc].total_host = (int64_t*)c->pinned + rc;
+        f[rc].cap = cap;
+        f[rc].hits = (HitRec*)hits[rc];
+        f[rc].hit_scores = scores[rc];
+        f[rc].pwm_counts = counts2_dev ? counts2_dev + (size_t)rc * K : nullptr;
+        f[rc].n0 = n0;
+        f[rc].hist_bins = (counts2_dev && 2 * bs[rc]->KP <= FILL_HIST_MAX) ? 2 * bs[rc]->KP : 0;
+    }
+    a[0].centries = (uint16_t*)c->centries.p;
+    a[0].afrag2 = (const uint4*)bs[1]->afrag.p;
+    a[0].cells2 = (uint32_t*)c->cnt2.p;
+    a[0].centries2 = (uint16_t*)c->centries2.p;
+    {
+        KernelTimer t(c, KS_SCAN_COUNT, true);
+        const hipError_t le = launch_cand(a[0], c->stream, t.e0, t.e1);
+        t.stamped = le == hipSuccess;
+        MOTIFS_HIP_CHECK(le);
+    }
+    {
+        KernelTimer t(c, KS_SCAN_OFFSETS);
+        MOTIFS_HIP_CHECK(launch_stage_hits(f[0], emit ? 1 : 0, c->stream, &f[1]));
+        MOTIFS_HIP_CHECK(launch_row_scan(f[0], c->stream, &f[1]));
+    }
+    if (emit) {
+        KernelTimer t(c, KS_SCAN_FILL);
+        MOTIFS_HIP_CHECK(launch_emit_records(f[0], c->stream, &f[1]));
+    }
+    c->scan_plan[0] = 1, c->scan_plan[1] = 0, c->scan_plan[2] = 1, c->scan_plan[3] = 1;
     return MOTIFS_OK;
 }
 
@@ -566,6 +627,7 @@ int motifs_ctx_create(int device, motifs_ctx** out) {
     c->scan_valu = ev && ev[0] == '1';
     if (const char* nc = getenv("MOTIFS_DENSE_CELLS")) c->compact_cells = !(nc[0] == '1');   // A/B: the round-2 cell round trip
     if (const char* dfv = getenv("MOTIFS_DENSE_FUSED")) c->dense_fused = !(dfv[0] == '0');   // A/B: the two-kernel dense form
+    if (const char* pl = getenv("MOTIFS_NO_PAIR_LAUNCHES")) c->pair_launches = !(pl[0] == '1');   // A/B: one launch of every stage per strand
     if (const char* cgv = getenv("MOTIFS_CG_CHUNKS")) c->cg_chunks = atoi(cgv);      // chunk groups: 0 = never, 1 / 2 / 4 = that size for every bank that can take it (tests, A/B)
     if (const char* nf = getenv("MOTIFS_NO_STRAND_FUSION")) c->fuse_strands = !(nf[0] == '1');  // A/B: one candidate launch per strand
     if (const char* wl = getenv("MOTIFS_WS_LIMIT_MB")) {       // experiments: the default of motifs_ctx_set_workspace_limit
@@ -985,6 +1047,7 @@ int motifs_pwm_scan_hits_both_dev(motifs_ctx* c, const uint16_t* pwms_fp16, cons
     // One candidate launch for both strands when the four-reads kernel with compact entries serves both banks and the shard is one
     // super-batch: the reverse bank then goes over the reads the forward bank's waves have already staged (scan_mfma.hip).
     bool fuse = c->compact_cells && c->fuse_strands;
+    bool pair_ok = true;
     {
         const int Lout0 = L - bs[0]->minlen + 1;
         CandArgs a0{}, a1{};
@@ -996,7 +1059,12 @@ int motifs_pwm_scan_hits_both_dev(motifs_ctx* c, const uint16_t* pwms_fp16, cons
         const HitGeom hg0 = hit_geom(c, *bs[0], K, Lout0, batch, emit, N, true);
         fuse = fuse && cand_two_strands_ok(a0) && cand_two_strands_ok(a1) && bs[0]->lenp == bs[1]->lenp && bs[0]->nch == bs[1]->nch &&
                hg0.compact && hg0.nb_max * batch >= N;
+        pair_ok = hg0.cgc == 0;           // (chunk groups keep their launches per strand)
     }
+    if (fuse && pair_ok && c->pair_launches && bs[0]->minlen == bs[1]->minlen) {
+        const int rcode = scan_hits_pair(c, bs, K, codes_dev, N, L, L - bs[0]->minlen + 1, n0, batch, hits, scores, cap, per_pwm_counts2_dev);
+        if (rcode) return rcode;
+    } else
     for (int rc = 0; rc < 2; rc++) {
         const int Lout = L - bs[rc]->minlen + 1;
         int64_t dummy = 0;

@@ -122,9 +122,10 @@ hipError_t launch_cand(const CandArgs& a, hipStream_t st, hipEvent_t ev0 = nullp
 int stage_row_reads(int nch);                                              // reads per row of cells
 int dense_row_reads(int nch);                                              // the same for the dense tensor (mode 2)
 // candidates -> row counts (mode 0), + staged hits (1), or a17's dense tensor, zeros included (2); + histogram
-hipError_t launch_stage_hits(const FillArgs& a, int mode, hipStream_t st);
-hipError_t launch_row_scan(const FillArgs& a, hipStream_t st);             // row counts -> offsets; *total = *base_in + hits
-hipError_t launch_emit_records(const FillArgs& a, hipStream_t st);         // staged hits -> records
+// (b != nullptr: the other strand of gpu_scan in the same launches - same bank shape and geometry, its own buffers)
+hipError_t launch_stage_hits(const FillArgs& a, int mode, hipStream_t st, const FillArgs* b = nullptr);
+hipError_t launch_row_scan(const FillArgs& a, hipStream_t st, const FillArgs* b = nullptr);             // row counts -> offsets; *total = *base_in + hits
+hipError_t launch_emit_records(const FillArgs& a, hipStream_t st, const FillArgs* b = nullptr);         // staged hits -> records
 // chunk groups: the largest group (chunks of 128 PWMs: 4, 2, 1) whose slice of the re-scoring table fits a block's LDS beside
 // the queues, 0 when the whole table fits (or the bank cannot take the mode); `want` > 0 forces a size (tests, A/B runs)
 int stage_cg_chunks(int K, int nch, int lenp, int tabk_stride, int want);

@@ -805,7 +805,9 @@ static __device__ __forceinline__ bool score_candidate(const FillArgs& a, const 
 // should be.  Needs K % 8 == 0 (16-byte stores).
 constexpr int DWIN = 2048;        // halves per window (4 KB: four 16-byte stores per lane and flush; 2-3 % faster than 1 KB windows)
 template <int LEN, bool LDS_TAB, int MODE>
-__global__ __launch_bounds__(VF_THREADS) __attribute__((amdgpu_waves_per_eu((LEN != 0 && LEN <= 32) ? 8 : 4, 8))) void stage_hits(FillArgs a) {
+__global__ __launch_bounds__(VF_THREADS) __attribute__((amdgpu_waves_per_eu((LEN != 0 && LEN <= 32) ? 8 : 4, 8))) void stage_hits(FillArgs a0, FillArgs a1) {
+    // blockIdx.y = strand: gpu_scan's two strands in one launch (a1 = a0 and gridDim.y = 1 for one)
+    const FillArgs& a = blockIdx.y ? a1 : a0;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: the row geometry stays on the scalar unit
     uint16_t* queue = (uint16_t*)smem + wv * QN;                      // [VF_WAVES][QN]
@@ -875,7 +877,8 @@ __global__ __launch_bounds__(VF_THREADS) __attribute__((amdgpu_waves_per_eu((LEN
         };
         // (mode 2 keeps the cells: its rows are 64 cells, 8 lanes' worth of entries - measured 0.49 of the HBM peak with entries
         // against 0.53 with cells on the same box)
-        if (MODE != 2 && a.centries) for_row_candidates_c<0>(a, g, g.row_cells, (size_t)0, queue, on_cand);
+        // (compact entries: only the cells of reads that exist are walked - the entries of the reads a short last batch lacks are never written)
+        if (MODE != 2 && a.centries) for_row_candidates_c<0>(a, g, g.nvalid * (uint32_t)a.nch, (size_t)0, queue, on_cand);
         else for_row_candidates<(MODE == 2 ? 1 : 2)>(g, queue, on_cand);
         if (MODE == 2)
             while (win_lo < seg_len) flush();                         // the rest of the run
@@ -967,7 +970,7 @@ __global__ __launch_bounds__(VF_THREADS) __attribute__((amdgpu_waves_per_eu(CGC 
             }
             nhit += (uint32_t)__builtin_popcountll(hb);
         };
-        for_row_candidates_c<0>(a, g, g.nreads * (uint32_t)CGC, (size_t)cg * a.Lout * a.batch * CGC, queue, on_cand);
+        for_row_candidates_c<0>(a, g, g.nvalid * (uint32_t)CGC, (size_t)cg * a.Lout * a.batch * CGC, queue, on_cand);
         if (MODE == 1 && nhit) {                                      // (an empty group's counts are never read)
             wave_lds_sync();
             for (uint32_t i = lane; i < R / 2; i += 64) blk[i] = rcnt[i];
@@ -983,8 +986,18 @@ __global__ __launch_bounds__(VF_THREADS) __attribute__((amdgpu_waves_per_eu(CGC 
 
 // exclusive scan of the row counts in three small steps: per 1024 rows, over the block totals, (added back in emit_records)
 // (ncg > 1, chunk groups: a row's count is the sum of its groups')
-__global__ __launch_bounds__(1024) void row_scan_local(const uint32_t* __restrict__ row_sum, int64_t nrows, uint32_t* __restrict__ row_excl,
-                                                       unsigned long long* __restrict__ blk_total, const int ncg) {
+struct RowScan2 {                     // the row-scan arguments of one or two strands (blockIdx.y)
+    const uint32_t* row_sum[2];
+    uint32_t* row_excl[2];
+    unsigned long long* blk[2];
+    const int64_t* base_in[2];
+    int64_t* total_out[2];
+    int64_t* total_host[2];
+};
+__global__ __launch_bounds__(1024) void row_scan_local(const RowScan2 rs, int64_t nrows, const int ncg) {
+    const uint32_t* __restrict__ row_sum = rs.row_sum[blockIdx.y];
+    uint32_t* __restrict__ row_excl = rs.row_excl[blockIdx.y];
+    unsigned long long* __restrict__ blk_total = rs.blk[blockIdx.y];
     __shared__ uint32_t wsum[16];
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: the row geometry stays on the scalar unit
     const int64_t i = (int64_t)blockIdx.x * 1024 + tid;
@@ -1006,8 +1019,11 @@ __global__ __launch_bounds__(1024) void row_scan_local(const uint32_t* __restric
     if (i < nrows) row_excl[i] = wbase + inc - v;                     // < 2^32: at most 1024 rows x 65536 candidates (x 8 reads per row in chunk-group mode)
     if (tid == 0) blk_total[blockIdx.x] = tot;
 }
-__global__ __launch_bounds__(1024) void row_scan_blocks(unsigned long long* __restrict__ blk, int64_t nblk, const int64_t* __restrict__ base_in,
-                                                        int64_t* __restrict__ total_out, int64_t* __restrict__ total_host) {
+__global__ __launch_bounds__(1024) void row_scan_blocks(const RowScan2 rs, int64_t nblk) {
+    unsigned long long* __restrict__ blk = rs.blk[blockIdx.x];
+    const int64_t* __restrict__ base_in = rs.base_in[blockIdx.x];
+    int64_t* __restrict__ total_out = rs.total_out[blockIdx.x];
+    int64_t* __restrict__ total_host = rs.total_host[blockIdx.x];
     __shared__ unsigned long long part[1024];
     const int tid = threadIdx.x;
     const int64_t per = (nblk + 1023) / 1024;
@@ -1039,7 +1055,8 @@ __global__ __launch_bounds__(1024) void row_scan_blocks(unsigned long long* __re
 
 // staged words -> records.  One wave per row; a row that overflowed its staging slots is re-scored from its cells.
 template <int LEN, bool LDS_TAB>
-__global__ __launch_bounds__(VF_THREADS) void emit_records(FillArgs a) {
+__global__ __launch_bounds__(VF_THREADS) void emit_records(FillArgs a0, FillArgs a1) {
+    const FillArgs& a = blockIdx.y ? a1 : a0;                         // blockIdx.y = strand
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: the row geometry stays on the scalar unit
     uint16_t* queue = (uint16_t*)smem + wv * QN;
@@ -1103,7 +1120,7 @@ __global__ __launch_bounds__(VF_THREADS) void emit_records(FillArgs a) {
                 if (hit) put(row_at + nhit + (uint32_t)__builtin_popcountll(hb & ((1ull << lane) - 1ull)), k, nin, sc);
                 nhit += (uint32_t)__builtin_popcountll(hb);
             };
-            if (a.centries) for_row_candidates_c<0>(a, g, g.row_cells, (size_t)0, queue, on_cand);
+            if (a.centries) for_row_candidates_c<0>(a, g, g.nvalid * (uint32_t)a.nch, (size_t)0, queue, on_cand);
             else for_row_candidates<2>(g, queue, on_cand);
         }
     }
@@ -1325,7 +1342,7 @@ __global__ __launch_bounds__(VF_THREADS) void emit_records_cg(FillArgs a, const 
                     }
                     nhit += (uint32_t)__builtin_popcountll(hb);
                 };
-                for_row_candidates_c<1>(a, g2, g2.row_cells, (size_t)0, queue, on_cand);
+                for_row_candidates_c<1>(a, g2, g2.nvalid * (uint32_t)a.nch, (size_t)0, queue, on_cand);
             }
         }
     }
@@ -1427,30 +1444,35 @@ int stage_row_reads(int nch) { return std::max(1, ROW_CELLS_MAX / nch); }
 int dense_row_reads(int nch) { return std::max(1, 64 / nch); }
 
 template <int LEN, int MODE>
-static hipError_t launch_stage_mode(const FillArgs& a, hipStream_t st) {
+static hipError_t launch_stage_mode(const FillArgs& a, hipStream_t st, const FillArgs* b) {
     if ((int64_t)a.rpr * a.nch > ROW_CELLS_MAX || a.nrows >= (int64_t)1 << 31) return hipErrorInvalidValue;
     const size_t base = (size_t)VF_WAVES * QN * 2 + (size_t)a.hist_bins * 4 + (MODE == 2 ? (size_t)VF_WAVES * DWIN * 2 : 0);
     const size_t tab_bytes = ((size_t)a.K * a.tabk_stride * 2 + 3) & ~(size_t)3;
     const bool lds_tab = base + tab_bytes <= 64 * 1024;
     if (MODE == 2 && a.K % 8 != 0) return hipErrorInvalidValue;
     const unsigned grid = (unsigned)std::min<int64_t>((a.nrows + VF_WAVES - 1) / VF_WAVES, 256 * 4);
-    if (lds_tab) hipLaunchKernelGGL((stage_hits<LEN, true, MODE>), dim3(grid), dim3(VF_THREADS), base + tab_bytes, st, a);
-    else hipLaunchKernelGGL((stage_hits<LEN, false, MODE>), dim3(grid), dim3(VF_THREADS), base, st, a);
+    // b != nullptr: the other strand's rows in the same launch (same bank shape, same geometry: grid.y = 2, half the blocks each)
+    const dim3 g2(b ? std::max(1u, (grid + 1) / 2) : grid, b ? 2 : 1, 1);
+    const FillArgs& a1 = b ? *b : a;
+    if (lds_tab) hipLaunchKernelGGL((stage_hits<LEN, true, MODE>), g2, dim3(VF_THREADS), base + tab_bytes, st, a, a1);
+    else hipLaunchKernelGGL((stage_hits<LEN, false, MODE>), g2, dim3(VF_THREADS), base, st, a, a1);
     return hipGetLastError();
 }
 template <int LEN>
-static hipError_t launch_stage_len(const FillArgs& a, int mode, hipStream_t st) {
-    return mode == 0 ? launch_stage_mode<LEN, 0>(a, st) : mode == 1 ? launch_stage_mode<LEN, 1>(a, st) : launch_stage_mode<LEN, 2>(a, st);
+static hipError_t launch_stage_len(const FillArgs& a, int mode, hipStream_t st, const FillArgs* b) {
+    return mode == 0 ? launch_stage_mode<LEN, 0>(a, st, b) : mode == 1 ? launch_stage_mode<LEN, 1>(a, st, b) : launch_stage_mode<LEN, 2>(a, st, b);
 }
 template <int LEN>
-static hipError_t launch_emit_len(const FillArgs& a, hipStream_t st) {
+static hipError_t launch_emit_len(const FillArgs& a, hipStream_t st, const FillArgs* b) {
     const size_t base = (size_t)VF_WAVES * QN * 2;
     const size_t tab_bytes = ((size_t)a.K * a.tabk_stride * 2 + 3) & ~(size_t)3;
     const unsigned grid = (unsigned)std::min<int64_t>((a.nrows + VF_WAVES - 1) / VF_WAVES, 256 * 8);
+    const dim3 g2(b ? std::max(1u, (grid + 1) / 2) : grid, b ? 2 : 1, 1);
+    const FillArgs& a1 = b ? *b : a;
     if (base + tab_bytes <= 64 * 1024)
-        hipLaunchKernelGGL((emit_records<LEN, true>), dim3(grid), dim3(VF_THREADS), base + tab_bytes, st, a);
+        hipLaunchKernelGGL((emit_records<LEN, true>), g2, dim3(VF_THREADS), base + tab_bytes, st, a, a1);
     else
-        hipLaunchKernelGGL((emit_records<LEN, false>), dim3(grid), dim3(VF_THREADS), base, st, a);
+        hipLaunchKernelGGL((emit_records<LEN, false>), g2, dim3(VF_THREADS), base, st, a, a1);
     return hipGetLastError();
 }
 
@@ -1541,21 +1563,28 @@ static hipError_t launch_emit_cg(const FillArgs& a, hipStream_t st) {
         default: return (lenp) > 64 ? CALL(0) : hipErrorInvalidValue;   /* LEN = 0: run-time length */ \
     }
 
-hipError_t launch_stage_hits(const FillArgs& a, int mode, hipStream_t st) {
-    if (a.cgc) return launch_stage_cg(a, mode, st);
-#define CALL(LEN) launch_stage_len<LEN>(a, mode, st)
+hipError_t launch_stage_hits(const FillArgs& a, int mode, hipStream_t st, const FillArgs* b) {
+    if (a.cgc) return b ? hipErrorInvalidValue : launch_stage_cg(a, mode, st);
+    if (b && mode == 2) return hipErrorInvalidValue;
+#define CALL(LEN) launch_stage_len<LEN>(a, mode, st, b)
     MOTIFS_LEN_SWITCH(a.lenp, CALL)
 #undef CALL
 }
-hipError_t launch_row_scan(const FillArgs& a, hipStream_t st) {
+hipError_t launch_row_scan(const FillArgs& a, hipStream_t st, const FillArgs* b) {
     const int64_t nblk = (a.nrows + 1023) / 1024;
-    hipLaunchKernelGGL(row_scan_local, dim3((unsigned)nblk), dim3(1024), 0, st, a.row_sum, a.nrows, a.row_excl, a.blk_base, a.cgc ? a.ncg : 1);
-    hipLaunchKernelGGL(row_scan_blocks, dim3(1), dim3(1024), 0, st, a.blk_base, nblk, a.base_in, a.total, a.total_host);
+    RowScan2 rs{};
+    const FillArgs* f[2] = {&a, b ? b : &a};
+    for (int i = 0; i < 2; i++) {
+        rs.row_sum[i] = f[i]->row_sum, rs.row_excl[i] = f[i]->row_excl, rs.blk[i] = f[i]->blk_base;
+        rs.base_in[i] = f[i]->base_in, rs.total_out[i] = f[i]->total, rs.total_host[i] = f[i]->total_host;
+    }
+    hipLaunchKernelGGL(row_scan_local, dim3((unsigned)nblk, b ? 2 : 1, 1), dim3(1024), 0, st, rs, a.nrows, a.cgc ? a.ncg : 1);
+    hipLaunchKernelGGL(row_scan_blocks, dim3(b ? 2 : 1), dim3(1024), 0, st, rs, nblk);
     return hipGetLastError();
 }
-hipError_t launch_emit_records(const FillArgs& a, hipStream_t st) {
-    if (a.cgc) return launch_emit_cg(a, st);
-#define CALL(LEN) launch_emit_len<LEN>(a, st)
+hipError_t launch_emit_records(const FillArgs& a, hipStream_t st, const FillArgs* b) {
+    if (a.cgc) return b ? hipErrorInvalidValue : launch_emit_cg(a, st);
+#define CALL(LEN) launch_emit_len<LEN>(a, st, b)
     MOTIFS_LEN_SWITCH(a.lenp, CALL)
 #undef CALL
 }
