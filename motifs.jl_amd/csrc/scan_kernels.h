@@ -120,6 +120,7 @@ bool cand_compact_ok(const CandArgs& a);
 bool cand_two_strands_ok(const CandArgs& a);   // ... and take both strands' banks in one launch   // this launch can write compact entries (four-reads-per-wave kernel, tile groups of 4)
 hipError_t launch_cand(const CandArgs& a, hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 int stage_row_reads(int nch);                                              // reads per row of cells
+bool stage_big_lds_ok(int K, int KP, int tabk_stride, bool hist);          // the table fits one 16-wave block's LDS (and not an 8-wave block's 64 KB)
 int dense_row_reads(int nch);                                              // the same for the dense tensor (mode 2)
 // candidates -> row counts (mode 0), + staged hits (1), or a17's dense tensor, zeros included (2); + histogram
 // (b != nullptr: the other strand of gpu_scan in the same launches - same bank shape and geometry, its own buffers)

@@ -804,25 +804,27 @@ static __device__ __forceinline__ bool score_candidate(const FillArgs& a, const 
 // written exactly once, in linear order: the pass is bound by the HBM write, as the dense contract says it
 // should be.  Needs K % 8 == 0 (16-byte stores).
 constexpr int DWIN = 2048;        // halves per window (4 KB: four 16-byte stores per lane and flush; 2-3 % faster than 1 KB windows)
-template <int LEN, bool LDS_TAB, int MODE>
-__global__ __launch_bounds__(VF_THREADS) __attribute__((amdgpu_waves_per_eu((LEN != 0 && LEN <= 32) ? 8 : 4, 8))) void stage_hits(FillArgs a0, FillArgs a1) {
+// NW = waves per block: 8; 16 (one 1024-thread block per CU, four waves per SIMD) for a bank whose table needs more LDS than two
+// blocks of 8 can share - 512 PWMs of 20 positions, 104 KB: with 8 waves per CU that form lost to gathers from L2, with 16 it does not
+template <int LEN, bool LDS_TAB, int MODE, int NW = VF_WAVES>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW == 16 ? 4 : (LEN != 0 && LEN <= 32) ? 8 : 4, NW == 16 ? 4 : 8))) void stage_hits(FillArgs a0, FillArgs a1) {
     // blockIdx.y = strand: gpu_scan's two strands in one launch (a1 = a0 and gridDim.y = 1 for one)
     const FillArgs& a = blockIdx.y ? a1 : a0;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: the row geometry stays on the scalar unit
-    uint16_t* queue = (uint16_t*)smem + wv * QN;                      // [VF_WAVES][QN]
-    uint32_t* hist = smem + VF_WAVES * QN / 2;                        // [hist_bins]
-    uint32_t* winbase = hist + a.hist_bins;                           // MODE 2: [VF_WAVES][DWIN] halves
+    uint16_t* queue = (uint16_t*)smem + wv * QN;                      // [NW][QN]
+    uint32_t* hist = smem + NW * QN / 2;                        // [hist_bins]
+    uint32_t* winbase = hist + a.hist_bins;                           // MODE 2: [NW][DWIN] halves
     uint16_t* win = (uint16_t*)winbase + wv * DWIN;
-    uint32_t* ltab = winbase + (MODE == 2 ? VF_WAVES * DWIN / 2 : 0);
-    for (int i = tid; i < a.hist_bins; i += VF_THREADS) hist[i] = 0;
+    uint32_t* ltab = winbase + (MODE == 2 ? NW * DWIN / 2 : 0);
+    for (int i = tid; i < a.hist_bins; i += (NW * 64)) hist[i] = 0;
     if (MODE == 2)
-        for (int i = tid; i < VF_WAVES * DWIN / 2; i += VF_THREADS) winbase[i] = 0u;
-    const _Float16* tb = stage_table<LDS_TAB, VF_THREADS>(a, ltab);
+        for (int i = tid; i < NW * DWIN / 2; i += (NW * 64)) winbase[i] = 0u;
+    const _Float16* tb = stage_table<LDS_TAB, (NW * 64)>(a, ltab);
     __syncthreads();
     // (rows handed out through one atomic counter instead of this fixed stride: 1.0 ms against 0.28 - ~85k device-scope
     // atomics on one address serialise at ~10 ns each)
-    const int64_t nwaves = (int64_t)gridDim.x * VF_WAVES;
+    const int64_t nwaves = (int64_t)gridDim.x * NW;
     for (int64_t r = (int64_t)wv * gridDim.x + blockIdx.x; r < a.nrows; r += nwaves) {
         const RowGeom g = row_geom(a, r);
         uint32_t* slots = MODE == 1 ? a.staging + (size_t)r * a.row_slots : nullptr;
@@ -886,7 +888,7 @@ __global__ __launch_bounds__(VF_THREADS) __attribute__((amdgpu_waves_per_eu((LEN
     }
     if (a.hist_bins) {
         __syncthreads();
-        for (int i = tid; i < a.hist_bins; i += VF_THREADS)
+        for (int i = tid; i < a.hist_bins; i += (NW * 64))
             if (hist[i]) atomicAdd((unsigned long long*)&a.pwm_counts[i], (unsigned long long)hist[i]);
     }
 }
@@ -1439,6 +1441,12 @@ hipError_t launch_cand(const CandArgs& a, hipStream_t st, hipEvent_t ev0, hipEve
 }
 
 int stage_row_reads(int nch) { return std::max(1, ROW_CELLS_MAX / nch); }
+// a bank whose table does not fit beside the queues of an 8-wave block (64 KB) but does fit ONE 16-wave block per CU
+bool stage_big_lds_ok(int K, int KP, int tabk_stride, bool hist) {
+    const size_t tab_bytes = ((size_t)K * tabk_stride * 2 + 3) & ~(size_t)3;
+    const size_t hist_bytes = (hist && 2 * KP <= FILL_HIST_MAX) ? (size_t)2 * KP * 4 : 0;
+    return (size_t)VF_WAVES * QN * 2 + hist_bytes + tab_bytes > 64 * 1024 && (size_t)16 * QN * 2 + hist_bytes + tab_bytes <= 160 * 1024 - 1024;
+}
 // Dense mode: short runs (64 cells: 16 reads x 400 B at K = 200) keep the write streams of the waves that run
 // together close to each other in memory; measured 0.36 ms per 1.5 GB against 0.40 with 512-cell rows.
 int dense_row_reads(int nch) { return std::max(1, 64 / nch); }
@@ -1454,8 +1462,19 @@ static hipError_t launch_stage_mode(const FillArgs& a, hipStream_t st, const Fil
     // b != nullptr: the other strand's rows in the same launch (same bank shape, same geometry: grid.y = 2, half the blocks each)
     const dim3 g2(b ? std::max(1u, (grid + 1) / 2) : grid, b ? 2 : 1, 1);
     const FillArgs& a1 = b ? *b : a;
-    if (lds_tab) hipLaunchKernelGGL((stage_hits<LEN, true, MODE>), g2, dim3(VF_THREADS), base + tab_bytes, st, a, a1);
-    else hipLaunchKernelGGL((stage_hits<LEN, false, MODE>), g2, dim3(VF_THREADS), base, st, a, a1);
+    if (lds_tab) {
+        hipLaunchKernelGGL((stage_hits<LEN, true, MODE>), g2, dim3(VF_THREADS), base + tab_bytes, st, a, a1);
+    } else if (MODE != 2 && LEN != 0 && LEN <= 32 && stage_big_lds_ok(a.K, a.KP, a.tabk_stride, a.hist_bins != 0)) {
+        // the whole table in the LDS of ONE 16-wave block per CU
+        const size_t lds16 = (size_t)16 * QN * 2 + (size_t)a.hist_bins * 4 + tab_bytes;
+        const unsigned grid16 = (unsigned)std::min<int64_t>((a.nrows + 15) / 16, 256);
+        const dim3 g16(b ? std::max(1u, (grid16 + 1) / 2) : grid16, b ? 2 : 1, 1);
+        auto kern = stage_hits<LEN, true, (MODE == 2 ? 1 : MODE), 16>;
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);
+        hipLaunchKernelGGL(kern, g16, dim3(1024), lds16, st, a, a1);
+    } else {
+        hipLaunchKernelGGL((stage_hits<LEN, false, MODE>), g2, dim3(VF_THREADS), base, st, a, a1);
+    }
     return hipGetLastError();
 }
 template <int LEN>
@@ -1489,6 +1508,7 @@ int stage_cg_chunks(int K, int nch, int lenp, int tabk_stride, int want) {
     if (want > 0) return (want == 1 || want == 2 || want == 4) && ok(want) ? want : 0;
     const size_t whole = (size_t)VF_WAVES * QN * 2 + (size_t)2 * nch * 64 * 4 + (((size_t)K * tabk_stride * 2 + 3) & ~(size_t)3);
     if (whole <= 64 * 1024) return 0;                                  // stage_hits<LEN, true, .> holds the whole table
+    if (stage_big_lds_ok(K, nch * 64, tabk_stride, true)) return 0;    // ... or one 16-wave block per CU does (no reordering of the records needed)
     for (int cgc : {2, 1, 4})
         if (ok(cgc) && (cgc == 4 || stage_cg_lds_bytes(cgc, tabk_stride) <= 64 * 1024)) return cgc;
     return 0;
