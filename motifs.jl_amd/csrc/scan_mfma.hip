@@ -924,31 +924,32 @@ static __device__ __forceinline__ bool score_candidate_cg(const FillArgs& a, con
 // MODE: 0 = count the hits of every (row, group); 1 = count and stage them.  A (row, group)'s staging block is
 // [R / 2 dwords: hits per read, 16 bits each][row_slots staged words], R = 512 / CGC reads: the per-read counts are what
 // emit_records_cg needs to interleave the groups, and the wave that scores the hits has them for one LDS atomic each.
-template <int LEN, int CGC, int MODE>
-__global__ __launch_bounds__(VF_THREADS) __attribute__((amdgpu_waves_per_eu(CGC == 1 ? 8 : 4, 8))) void stage_hits_cg(FillArgs a) {
+// (NW = waves per block: 16 - one block per CU - for groups of 4 chunks, whose 104 KB slice leaves room for one block only)
+template <int LEN, int CGC, int MODE, int NW = (CGC == 4 ? 16 : VF_WAVES)>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(CGC == 1 ? 8 : 4, CGC == 4 ? 4 : 8))) void stage_hits_cg(FillArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     constexpr uint32_t R = 512 / CGC;
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    uint16_t* queue = (uint16_t*)smem + wv * QN;                      // [VF_WAVES][QN]
-    uint32_t* hist = smem + VF_WAVES * QN / 2;                        // [CGC * 128]
-    uint32_t* rcnt = hist + CGC * 128 + wv * (R / 2);                 // [VF_WAVES][R / 2]: hits per read of the wave's sub-row
-    uint32_t* ltab = hist + CGC * 128 + VF_WAVES * (R / 2);
+    uint16_t* queue = (uint16_t*)smem + wv * QN;                      // [NW][QN]
+    uint32_t* hist = smem + NW * QN / 2;                        // [CGC * 128]
+    uint32_t* rcnt = hist + CGC * 128 + wv * (R / 2);                 // [NW][R / 2]: hits per read of the wave's sub-row
+    uint32_t* ltab = hist + CGC * 128 + NW * (R / 2);
     const uint32_t ncg = (uint32_t)a.ncg;
     const uint32_t xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
     const uint32_t cg = j % ncg, cg0 = cg * CGC;                      // first chunk of the block's group
     const int64_t stripe = (int64_t)(j / ncg) * 8 + xcd, nstripes = gridDim.x / ncg;   // gridDim.x is a multiple of 8 * ncg
-    for (int i = tid; i < CGC * 128; i += VF_THREADS) hist[i] = 0;
+    for (int i = tid; i < CGC * 128; i += (NW * 64)) hist[i] = 0;
     {   // the group's slice of the table (rows of PWMs past K do not exist: the last group may be short)
         const int k0 = (int)cg0 * 128;
         const int nk = a.K - k0 < CGC * 128 ? a.K - k0 : CGC * 128;
         const int ndw = nk > 0 ? nk * (a.tabk_stride / 2) : 0;
         const uint32_t* src = (const uint32_t*)(a.tabk + (size_t)k0 * a.tabk_stride);
-        for (int i = tid; i < ndw; i += VF_THREADS) ltab[i] = src[i];
+        for (int i = tid; i < ndw; i += (NW * 64)) ltab[i] = src[i];
     }
     __syncthreads();
     const _Float16* tbl = (const _Float16*)ltab;
     const size_t sub_stride = (size_t)a.row_slots + R / 2;
-    for (int64_t r = (int64_t)wv * nstripes + stripe; r < a.nrows; r += nstripes * VF_WAVES) {
+    for (int64_t r = (int64_t)wv * nstripes + stripe; r < a.nrows; r += nstripes * NW) {
         const RowGeom g = row_geom(a, r);
         uint32_t* blk = MODE == 1 ? a.staging + ((size_t)r * ncg + cg) * sub_stride : nullptr;
         uint32_t* slots = MODE == 1 ? blk + R / 2 : nullptr;
@@ -981,7 +982,7 @@ __global__ __launch_bounds__(VF_THREADS) __attribute__((amdgpu_waves_per_eu(CGC 
     }
     if (a.pwm_counts) {
         __syncthreads();
-        for (int i = tid; i < CGC * 128; i += VF_THREADS)
+        for (int i = tid; i < CGC * 128; i += (NW * 64))
             if (hist[i]) atomicAdd((unsigned long long*)&a.pwm_counts[cg0 * 128 + i], (unsigned long long)hist[i]);
     }
 }
@@ -1141,7 +1142,7 @@ __global__ __launch_bounds__(VF_THREADS) void emit_records(FillArgs a0, FillArgs
 // does it, 512 cells at a time with the table in L2 (rare: more than two hits per cell on average over 512 cells).
 constexpr uint32_t CG_WIN = 768;      // records per LDS window (32 reads x 2048 PWMs at a 1 % hit rate: ~650)
 template <int LEN, int CGC>
-__global__ __launch_bounds__(VF_THREADS) void emit_records_cg(FillArgs a, const int rpr_small) {
+__global__ __launch_bounds__(VF_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8))) void emit_records_cg(FillArgs a, const int rpr_small) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     constexpr uint32_t R = 512 / CGC, CGL = CGC == 4 ? 2 : CGC == 2 ? 1 : 0, NH = R / 32;
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1496,8 +1497,10 @@ static hipError_t launch_emit_len(const FillArgs& a, hipStream_t st, const FillA
 }
 
 // ---- chunk-group launchers
+static int stage_cg_waves(int cgc) { return cgc == 4 ? 16 : VF_WAVES; }
 size_t stage_cg_lds_bytes(int cgc, int tabk_stride) {
-    return (size_t)VF_WAVES * QN * 2 + (size_t)cgc * 128 * 4 + (size_t)VF_WAVES * (512 / cgc) * 2 + (((size_t)cgc * 128 * tabk_stride * 2 + 3) & ~(size_t)3);
+    const size_t nw = (size_t)stage_cg_waves(cgc);
+    return nw * QN * 2 + (size_t)cgc * 128 * 4 + nw * (512 / cgc) * 2 + (((size_t)cgc * 128 * tabk_stride * 2 + 3) & ~(size_t)3);
 }
 int stage_cg_chunks(int K, int nch, int lenp, int tabk_stride, int want) {
     if (lenp > 20 || lenp % 4 != 0) return 0;                          // compact entries exist for PWMs of up to 20 positions
@@ -1516,10 +1519,11 @@ int stage_cg_chunks(int K, int nch, int lenp, int tabk_stride, int want) {
 template <int LEN, int CGC>
 static hipError_t launch_stage_cg_t(const FillArgs& a, int mode, hipStream_t st) {
     const size_t lds = stage_cg_lds_bytes(CGC, a.tabk_stride);
-    const int bpc = (int)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / (lds + 512)));     // blocks a CU holds
+    const int nw = stage_cg_waves(CGC);
+    const int bpc = (int)std::max<size_t>(1, std::min<size_t>(32 / nw, (160 * 1024) / (lds + 512)));     // blocks a CU holds
     const int64_t unit = 8 * (int64_t)a.ncg;                            // one block per (XCD, group)
     int64_t grid = std::max<int64_t>(1, (256 * (int64_t)bpc) / unit) * unit;
-    const int64_t need = ((a.nrows + VF_WAVES - 1) / VF_WAVES + 7) / 8 * unit;     // stripes that have a row, in whole units
+    const int64_t need = ((a.nrows + nw - 1) / nw + 7) / 8 * unit;      // stripes that have a row, in whole units
     grid = std::max<int64_t>(unit, std::min(grid, need));
     if (a.nrows >= (int64_t)1 << 31) return hipErrorInvalidValue;
     auto k0 = stage_hits_cg<LEN, CGC, 0>;
@@ -1528,8 +1532,8 @@ static hipError_t launch_stage_cg_t(const FillArgs& a, int mode, hipStream_t st)
         (void)hipFuncSetAttribute((const void*)k0, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
-    if (mode == 0) hipLaunchKernelGGL(k0, dim3((unsigned)grid), dim3(VF_THREADS), lds, st, a);
-    else hipLaunchKernelGGL(k1, dim3((unsigned)grid), dim3(VF_THREADS), lds, st, a);
+    if (mode == 0) hipLaunchKernelGGL(k0, dim3((unsigned)grid), dim3(nw * 64), lds, st, a);
+    else hipLaunchKernelGGL(k1, dim3((unsigned)grid), dim3(nw * 64), lds, st, a);
     return hipGetLastError();
 }
 template <int LEN>
