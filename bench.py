@@ -579,7 +579,7 @@ def main():
         hp = md.Hyperparam(filter_len=args.filter_len, M=args.filters)
         Gt = args.train_groups
         St = Gt * hp.batch_size
-        cdl = md.ucdl(hp, L, ctx=ctx, seed=seed, arena_bytes=int((1.3 * Gt + 2) * (1 << 30)))
+        cdl = md.ucdl(hp, L, ctx=ctx, seed=seed, arena_bytes=int((0.3 * Gt + 2) * (1 << 30)))   # a step of Gt mini-batches peaks at 0.17 GiB per mini-batch (arena_peak_bytes)
         tcodes = sy.gen_codes(St, L, seed + 77 + 1000 * rank, n_plant=5, k=args.filter_len)
         traw = torch.from_numpy(tcodes).to(dev)
         tdev = torch.zeros(lib.Context.codes_bytes(St, L), dtype=torch.uint8, device=dev)

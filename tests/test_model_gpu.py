@@ -316,7 +316,7 @@ def test_step_sizes_take_different_kernels_and_agree(ctx, pkg, G):
     md, sy = pkg.model, pkg.synth
     hp = md.Hyperparam(filter_len=12, M=200)
     L = 200
-    cdl = md.ucdl(hp, L, ctx=ctx, seed=3, arena_bytes=int((1.3 * G + 2) * (1 << 30)))
+    cdl = md.ucdl(hp, L, ctx=ctx, seed=3, arena_bytes=int((0.3 * G + 2) * (1 << 30)))
     try:
         codes = sy.gen_codes(G * hp.batch_size, L, 91, n_plant=5, k=12)
         l_all, g_all = gpu_loss_grad(pkg, ctx, cdl, codes, G)

@@ -31,7 +31,7 @@ def main():
     hp = md.Hyperparam(filter_len=12, M=200)
     L, G = 200, a.groups
     S = G * hp.batch_size
-    cdl = md.ucdl(hp, L, ctx=ctx, seed=1, arena_bytes=int((1.3 * G + 2) * (1 << 30)))
+    cdl = md.ucdl(hp, L, ctx=ctx, seed=1, arena_bytes=int((0.3 * G + 2) * (1 << 30)))
     codes = sy.gen_codes(S, L, 78, n_plant=5, k=12)
     raw = torch.from_numpy(codes).cuda()
     dev = torch.zeros(lib.Context.codes_bytes(S, L), dtype=torch.uint8, device="cuda")
