@@ -527,18 +527,26 @@ def main():
             stage_ms = {"scan_cand": cms / reps_, "stage_hits_row_scan": oms / reps_, "emit_records": fms / reps_}
             hits_strand = sum(got_) / 2.0
             lenp_ = (int(ln.max()) + 3) // 4 * 4
-            # the other two stages against what bounds them.  Re-scoring: one LDS (or L2) gather of 2 bytes per position and candidate;
-            # the LDS delivers 64 lane accesses per clock and CU (64 banks), 256 CUs at 2.4 GHz.  Candidates >= hits (the count of
-            # candidates is not kept; hits are a lower bound of the gathers done).  Records: 14 B written + 4 B of staged word read per hit.
-            lds_rate = 64.0 * 256 * 2.4e9
-            gathers = hits_strand * lenp_
-            rescoring = {"kernel": ("stage_hits_cg (chunk groups: one group's table slice in LDS per block)" if plan_["cg_chunks"] else
-                                    "stage_hits (whole table in LDS, or gathered from L2 when it does not fit)"),
-                         "bound": "lds-gather", "achieved": gathers / (oms / (2 * reps_) * 1e-3) / 1e12, "peak": lds_rate / 1e12, "unit": "T lane-gathers/s",
-                         "frac": gathers / (oms / (2 * reps_) * 1e-3) / lds_rate, "gathers_per_strand_lower_bound": gathers,
+            # the other two stages against what bounds them.  Re-scoring (stage_hits / stage_hits_cg): VALU issue.  The counters of the
+            # chunk-group kernel at this bank shape (profiles/r04_cg_stage_counters.txt) show 65 % of its cycles issuing VALU instructions,
+            # 4.1 wave-instructions per hit, and LDS gathers at a few per cent of the LDS rate: the bound is the kernel's own instruction
+            # count against the chip's VALU issue rate (1024 SIMDs, one wave-instruction per 4 cycles, 2.4 GHz).
+            valu_peak = 1024 * 2.4e9 / 4.0
+            vf = os.path.join(ROOT, "profiles", "r04_cg_stage_valu.json")
+            ipw, vsrc = 4.1, None
+            if os.path.exists(vf):
+                with open(vf) as fh:
+                    vj = json.load(fh)
+                ipw, vsrc = vj["valu_wave_insts_per_hit"], {"file": os.path.relpath(vf, ROOT), "commit": vj.get("commit"), "kernel": vj.get("kernel")}
+            hits_per_s = hits_strand / (oms / (2 * reps_) * 1e-3)
+            rescoring = {"kernel": ("stage_hits_cg (chunk groups: one group's table slice in LDS per block) + row scan" if plan_["cg_chunks"] else
+                                    "stage_hits (whole table in the LDS of one 16-wave block per CU when it is past 64 KB) + row scan"),
+                         "bound": "valu-issue", "achieved": hits_per_s * ipw / 1e9, "peak": valu_peak / 1e9, "unit": "G wave-instructions/s",
+                         "frac": hits_per_s * ipw / valu_peak, "valu_wave_insts_per_hit": ipw, "insts_source": vsrc, "hits_per_s": hits_per_s,
+                         "lds_gather_frac_of_lds_rate": hits_strand * lenp_ / (oms / (2 * reps_) * 1e-3) / (64.0 * 256 * 2.4e9),
                          "ms_per_strand": oms / (2 * reps_),
-                         "note": "far below the LDS rate: the kernel is bound by VALU issue and the latency of its dependent chain (entry decode -> queue -> "
-                                 "code words -> gathers -> adds); counters in profiles/r04_cg_stage_counters.txt"}
+                         "note": "instructions per hit from the PMC pass of the chunk-group kernel at the configs[4] bank shape (the 16-wave form of "
+                                 "configs[3] issues about the same per candidate but walks 15x more empty cells per hit: its fraction is a lower bound)"}
             rec_bytes = hits_strand * 18.0
             records = {"kernel": "emit_records_cg" if plan_["cg_chunks"] else "emit_records", "bound": "hbm",
                        "achieved": rec_bytes / (fms / (2 * reps_) * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
