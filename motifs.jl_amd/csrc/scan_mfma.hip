@@ -1056,30 +1056,31 @@ __global__ __launch_bounds__(1024) void row_scan_blocks(const RowScan2 rs, int64
     }
 }
 
-// staged words -> records.  One wave per row; a row that overflowed its staging slots is re-scored from its cells.
-template <int LEN, bool LDS_TAB>
+// staged words -> records.  One wave per row; a row that overflowed its staging slots is re-scored from its cells (with the table in
+// L2: such rows are rare, and a table staged lazily in LDS needed a block barrier in every turn of this loop).  The waves are independent.
+// A row of BASELINE configs[1] holds ~100 hits, i.e. one turn: the row's count, its offsets and its first 128 staged words are
+// requested TOGETHER (the words speculatively: beyond the count they are whatever the slots held), one trip to memory per row
+// instead of three dependent ones.
+template <int LEN>
 __global__ __launch_bounds__(VF_THREADS) void emit_records(FillArgs a0, FillArgs a1) {
     const FillArgs& a = blockIdx.y ? a1 : a0;                         // blockIdx.y = strand
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: the row geometry stays on the scalar unit
     uint16_t* queue = (uint16_t*)smem + wv * QN;
-    uint32_t* ltab = smem + VF_WAVES * QN / 2;
-    const _Float16* tb = nullptr;                                     // staged lazily: only overflowed rows need the bank
-    bool staged = !LDS_TAB;
-    if (!LDS_TAB) tb = (const _Float16*)a.tabk;
+    const _Float16* tb = (const _Float16*)a.tabk;
     const int64_t nwaves = (int64_t)gridDim.x * VF_WAVES;
-    // block-uniform loop bounds so that the lazy staging barrier is reached by every wave
-    for (int64_t rb = (int64_t)blockIdx.x * VF_WAVES; rb < a.nrows; rb += nwaves) {
-        const int64_t r = rb + wv;
-        const uint32_t cnt = r < a.nrows ? a.row_sum[r] : 0u;
-        const bool big = cnt > (uint32_t)a.row_slots;
-        if (__syncthreads_or(big) && !staged) {
-            tb = stage_table<LDS_TAB, VF_THREADS>(a, ltab);
-            staged = true;
-        }
+    for (int64_t r = (int64_t)blockIdx.x * VF_WAVES + wv; r < a.nrows; r += nwaves) {
+        const uint32_t* slots = a.staging + (size_t)r * a.row_slots;
+        const uint32_t cnt = a.row_sum[r];
+        const uint32_t excl = a.row_excl[r];
+        const unsigned long long bbase = a.blk_base[r >> 10];
+        uint32_t e[4];
+        e[0] = lane < a.row_slots ? slots[lane] : 0u;
+        e[1] = 64 + lane < a.row_slots ? slots[64 + lane] : 0u;
         if (cnt == 0) continue;
+        const bool big = cnt > (uint32_t)a.row_slots;
         const RowGeom g = row_geom(a, r);
-        const int64_t row_at = (int64_t)a.blk_base[r >> 10] + a.row_excl[r];
+        const int64_t row_at = (int64_t)bbase + excl;
         auto put = [&](const int64_t at, const uint32_t k, const uint32_t nin, const uint16_t sc) {
             if (at < a.cap) {
                 a.hits[at] = HitRec{k + 1, (uint32_t)(g.nrow0 + nin + a.n0 + 1), (uint32_t)(g.l + 1)};
@@ -1089,18 +1090,16 @@ __global__ __launch_bounds__(VF_THREADS) void emit_records(FillArgs a0, FillArgs
         if (!big) {
             // four 256-byte loads of staged words in flight per wave (one at a time left the pass bound by load latency);
             // the capacity check is folded into the trip count
-            const uint32_t* slots = a.staging + (size_t)r * a.row_slots;
             const int64_t room = a.cap - row_at;
             const uint32_t lim = room <= 0 ? 0u : (room < (int64_t)cnt ? (uint32_t)room : cnt);
             HitRec* hrow = a.hits + row_at;
             uint16_t* srow = a.hit_scores + row_at;
             const uint32_t rec_n = (uint32_t)(g.nrow0 + a.n0 + 1), rec_l = (uint32_t)(g.l + 1);
             for (uint32_t j0 = 0; j0 < lim; j0 += 256) {
-                uint32_t e[4];
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     const uint32_t j = j0 + u * 64 + lane;
-                    e[u] = j < lim ? slots[j] : 0u;
+                    if (j0 != 0 || u >= 2) e[u] = j < lim ? slots[j] : 0u;        // (the first 128 words are already here)
                 }
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
@@ -1485,14 +1484,10 @@ static hipError_t launch_stage_len(const FillArgs& a, int mode, hipStream_t st, 
 template <int LEN>
 static hipError_t launch_emit_len(const FillArgs& a, hipStream_t st, const FillArgs* b) {
     const size_t base = (size_t)VF_WAVES * QN * 2;
-    const size_t tab_bytes = ((size_t)a.K * a.tabk_stride * 2 + 3) & ~(size_t)3;
     const unsigned grid = (unsigned)std::min<int64_t>((a.nrows + VF_WAVES - 1) / VF_WAVES, 256 * 8);
     const dim3 g2(b ? std::max(1u, (grid + 1) / 2) : grid, b ? 2 : 1, 1);
     const FillArgs& a1 = b ? *b : a;
-    if (base + tab_bytes <= 64 * 1024)
-        hipLaunchKernelGGL((emit_records<LEN, true>), g2, dim3(VF_THREADS), base + tab_bytes, st, a, a1);
-    else
-        hipLaunchKernelGGL((emit_records<LEN, false>), g2, dim3(VF_THREADS), base, st, a, a1);
+    hipLaunchKernelGGL((emit_records<LEN>), g2, dim3(VF_THREADS), base, st, a, a1);
     return hipGetLastError();
 }
 
