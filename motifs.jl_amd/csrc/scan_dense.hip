@@ -282,16 +282,18 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
             uint16_t* dst = a.out + ((size_t)l * a.N + n0) * a.K;
             typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
             constexpr int NV = DF_READS * 32 * NT / 8 / 64;           // 16-byte pieces per lane of the largest span this instance serves (32 reads x 32 NT PWMs)
+            // (the window is read whether or not anything was dropped into it - it is all zeros then: no selects in this loop; pieces past the
+            // span - a short last block, the unrolling's tail - are read from the window's own first bytes and not stored)
             uint4 v[NV];
+            const uint32_t i0 = (uint32_t)lane * 8;
 #pragma unroll
             for (int u = 0; u < NV; u++) {
-                const uint32_t i = (uint32_t)(u * 64 + lane) * 8;
-                v[u] = make_uint4(0u, 0u, 0u, 0u);
-                if (dirty && i < span) v[u] = *(const uint4*)(win + i);
+                const uint32_t i = i0 + (uint32_t)u * 512;
+                v[u] = *(const uint4*)(win + (i < span ? i : i0));
             }
 #pragma unroll
             for (int u = 0; u < NV; u++) {
-                const uint32_t i = (uint32_t)(u * 64 + lane) * 8;
+                const uint32_t i = i0 + (uint32_t)u * 512;
                 if (i < span) __builtin_nontemporal_store(u32x4{v[u].x, v[u].y, v[u].z, v[u].w}, (u32x4*)(dst + i));
             }
         }
