@@ -48,7 +48,7 @@ def _build(hipcc, OBJ, LIB, defs, verbose, force):
     os.makedirs(OBJ, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(HERE, "..", "include", "motifs_hip.h"))
-    objs = []
+    objs, cmds = [], []
     for f in sorted(os.listdir(CSRC)):
         if not f.endswith(".hip"):
             continue
@@ -56,10 +56,16 @@ def _build(hipcc, OBJ, LIB, defs, verbose, force):
         obj = os.path.join(OBJ, f[:-4] + ".o")
         objs.append(obj)
         if force or _newer([src] + headers, obj):
-            cmd = [hipcc] + COMMON + defs + EXTRA.get(f, []) + ["-c", src, "-o", obj]
+            cmds.append([hipcc] + COMMON + defs + EXTRA.get(f, []) + ["-c", src, "-o", obj])
+    if cmds:    # the translation units side by side (the largest, scan_mfma.hip, is half of a sequential build)
+        from concurrent.futures import ThreadPoolExecutor
+
+        def run(cmd):
             if verbose:
                 print("[build]", " ".join(cmd), file=sys.stderr, flush=True)
             subprocess.check_call(cmd)
+        with ThreadPoolExecutor(max_workers=min(len(cmds), max(1, (os.cpu_count() or 2) // 2))) as ex:
+            list(ex.map(run, cmds))
     if force or _newer(objs, LIB):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         if verbose:
