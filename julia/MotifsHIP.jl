@@ -60,6 +60,12 @@ end
 use_private_stream!(c::Context) = check(ccall((:motifs_ctx_use_private_stream, lib), Cint, (Ptr{Cvoid},), c.h))
 set_workspace_limit!(c::Context, bytes::Integer) =
     check(ccall((:motifs_ctx_set_workspace_limit, lib), Cint, (Ptr{Cvoid}, Csize_t), c.h, bytes))
+# diagnostics: how the last hit-record scan was laid out (compact entries, chunks per chunk group, groups, launches)
+function scan_plan(c::Context)
+    v = zeros(Int32, 4)
+    check(ccall((:motifs_ctx_scan_plan, lib), Cint, (Ptr{Cvoid}, Ptr{Int32}), c.h, v))
+    (compact = v[1] != 0, cg_chunks = Int(v[2]), cg_groups = Int(v[3]), launches = Int(v[4]))
+end
 
 const default_context = Ref{Union{Nothing, Context}}(nothing)
 context() = (default_context[] === nothing && (default_context[] = Context(0)); default_context[])
@@ -112,6 +118,12 @@ function Base.getproperty(m::ucdl, s::Symbol)
     getfield(m, s)
 end
 
+# bytes of the engine arena the steps so far needed at most: what `arena_bytes` has to cover
+function arena_peak(m::ucdl)
+    r = Ref{Csize_t}(0)
+    check(ccall((:motifs_model_arena_peak, lib), Cint, (Ptr{Cvoid}, Ref{Csize_t}), getfield(m, :h), r))
+    Int(r[])
+end
 function l1_syntax(m::ucdl)                       # sum(abs.(prep_syntax_filters(cdl.F))), train.jl:47
     r = Ref{Float32}(0)
     check(ccall((:motifs_model_l1_syntax, lib), Cint, (Ptr{Cvoid}, Ref{Float32}), getfield(m, :h), r))
