@@ -107,6 +107,7 @@ struct Engine {
         }
     };
     std::map<RelayoutKey, float*> derived;
+    std::map<const void*, uint32_t*> absmax_of;   // tensor -> bits of its largest magnitude (device), where a producer kernel keeps it (f16x3 GEMM scale)
     float* relayout(const float* src, int kind, int d0, int d1, int d2, size_t n, bool& fresh);   // fresh: the caller fills it
     float* zpool = nullptr;        // current pre-zeroed chunk (dies with the arena at reset())
     size_t zleft = 0;

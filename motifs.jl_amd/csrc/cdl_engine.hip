@@ -47,6 +47,7 @@ void Engine::reset() {
     named.clear();
     arena.reset();
     derived.clear();
+    absmax_of.clear();
     zpool = nullptr;
     zleft = 0;
     failed = false;
@@ -363,14 +364,29 @@ __global__ void k_resid_sumsq_bwd(const float* gout, const float* x, const float
 // a*x + b*y + c*z in one pass (z optional), one grid row per group of `per` elements.
 // ythr (optional): cat_ZY's median mask folded in as a threshold per group, y counts where y >= ythr[group]
 // (a constant in the backward, @ignore model.jl:208) - no 0/1 mask is ever written or read.
+// amax (optional, pre-zeroed): the bits of the largest |out| - the image this forms is the syntax-layer GEMM's operand, whose binary16
+// form (k_ana_f16x3) is scaled by it; one atomic per block, and only when it can raise the maximum
 __global__ void k_lin3(const float* x, float a, const float* y, const float* ythr, float b, const float* z, float c, size_t per,
-                       float* out) {
+                       float* out, uint32_t* amax) {
     const size_t base = (size_t)blockIdx.y * per;
     const float t = ythr ? ythr[blockIdx.y] : 0.0f;
+    uint32_t m = 0;
     for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < per; j += (size_t)gridDim.x * blockDim.x) {
         const size_t i = base + j;
         const float yv = y[i];
-        out[i] = a * x[i] + b * ((ythr && !(yv >= t)) ? 0.0f : yv) + (z ? c * z[i] : 0.0f);
+        const float o = a * x[i] + b * ((ythr && !(yv >= t)) ? 0.0f : yv) + (z ? c * z[i] : 0.0f);
+        out[i] = o;
+        m = max(m, __float_as_uint(o) & 0x7fffffffu);
+    }
+    if (amax) {
+        for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d));
+        __shared__ uint32_t wm[4];
+        if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            m = max(max(wm[0], wm[1]), max(wm[2], wm[3]));
+            if (m > __hip_atomic_load(amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(amax, m);
+        }
     }
 }
 // VJP of k_lin3: d{x,y,z} (+)= {a, b*[y >= thr], c} * go, go read once
@@ -730,7 +746,10 @@ Tensor Engine::lin3(Tensor x, float a, Tensor y, float b, Tensor z, float c, con
     const int G = ythr ? groups : 1;
     const size_t per = x->n / G;
     const dim3 grid(nblocks(per, 256, std::max<size_t>(256 * 32 / G, 1)), G);
-    hipLaunchKernelGGL(k_lin3, grid, dim3(256), 0, st, x->v, a, y->v, ythr, b, z ? z->v : nullptr, c, per, out->v);
+    uint32_t* am = (uint32_t*)zeros(1);
+    if (failed) return out;
+    absmax_of[out->v] = am;
+    hipLaunchKernelGGL(k_lin3, grid, dim3(256), 0, st, x->v, a, y->v, ythr, b, z ? z->v : nullptr, c, per, out->v, am);
     if (recording && out->needs_grad)
         tape.push_back([this, out, x, y, z, a, b, c, ythr, per, grid]() {
             if (!out->g) return;
@@ -806,7 +825,10 @@ Tensor Engine::lin3_zy(Tensor FX, Tensor zy, float b, Tensor abn, const float* t
     const int G = thr ? groups : 1;
     const size_t per = FX->n / G;
     const dim3 grid(nblocks(per, 256, std::max<size_t>(256 * 32 / G, 1)), G);
-    hipLaunchKernelGGL(k_lin3, grid, dim3(256), 0, st, FX->v, 1.0f, zy->v, thr, b, abn->v, 1.0f, per, out->v);
+    uint32_t* am = (uint32_t*)zeros(1);
+    if (failed) return out;
+    absmax_of[out->v] = am;
+    hipLaunchKernelGGL(k_lin3, grid, dim3(256), 0, st, FX->v, 1.0f, zy->v, thr, b, abn->v, 1.0f, per, out->v, am);
     if (recording && out->needs_grad) {            // no tape entry: zy_step2's VJP (the neighbour on the tape) picks this up
         zy->fl_img = out;
         zy->fl_x = FX;
@@ -1773,6 +1795,246 @@ static bool launch_ana_lds(Engine& e, const float* A, const float* Bm, float* C,
     return true;
 }
 
+// ---- the same contraction on the binary16 matrix instruction, three products per term ("f16x3") ----------------------------
+// k_ana_lds sits at 81 % matrix-pipe busy on v_mfma_f32_32x32x2_f32 (157 TFLOP/s peak): the largest kernel of a 64-mini-batch step.
+// v_mfma_f32_32x32x16_f16 runs 16x the flops per instruction cycle.  Each float32 operand x is split as hi = f16(x s), lo = f16(x s - hi)
+// (s a power of two that puts the tensor's largest magnitude just under 2^15, so that lo is a normal binary16 number for every entry
+// that matters: hi + lo carries 22 bits), and a b = hi_a hi_b + hi_a lo_b + lo_a hi_b to 2^-22, accumulated in float32 as before
+// (the two small products in an accumulator of their own).  Emulated on the shapes of this layer: 4e-8 of the largest output against
+// 3.5e-7 for a float32 GEMM with float32 accumulation.  Three instructions of 32 cycles replace eight of 64 per 16 reduction terms: the
+// kernel stops being bound by the matrix pipe and becomes bound by the filter fragments it pulls from L2, which is why a wave carries
+// NT row tiles per fragment (the float32 form re-reads the whole 614 KB bank per 32 output rows).
+__global__ void k_absmax(const float* __restrict__ x0, size_t n, size_t stride, int nseg, uint32_t* __restrict__ out) {   // out: pre-zeroed; bits of max |x|
+    // nseg segments of n floats, `stride` apart; blocks stride over the segments; ONE atomic per block, and only if it can raise the maximum
+    // (an atomic per wave - 15 000 on one address - took 185 us for 116 MB, the streaming itself 20)
+    uint32_t m = 0;
+    for (int sg = blockIdx.y; sg < nseg; sg += gridDim.y) {
+        const float* x = x0 + (size_t)sg * stride;
+        const bool al = (((uintptr_t)x) & 15) == 0;
+        const size_t n4 = al ? n / 4 : 0;
+        const float4* x4 = (const float4*)x;
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+            const float4 v = x4[i];
+            m = max(max(m, __float_as_uint(v.x) & 0x7fffffffu), __float_as_uint(v.y) & 0x7fffffffu);
+            m = max(max(m, __float_as_uint(v.z) & 0x7fffffffu), __float_as_uint(v.w) & 0x7fffffffu);
+        }
+        if (blockIdx.x == 0)
+            for (size_t i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) m = max(m, __float_as_uint(x[i]) & 0x7fffffffu);
+    }
+    for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d));
+    __shared__ uint32_t wm[4];
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = max(max(wm[0], wm[1]), max(wm[2], wm[3]));
+        if (m > __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out, m);
+    }
+}
+// the power of two that takes a tensor whose largest magnitude has the bits `mb` into [2^14, 2^15) (1 for an all-zero tensor; Inf / NaN
+// inputs give Inf / NaN outputs either way)
+static __device__ __forceinline__ int f16x3_scale_exp(uint32_t mb) {
+    const int e = (int)((mb >> 23) & 255u);
+    if (mb == 0 || e == 255) return 0;
+    const int se = 141 - (e ? e : 1);
+    return se > 120 ? 120 : se < -120 ? -120 : se;
+}
+// filter fragments: Bf16[g][q16][plane][lane] = 8 halves, plane 0 = hi, 1 = lo; lane (n = lane & 31, kb = lane >> 5) holds
+// B[g][16 q16 + 8 kb + i][min(n, N - 1)] * 2^seB, i < 8
+__global__ void k_frag_b16(const float* __restrict__ Bm, int G, int Q, int N, const uint32_t* __restrict__ bmax, uint4* __restrict__ out) {
+    const float sB = __uint_as_float((uint32_t)(f16x3_scale_exp(*bmax) + 127) << 23);
+    const size_t per = (size_t)(Q / 16) * 128, total = per * G;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t g = i / per, r = i - g * per;
+        const int lane = (int)(r & 63), plane = (int)((r >> 6) & 1);
+        const size_t q16 = r >> 7;
+        const int n = min(lane & 31, N - 1), kb = lane >> 5;
+        uint32_t w[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            uint32_t hh[2];
+#pragma unroll
+            for (int v = 0; v < 2; v++) {
+                const size_t q = 16 * q16 + 8 * kb + 2 * u + v;
+                const float x = Bm[g * (size_t)Q * N + q * N + n] * sB;
+                const _Float16 hi = (_Float16)x;
+                const _Float16 lo = (_Float16)(x - (float)hi);
+                hh[v] = (uint32_t)__builtin_bit_cast(uint16_t, plane ? lo : hi);
+            }
+            w[u] = hh[0] | (hh[1] << 16);
+        }
+        out[i] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
+template <int H, int CC, int NT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_ana_f16x3(const float* __restrict__ A, const uint4* __restrict__ Bf, float* __restrict__ C,
+                                                                                               ToepGeom gm, int acc, int tps, int64_t ldbf,
+                                                                                               const uint32_t* __restrict__ amax, const uint32_t* __restrict__ bmax) {
+    constexpr int RS = CC + 8, ROWS = 32 * NT + H, JW = H / 4, C4 = CC / 4, NV = (ROWS * C4 + 255) / 256, KT = CC / 16;
+    static_assert(CC % 16 == 0 && H % 4 == 0, "whole k-steps of 16 channels, four waves over the window rows");
+    extern __shared__ __attribute__((aligned(16))) uint16_t ldsh[];        // 2 buffers x 2 planes x [ROWS][RS] halves; at the end 4 x NT x [32][32] floats
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int job = blockIdx.x;
+    const int s = job / tps, p0 = (job - s * tps) * (32 * NT);
+    const int W = gm.sa, NCH = W / CC, N = gm.N;
+    const float* img = A + (size_t)s * gm.lda + gm.a0 + (size_t)p0 * W;
+    const int lim = gm.amax - gm.a0 - p0 * W;      // valid flat range seen from img
+    const int seA = f16x3_scale_exp(*amax), seB = f16x3_scale_exp(*bmax);
+    const float sA = __uint_as_float((uint32_t)(seA + 127) << 23);
+    const uint4* Bg = Bf + (size_t)(s / gm.B) * ldbf + lane;
+    float4 v[NV];
+    auto gload = [&](int c0) {
+#pragma unroll
+        for (int i = 0; i < NV; i++) {
+            const int idx = tid + i * 256, row = idx / C4, c4 = idx - row * C4;
+            const int flat = row * W + c0 + c4 * 4;
+            const bool ok = idx < ROWS * C4 && flat + 3 < lim;
+            const float4 x = *(const float4*)(img + (ok ? flat : 0));
+            v[i] = ok ? x : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto lstore = [&](uint16_t* buf) {             // buf: [2 planes][ROWS][RS]
+#pragma unroll
+        for (int i = 0; i < NV; i++) {
+            const int idx = tid + i * 256, row = idx / C4, c4 = idx - row * C4;
+            if (idx < ROWS * C4) {
+                const float x[4] = {v[i].x * sA, v[i].y * sA, v[i].z * sA, v[i].w * sA};
+                uint16_t hb[4], lb[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const _Float16 hi = (_Float16)x[u];
+                    const _Float16 lo = (_Float16)(x[u] - (float)hi);
+                    hb[u] = __builtin_bit_cast(uint16_t, hi), lb[u] = __builtin_bit_cast(uint16_t, lo);
+                }
+                uint16_t* d = buf + row * RS + c4 * 4;
+                *(uint2*)d = make_uint2((uint32_t)hb[0] | ((uint32_t)hb[1] << 16), (uint32_t)hb[2] | ((uint32_t)hb[3] << 16));
+                *(uint2*)(d + ROWS * RS) = make_uint2((uint32_t)lb[0] | ((uint32_t)lb[1] << 16), (uint32_t)lb[2] | ((uint32_t)lb[3] << 16));
+            }
+        }
+    };
+    f32x16 accM[NT], accS[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) accM[t][i] = 0.0f, accS[t][i] = 0.0f;
+    // fragments of (window row j, chunk ch): k-steps (j W + ch CC) / 16 + t, t < KT; per k-step 2 planes x 64 lanes of 16 bytes
+    auto bfrag = [&](int ch, int j, int t, int plane) -> uint4 { return Bg[(((size_t)j * W + (size_t)ch * CC) / 16 + t) * 128 + plane * 64]; };
+    uint4 bh[KT], bl[KT];
+    gload(0);
+#pragma unroll
+    for (int t = 0; t < KT; t++) bh[t] = bfrag(0, wave * JW, t, 0), bl[t] = bfrag(0, wave * JW, t, 1);
+    lstore(ldsh);
+    __syncthreads();
+    const int arow = (lane & 31), acol = 8 * (lane >> 5);
+    for (int ch = 0; ch < NCH; ch++) {
+        const uint16_t* buf = ldsh + (ch & 1) * (2 * ROWS * RS);
+        const bool more = ch + 1 < NCH;
+        if (more) gload((ch + 1) * CC);            // in flight under the MFMAs below
+#pragma unroll 1
+        for (int jj = 0; jj < JW; jj++) {
+            const int j = wave * JW + jj;
+            // the next window row's fragments are requested before this one's matrix instructions
+            uint4 nh[KT], nl[KT];
+            const bool last = jj + 1 == JW;
+            if (!last || more) {
+                const int nch = last ? ch + 1 : ch, nj = last ? wave * JW : j + 1;
+#pragma unroll
+                for (int t = 0; t < KT; t++) nh[t] = bfrag(nch, nj, t, 0), nl[t] = bfrag(nch, nj, t, 1);
+            }
+#pragma unroll
+            for (int t = 0; t < KT; t++) {
+                const f16x8v Bh = __builtin_bit_cast(f16x8v, bh[t]), Bl = __builtin_bit_cast(f16x8v, bl[t]);
+#pragma unroll
+                for (int rt = 0; rt < NT; rt++) {
+                    const uint16_t* ap = buf + (32 * rt + arow + j) * RS + 16 * t + acol;
+                    const f16x8v Ah = __builtin_bit_cast(f16x8v, *(const uint4*)ap);
+                    const f16x8v Al = __builtin_bit_cast(f16x8v, *(const uint4*)(ap + ROWS * RS));
+                    accM[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bh, accM[rt], 0, 0, 0);
+                    accS[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bl, accS[rt], 0, 0, 0);
+                    accS[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, Bh, accS[rt], 0, 0, 0);
+                }
+            }
+            if (!last || more) {
+#pragma unroll
+                for (int t = 0; t < KT; t++) bh[t] = nh[t], bl[t] = nl[t];
+            }
+        }
+        if (more) lstore(ldsh + ((ch + 1) & 1) * (2 * ROWS * RS));
+        __syncthreads();
+    }
+    // partial tiles -> LDS [wave][tile][row][32], scaled back; register r of lane l is (row (r&3) + 8*(r>>2) + 4*(l>>5), column l&31)
+    float* red = (float*)ldsh;
+    const float iA = __uint_as_float((uint32_t)(127 - seA) << 23), iB = __uint_as_float((uint32_t)(127 - seB) << 23);
+#pragma unroll
+    for (int rt = 0; rt < NT; rt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+            red[((wave * NT + rt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = ((accM[rt][r] + accS[rt][r]) * iA) * iB;
+    __syncthreads();
+    const int nrow = min(32 * NT, gm.P - p0);
+    float* Cs = C + (size_t)s * gm.ldc + (size_t)p0 * N;
+    const int total = nrow * N;                    // one contiguous span of the output
+    for (int e = tid; e < total; e += 256) {
+        const int row = e / N, col = e - row * N;
+        const float* q = red + row * 32 + col;     // tile row / 32, row % 32: consecutive tiles are 1024 floats apart, as rows are 32
+        const float o = (q[0] + q[NT * 1024]) + (q[2 * NT * 1024] + q[3 * NT * 1024]);
+        Cs[e] = acc ? Cs[e] + o : o;
+    }
+}
+template <int H, int CC>
+static bool launch_ana_f16x3(Engine& e, const float* A, const float* Bm, float* C, const ToepGeom& gm, int acc) {
+    static const bool off = getenv("MOTIFS_ANA_F32") != nullptr;        // A/B: the float32 matrix instruction for every launch
+    if (off) return false;
+    if (gm.sa <= 0 || gm.Q != H * gm.sa || gm.sa % CC != 0 || gm.N < 9 || gm.N > 32) return false;
+    if (gm.a0 < 0 || (int64_t)gm.a0 + (int64_t)(gm.P - 1) * gm.sa + gm.Q > gm.amax) return false;
+    if ((gm.sa & 15) || (gm.a0 & 3) || (gm.lda & 3) || (((uintptr_t)A) & 15)) return false;
+    if ((long)gm.S * ((gm.P + 31) / 32) < 1024) return false;              // steps of few reads keep the float32 form (its split over channel chunks)
+    const int gB = gm.ldb == 0 ? 1 : gm.S / gm.B;
+    const size_t perf = (size_t)(gm.Q / 16) * 128;                        // uint4 per bank
+    // the largest magnitudes (bits): of the bank (cached with its fragments) and of this call's image
+    bool fresh;
+    float* Bf = e.relayout(Bm, 7, gm.Q, gm.N, 0, perf * gB * 4 + 4, fresh);
+    uint32_t* am = (uint32_t*)e.zeros(1);
+    if (!Bf || !am) {
+        e.failed = true;
+        return true;
+    }
+    uint32_t* bm = (uint32_t*)(Bf + perf * gB * 4);
+    if (fresh) {
+        dev_zero(e.st, (float*)bm, 1);
+        hipLaunchKernelGGL(k_absmax, dim3(nblocks((size_t)gB * gm.Q * gm.N / 4 + 1, 256, 512)), dim3(256), 0, e.st, Bm, (size_t)gB * gm.Q * gm.N, (size_t)0, 1, bm);
+        hipLaunchKernelGGL(k_frag_b16, dim3(nblocks(perf * gB)), dim3(256), 0, e.st, Bm, gB, gm.Q, gm.N, bm, (uint4*)Bf);
+    }
+    // the image's largest magnitude: kept by the kernel that formed it (k_lin3), else one streaming pass over the windows' ranges
+    // (sequences are lda apart and use [a0, amax) of each)
+    const auto known = e.absmax_of.find((const void*)A);
+    if (known != e.absmax_of.end()) {
+        am = known->second;
+    } else {
+        const size_t nper = (size_t)(gm.amax - gm.a0);
+        const unsigned bx = (unsigned)std::max<size_t>(1, std::min<size_t>(8, nper / 4 / 1024));
+        const unsigned by = (unsigned)std::min<int>(gm.S, std::max<int>(1, 2048 / (int)bx));
+        hipLaunchKernelGGL(k_absmax, dim3(bx, by), dim3(256), 0, e.st, A + gm.a0, nper, (size_t)gm.lda, gm.S, am);
+    }
+    auto go = [&](auto nt) {
+        constexpr int NT = decltype(nt)::value;
+        const int tps = (gm.P + 32 * NT - 1) / (32 * NT);
+        const size_t lds = std::max<size_t>((size_t)2 * 2 * (32 * NT + H) * (CC + 8) * 2, (size_t)4 * NT * 4096);
+        auto kern = k_ana_f16x3<H, CC, NT>;
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3((unsigned)((long)gm.S * tps)), dim3(256), lds, e.st, A, (const uint4*)Bf, C, gm, acc, tps,
+                           (int64_t)(gm.ldb == 0 ? 0 : perf), am, bm);
+    };
+    static const int want_nt = getenv("MOTIFS_ANA_NT") ? atoi(getenv("MOTIFS_ANA_NT")) : 0;
+    // row tiles per wave: the fewest padded rows, then the most rows per fragment
+    const int pad2 = (gm.P + 63) / 64 * 64, pad3 = (gm.P + 95) / 96 * 96;
+    const int nt = want_nt ? want_nt : (pad3 <= pad2 ? 3 : 2);
+    if (nt == 3) go(std::integral_constant<int, 3>{});
+    else if (nt == 1) go(std::integral_constant<int, 1>{});
+    else go(std::integral_constant<int, 2>{});
+    return true;
+}
+
 // N <= 4 outputs (D-layer synthesis and its relatives: an image 4 bases wide): one row per lane, 4
 // accumulators, 8 waves = 2 row tiles of 64 x 4 slices of the reduction, wave-private LDS as above.
 __global__ __launch_bounds__(512) void k_toep_n4(const float* __restrict__ A, const float* __restrict__ Bm,
@@ -2421,7 +2683,7 @@ static void launch_toep(Engine& e, const float* A, const float* Bm, float* C, co
     }
     static const bool legacy = getenv("MOTIFS_TOEP_LEGACY") != nullptr;   // debugging aid: the pre-LDS kernels
     if (legacy) {
-    } else if (launch_ana_lds<12, 80>(e, A, Bm, C, gm, acc) || launch_ana_lds<12, 64>(e, A, Bm, C, gm, acc) ||
+    } else if (launch_ana_f16x3<12, 80>(e, A, Bm, C, gm, acc) || launch_ana_f16x3<12, 64>(e, A, Bm, C, gm, acc) || launch_ana_lds<12, 80>(e, A, Bm, C, gm, acc) || launch_ana_lds<12, 64>(e, A, Bm, C, gm, acc) ||
                launch_ana_lds<12, 32>(e, A, Bm, C, gm, acc) || launch_ana_lds<8, 64>(e, A, Bm, C, gm, acc) ||
                launch_ana_lds<8, 32>(e, A, Bm, C, gm, acc)) {
         return;
