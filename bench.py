@@ -663,14 +663,19 @@ def main():
                 "frac": a4_bytes / (a4_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_launch_ms": a4_ms, "algorithmic_bytes": a4_bytes,
                 "reads_per_launch": St, "bases_per_s": St * L / (a4_ms * 1e-3),
             },
-            "roofline": {
-                "kernel": "k_ana_lds (a7: conv(ZY, F, flipped=true), model.jl:214,251, on v_mfma_f32_32x32x2_f32; rows = reads x l, columns = K, "
-                          "reduction = h * 2M)",
-                "bound": "mfma", "achieved": a7_flops / (a7_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": a7_flops / (a7_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, "avg_launch_ms": a7_ms, "flops_per_launch": a7_flops,
-                "reads_per_launch": St, "traffic": a7_traffic,
-                "note": "algorithmic flops 2 * l * K * h * 2M per read (SURVEY 8d); the kernel pads K 24 -> 32 and l 178 -> 192",
-            },
+            "roofline": (lambda f16x3: {
+                "kernel": ("k_ana_f16x3 (a7: conv(ZY, F, flipped=true), model.jl:214,251, on v_mfma_f32_32x32x16_f16 with THREE products per term - every float32 operand "
+                           "split into two binary16 numbers, 22 bits - + the pass that finds the image's largest magnitude; MOTIFS_ANA_F32=1: k_ana_lds on "
+                           "v_mfma_f32_32x32x2_f32)") if f16x3 else
+                          "k_ana_lds (a7: conv(ZY, F, flipped=true), model.jl:214,251, on v_mfma_f32_32x32x2_f32; rows = reads x l, columns = K, reduction = h * 2M)",
+                "bound": "mfma", "achieved": a7_flops / (a7_ms * 1e-3) / 1e12, "peak": MFMA_F16_PEAK_TFLOPS / 3.0 if f16x3 else MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": a7_flops / (a7_ms * 1e-3) / 1e12 / (MFMA_F16_PEAK_TFLOPS / 3.0 if f16x3 else MFMA_F32_PEAK_TFLOPS),
+                "frac_of_f32_matrix_peak": a7_flops / (a7_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                "avg_launch_ms": a7_ms, "flops_per_launch": a7_flops, "reads_per_launch": St, "traffic": a7_traffic if not f16x3 else None,
+                "note": "algorithmic flops 2 * l * K * h * 2M per read (SURVEY 8d; the kernel pads K 24 -> 32 and l 178 -> 192).  f16x3: the peak is the dense f16 "
+                        "peak over the three matrix instructions a term costs; the kernel is no longer bound by the matrix pipe but by the filter fragments it "
+                        "pulls from L2 (437 MB per launch at three row tiles per fragment) and the 171 MB image from HBM",
+            })(os.environ.get("MOTIFS_ANA_F32") is None and St * ((l_rows + 31) // 32) >= 1024 and (2 * args.filters) % 16 == 0 and hp.h == 12),
             "step_hbm": step_hbm,
             "arena_peak_bytes": cdl.model.arena_peak(),
             "arena_peak_GiB_per_mini_batch": cdl.model.arena_peak() / Gt / 2**30,

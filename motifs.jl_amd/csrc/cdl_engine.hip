@@ -1988,7 +1988,10 @@ static bool launch_ana_f16x3(Engine& e, const float* A, const float* Bm, float* 
     if (gm.sa <= 0 || gm.Q != H * gm.sa || gm.sa % CC != 0 || gm.N < 9 || gm.N > 32) return false;
     if (gm.a0 < 0 || (int64_t)gm.a0 + (int64_t)(gm.P - 1) * gm.sa + gm.Q > gm.amax) return false;
     if ((gm.sa & 15) || (gm.a0 & 3) || (gm.lda & 3) || (((uintptr_t)A) & 15)) return false;
-    if ((long)gm.S * ((gm.P + 31) / 32) < 1024) return false;              // steps of few reads keep the float32 form (its split over channel chunks)
+    // steps of few reads keep the float32 form (its split over channel chunks); MOTIFS_ANA_F16_MIN_JOBS lowers the bar (tests: the
+    // one-mini-batch goldens through this kernel)
+    static const long min_jobs = getenv("MOTIFS_ANA_F16_MIN_JOBS") ? atol(getenv("MOTIFS_ANA_F16_MIN_JOBS")) : 1024;
+    if ((long)gm.S * ((gm.P + 31) / 32) < min_jobs) return false;
     const int gB = gm.ldb == 0 ? 1 : gm.S / gm.B;
     const size_t perf = (size_t)(gm.Q / 16) * 128;                        // uint4 per bank
     // the largest magnitudes (bits): of the bank (cached with its fragments) and of this call's image

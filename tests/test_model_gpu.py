@@ -307,6 +307,32 @@ def test_fused_forms_equal_the_separate_launches(ctx, pkg, tmp_path):
     assert rel_inf(outs["fused"]["flat"], outs["poisoned"]["flat"]) <= 1e-5
 
 
+def test_f16x3_syntax_gemm_meets_the_oracle(ctx, pkg, tmp_path):
+    """Steps of many mini-batches run the syntax-layer analysis GEMM on the binary16 matrix instruction with three products per term
+    (k_ana_f16x3: every float32 operand split into two binary16 numbers at a power-of-two scale).  MOTIFS_ANA_F16_MIN_JOBS=1 sends the
+    one-mini-batch configs[1] fixture through it (a fresh process: the switch is read once): loss and every gradient against the float64
+    oracle's at the tolerances of test_cfg2_golden, i.e. the split form is as close to the oracle as the float32 instruction."""
+    import subprocess
+    import sys
+    path = str(tmp_path / "f16x3.npz")
+    e = dict(os.environ)
+    e.pop("MOTIFS_ANA_F32", None)
+    e["MOTIFS_ANA_F16_MIN_JOBS"] = "1"
+    subprocess.run([sys.executable, os.path.join(HERE, "_df_literal_helper.py"), path], check=True, env=e, timeout=300)
+    out = np.load(path)
+    g = np.load(os.path.join(HERE, "golden", "model_cfg2.npz"))
+    hp = mo.Hyperparam(filter_len=12, M=200)
+    assert abs(out["loss"][0] - g["loss0"]) <= LOSS_RTOL * g["loss0"]
+    nD, nF = 48 * 200, 12 * 400 * 24
+    got = {"D": out["flat"][:nD], "F": out["flat"][nD:nD + nF]}
+    o = nD + nF
+    for name, n in zip(pkg_vec_fields(), pkg_vec_sizes(hp)):
+        got[name] = out["flat"][o:o + n]
+        o += n
+    for n in NAMES:
+        assert_grad(got[n], g[f"grad0_{n}"].astype(np.float64), n)
+
+
 @pytest.mark.parametrize("G", [16, 40, 64])
 def test_step_sizes_take_different_kernels_and_agree(ctx, pkg, G):
     """The engine picks its kernel forms by step size (per-read sparse gradients to 24 mini-batches, 2-row synthesis blocks and
