@@ -364,6 +364,7 @@ __global__ void k_resid_sumsq_bwd(const float* gout, const float* x, const float
 // a*x + b*y + c*z in one pass (z optional), one grid row per group of `per` elements.
 // ythr (optional): cat_ZY's median mask folded in as a threshold per group, y counts where y >= ythr[group]
 // (a constant in the backward, @ignore model.jl:208) - no 0/1 mask is ever written or read.
+constexpr size_t AMAX_MIN_N = (size_t)8 << 20;    // floats: images this large may feed k_ana_f16x3 (1024+ row tiles)
 // amax (optional, pre-zeroed): the bits of the largest |out| - the image this forms is the syntax-layer GEMM's operand, whose binary16
 // form (k_ana_f16x3) is scaled by it; one atomic per block, and only when it can raise the maximum
 __global__ void k_lin3(const float* x, float a, const float* y, const float* ythr, float b, const float* z, float c, size_t per,
@@ -746,9 +747,9 @@ Tensor Engine::lin3(Tensor x, float a, Tensor y, float b, Tensor z, float c, con
     const int G = ythr ? groups : 1;
     const size_t per = x->n / G;
     const dim3 grid(nblocks(per, 256, std::max<size_t>(256 * 32 / G, 1)), G);
-    uint32_t* am = (uint32_t*)zeros(1);
+    uint32_t* am = out->n >= AMAX_MIN_N ? (uint32_t*)zeros(1) : nullptr;   // (images of small steps never reach the binary16 GEMM)
     if (failed) return out;
-    absmax_of[out->v] = am;
+    if (am) absmax_of[out->v] = am;
     hipLaunchKernelGGL(k_lin3, grid, dim3(256), 0, st, x->v, a, y->v, ythr, b, z ? z->v : nullptr, c, per, out->v, am);
     if (recording && out->needs_grad)
         tape.push_back([this, out, x, y, z, a, b, c, ythr, per, grid]() {
@@ -825,9 +826,9 @@ Tensor Engine::lin3_zy(Tensor FX, Tensor zy, float b, Tensor abn, const float* t
     const int G = thr ? groups : 1;
     const size_t per = FX->n / G;
     const dim3 grid(nblocks(per, 256, std::max<size_t>(256 * 32 / G, 1)), G);
-    uint32_t* am = (uint32_t*)zeros(1);
+    uint32_t* am = out->n >= AMAX_MIN_N ? (uint32_t*)zeros(1) : nullptr;
     if (failed) return out;
-    absmax_of[out->v] = am;
+    if (am) absmax_of[out->v] = am;
     hipLaunchKernelGGL(k_lin3, grid, dim3(256), 0, st, FX->v, 1.0f, zy->v, thr, b, abn->v, 1.0f, per, out->v, am);
     if (recording && out->needs_grad) {            // no tape entry: zy_step2's VJP (the neighbour on the tape) picks this up
         zy->fl_img = out;
