@@ -379,15 +379,9 @@ __global__ void k_lin3(const float* x, float a, const float* y, const float* yth
         out[i] = o;
         m = max(m, __float_as_uint(o) & 0x7fffffffu);
     }
-    if (amax) {
+    if (amax) {                                     // per wave, no block barrier: the atomic itself only when it can raise the maximum
         for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d));
-        __shared__ uint32_t wm[4];
-        if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            m = max(max(wm[0], wm[1]), max(wm[2], wm[3]));
-            if (m > __hip_atomic_load(amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(amax, m);
-        }
+        if ((threadIdx.x & 63) == 0 && m > __hip_atomic_load(amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(amax, m);
     }
 }
 // VJP of k_lin3: d{x,y,z} (+)= {a, b*[y >= thr], c} * go, go read once
@@ -2611,6 +2605,132 @@ __global__ __launch_bounds__(256) void k_toep_wide(const float* __restrict__ A, 
         }
     }
 }
+// ---- k_toep_wide on the binary16 matrix instruction, three products per term (see k_ana_f16x3) ----
+// Here both operands are small - the block's windows (172 floats at stride 4) and the bank (48 x 400) - and the reduction (Q <= 64 terms) lies
+// inside one block, so the windows are scaled by the largest magnitude of the BLOCK's own span (found while it is staged in LDS; no pass over
+// the signal) and the bank by its own (cached with its fragments).  9 instructions of 32 cycles per 32 x 32 tile instead of 24 of 64.
+// Bf16[g][ct][t][plane][lane] = 8 halves: B[g][16 t + 8 kb + u][min(32 ct + n, N - 1)] * 2^seB, lane = (n, kb)
+__global__ void k_frag_bw16(const float* __restrict__ Bm, int G, int Q, int N, const uint32_t* __restrict__ bmax, uint4* __restrict__ out) {
+    const float sB = __uint_as_float((uint32_t)(f16x3_scale_exp(*bmax) + 127) << 23);
+    const int KT = Q / 16, NCT = (N + 31) / 32;
+    const size_t per = (size_t)NCT * KT * 128, total = per * G;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t g = i / per, r = i - g * per;
+        const int lane = (int)(r & 63), plane = (int)((r >> 6) & 1);
+        const size_t ctt = r >> 7;
+        const int t = (int)(ctt % KT), ct = (int)(ctt / KT);
+        const int col = min(32 * ct + (lane & 31), N - 1), kb = lane >> 5;
+        uint32_t w[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            uint32_t hh[2];
+#pragma unroll
+            for (int v = 0; v < 2; v++) {
+                const int q = 16 * t + 8 * kb + 2 * u + v;
+                const float x = Bm[g * (size_t)Q * N + (size_t)q * N + col] * sB;
+                const _Float16 hi = (_Float16)x;
+                const _Float16 lo = (_Float16)(x - (float)hi);
+                hh[v] = (uint32_t)__builtin_bit_cast(uint16_t, plane ? lo : hi);
+            }
+            w[u] = hh[0] | (hh[1] << 16);
+        }
+        out[i] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+template <int KT>
+__global__ __launch_bounds__(256) void k_toep_wide16(const float* __restrict__ A, const uint4* __restrict__ Bf, float* __restrict__ C, ToepGeom gm,
+                                                     int acc, int tps, int64_t ldbf, int SO, const uint32_t* __restrict__ bmax) {
+    extern __shared__ float lds[];                 // the block's 32 output rows, [32][SO]
+    __shared__ uint32_t wmax[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int job = blockIdx.x;
+    const int s = job / tps, p0 = (job - s * tps) * 32;
+    const float* sig = A + (size_t)s * gm.lda;
+    const uint4* bp = Bf + (size_t)(s / gm.B) * ldbf + lane;
+    const int nct = (gm.N + 31) >> 5;
+    uint4 cur[2 * KT], nxt[2 * KT];
+    if (wave < nct) {
+#pragma unroll
+        for (int q = 0; q < 2 * KT; q++) cur[q] = bp[(size_t)(wave * 2 * KT + q) * 64];
+    }
+    // the block's windows: their span (31 sa + Q floats) through LDS once, and its largest magnitude on the way
+    const int span = 31 * gm.sa + 16 * KT, e0 = gm.a0 + p0 * gm.sa;
+    uint32_t m = 0;
+    for (int i = tid; i < span; i += 256) {
+        const int e = e0 + i;
+        const bool ok = e >= 0 && e < gm.amax;
+        const float x = sig[ok ? e : 0];
+        lds[i] = ok ? x : 0.0f;
+        m = max(m, ok ? __float_as_uint(x) & 0x7fffffffu : 0u);
+    }
+    for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d));
+    if (lane == 0) wmax[wave] = m;
+    __syncthreads();
+    const int seA = f16x3_scale_exp(max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]))), seB = f16x3_scale_exp(*bmax);
+    const float sA = __uint_as_float((uint32_t)(seA + 127) << 23);
+    f16x8v ah[KT], al[KT];
+    {
+        const float* w = lds + (lane & 31) * gm.sa + 8 * (lane >> 5);
+#pragma unroll
+        for (int t = 0; t < KT; t++)
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const float x = w[16 * t + u] * sA;
+                const _Float16 hi = (_Float16)x;
+                ah[t][u] = hi;
+                al[t][u] = (_Float16)(x - (float)hi);
+            }
+    }
+    __syncthreads();                               // the tile stores below reuse the space
+    const float iA = __uint_as_float((uint32_t)(127 - seA) << 23), iB = __uint_as_float((uint32_t)(127 - seB) << 23);
+    for (int ct = wave; ct < nct; ct += 4) {       // wave w: column tiles w, w+4, ..
+        const int cn = min(ct + 4, nct - 1);
+#pragma unroll
+        for (int q = 0; q < 2 * KT; q++) nxt[q] = bp[(size_t)(cn * 2 * KT + q) * 64];
+        f32x16 accM, accS;
+#pragma unroll
+        for (int i = 0; i < 16; i++) accM[i] = 0.0f, accS[i] = 0.0f;
+#pragma unroll
+        for (int t = 0; t < KT; t++) {
+            const f16x8v Bh = __builtin_bit_cast(f16x8v, cur[2 * t]), Bl = __builtin_bit_cast(f16x8v, cur[2 * t + 1]);
+            accM = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], Bh, accM, 0, 0, 0);
+            accS = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], Bl, accS, 0, 0, 0);
+            accS = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[t], Bh, accS, 0, 0, 0);
+        }
+        const int col = ct * 32 + (lane & 31);
+        if (col < gm.N) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) lds[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * SO + col] = ((accM[r] + accS[r]) * iA) * iB;
+        }
+#pragma unroll
+        for (int q = 0; q < 2 * KT; q++) cur[q] = nxt[q];
+    }
+    __syncthreads();
+    // the rows leave whole: [nrow][N] is one contiguous span of the output
+    const int nrow = min(32, gm.P - p0), N4 = gm.N >> 2;
+    float* Cs = C + (size_t)s * gm.ldc + (size_t)p0 * gm.N;
+    if ((gm.N & 3) == 0 && (((uintptr_t)Cs) & 15) == 0) {
+        int row = tid / N4, c4 = tid - row * N4;
+        const int drow = 256 / N4, dc = 256 - drow * N4;
+        for (int idx = tid; idx < nrow * N4; idx += 256) {
+            float4 o = *(const float4*)(lds + row * SO + c4 * 4);
+            float4* dst = (float4*)Cs + idx;
+            if (acc) {
+                const float4 t = *dst;
+                o.x += t.x, o.y += t.y, o.z += t.z, o.w += t.w;
+            }
+            *dst = o;
+            row += drow, c4 += dc;
+            if (c4 >= N4) c4 -= N4, row++;
+        }
+    } else {
+        for (int idx = tid; idx < nrow * gm.N; idx += 256) {
+            const int row = idx / gm.N, col = idx - row * gm.N;
+            const float o = lds[row * SO + col];
+            Cs[idx] = acc ? Cs[idx] + o : o;
+        }
+    }
+}
 static bool launch_toep_wide(Engine& e, const float* A, const float* Bm, float* C, const ToepGeom& gm, int acc) {
     if (gm.N < 64 || gm.N > 480 || gm.Q > 64 || (gm.Q & 7) || gm.Q < 32) return false;
     const int KG = gm.Q / 8, NCT = (gm.N + 31) / 32;
@@ -2626,6 +2746,27 @@ static bool launch_toep_wide(Engine& e, const float* A, const float* Bm, float* 
     const int SO = ((gm.N + 15) & ~15) + 8;        // 4 rows apart = 32 banks apart: the two lane halves of a tile store never meet
     const size_t lds = (size_t)32 * SO * 4;
     const int64_t ldbf = gm.ldb == 0 ? 0 : (int64_t)perf;
+    static const bool f32_only = getenv("MOTIFS_TOEP_F32") != nullptr || getenv("MOTIFS_ANA_F32") != nullptr;   // A/B: the float32 matrix instruction
+    if (!f32_only && cs == 1 && (long)gm.S * tps >= 1024 && gm.Q % 16 == 0 && gm.sa > 0 && 31 * gm.sa + gm.Q <= 32 * SO) {
+        const int KT = gm.Q / 16;
+        const size_t perf16 = (size_t)NCT * KT * 128;                 // uint4 per bank
+        bool fresh16;
+        float* Bf16 = e.relayout(Bm, 8, gm.Q, gm.N, 0, perf16 * gB * 4 + 4, fresh16);
+        if (!Bf16) return true;
+        uint32_t* bm = (uint32_t*)(Bf16 + perf16 * gB * 4);
+        if (fresh16) {
+            dev_zero(e.st, (float*)bm, 1);
+            hipLaunchKernelGGL(k_absmax, dim3(nblocks((size_t)gB * gm.Q * gm.N / 4 + 1, 256, 512)), dim3(256), 0, e.st, Bm, (size_t)gB * gm.Q * gm.N, (size_t)0, 1, bm);
+            hipLaunchKernelGGL(k_frag_bw16, dim3(nblocks(perf16 * gB)), dim3(256), 0, e.st, Bm, gB, gm.Q, gm.N, bm, (uint4*)Bf16);
+        }
+        const int64_t ldbf16 = gm.ldb == 0 ? 0 : (int64_t)perf16;
+#define TOEPWIDE16(K) hipLaunchKernelGGL((k_toep_wide16<K>), grid, dim3(256), lds, e.st, A, (const uint4*)Bf16, C, gm, acc, tps, ldbf16, SO, bm)
+        if (KT == 2) TOEPWIDE16(2);
+        else if (KT == 3) TOEPWIDE16(3);
+        else TOEPWIDE16(4);
+#undef TOEPWIDE16
+        return true;
+    }
 #define TOEPWIDE(K) hipLaunchKernelGGL((k_toep_wide<K>), grid, dim3(256), lds, e.st, A, Bf, C, gm, acc, tps, ldbf, SO, cs)
     if (KG == 4) TOEPWIDE(4);
     else if (KG == 5) TOEPWIDE(5);
