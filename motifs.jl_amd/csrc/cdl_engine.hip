@@ -1835,7 +1835,7 @@ static __device__ __forceinline__ int f16x3_scale_exp(uint32_t mb) {
 }
 // filter fragments: Bf16[g][q16][plane][lane] = 8 halves, plane 0 = hi, 1 = lo; lane (n = lane & 31, kb = lane >> 5) holds
 // B[g][16 q16 + 8 kb + i][min(n, N - 1)] * 2^seB, i < 8
-__global__ void k_frag_b16(const float* __restrict__ Bm, int G, int Q, int N, const uint32_t* __restrict__ bmax, uint4* __restrict__ out) {
+__global__ void k_frag_b_hilo(const float* __restrict__ Bm, int G, int Q, int N, const uint32_t* __restrict__ bmax, uint4* __restrict__ out) {
     const float sB = __uint_as_float((uint32_t)(f16x3_scale_exp(*bmax) + 127) << 23);
     const size_t per = (size_t)(Q / 16) * 128, total = per * G;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -1861,6 +1861,8 @@ __global__ void k_frag_b16(const float* __restrict__ Bm, int G, int Q, int N, co
     }
 }
 typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
 template <int H, int CC, int NT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_ana_f16x3(const float* __restrict__ A, const uint4* __restrict__ Bf, float* __restrict__ C,
                                                                                                ToepGeom gm, int acc, int tps, int64_t ldbf,
@@ -2001,7 +2003,7 @@ static bool launch_ana_f16x3(Engine& e, const float* A, const float* Bm, float* 
     if (fresh) {
         dev_zero(e.st, (float*)bm, 1);
         hipLaunchKernelGGL(k_absmax, dim3(nblocks((size_t)gB * gm.Q * gm.N / 4 + 1, 256, 512)), dim3(256), 0, e.st, Bm, (size_t)gB * gm.Q * gm.N, (size_t)0, 1, bm);
-        hipLaunchKernelGGL(k_frag_b16, dim3(nblocks(perf * gB)), dim3(256), 0, e.st, Bm, gB, gm.Q, gm.N, bm, (uint4*)Bf);
+        hipLaunchKernelGGL(k_frag_b_hilo, dim3(nblocks(perf * gB)), dim3(256), 0, e.st, Bm, gB, gm.Q, gm.N, bm, (uint4*)Bf);
     }
     // the image's largest magnitude: kept by the kernel that formed it (k_lin3), else one streaming pass over the windows' ranges
     // (sequences are lda apart and use [a0, amax) of each)
@@ -2462,6 +2464,7 @@ static bool launch_tall_fused(Engine& e, const float* A, const float* Bt, float*
     return true;
 }
 
+static bool launch_rowgemm16(Engine& e, const float* A, const float* Bm, float* C, const ToepGeom& rg, int acc, int groups, long rpg, int tpg);
 // rows must be contiguous ([S][P][Q] with nothing between sequences), Q a multiple of 16 up to 480, N <= 64
 static bool launch_rowgemm_lds(Engine& e, const float* A, const float* Bm, float* C, const ToepGeom& rg, int acc) {
     if (rg.a0 != 0 || rg.sa != rg.Q || rg.lda != (int64_t)rg.P * rg.Q || rg.ldc != (int64_t)rg.P * rg.N) return false;
@@ -2469,6 +2472,7 @@ static bool launch_rowgemm_lds(Engine& e, const float* A, const float* Bm, float
     const int groups = rg.ldb == 0 ? 1 : rg.S / rg.B;
     const long rpg = (long)(rg.S / groups) * rg.P;
     const int tpg = (int)((rpg + 31) / 32);
+    if (launch_rowgemm16(e, A, Bm, C, rg, acc, groups, rpg, tpg)) return true;
     const size_t perf = (size_t)(rg.Q / 4) * 256;
     bool fresh;
     float* Bf = e.relayout(Bm, 2, rg.Q, rg.N, 0, perf * groups, fresh);
@@ -2637,6 +2641,256 @@ __global__ void k_frag_bw16(const float* __restrict__ Bm, int G, int Q, int N, c
         out[i] = make_uint4(w[0], w[1], w[2], w[3]);
     }
 }
+// ---- k_rowgemm_lds on the same instruction: C[r][n] = sum_q A[r][q] B[q][n], rows of Q floats read once ----
+// The float32 form is a block per 32 rows that loads, then multiplies, then writes: co-resident blocks run in step, so HBM idles while the matrix
+// pipe works (34 us with the matrix loop removed, 49 with it, 26 at the HBM rate).  Prefetching the next rows from the same waves does not help on
+// gfx9: a wave's memory loads return in order (vmcnt), so the first wait for a filter fragment is a wait for the whole prefetch in front of it
+// (a persistent form with the next tile in flight and this instruction measured the same 48.6 us).  So the waves take ROLES here, each with its own
+// counter: one block of 8 waves per CU for the whole launch; waves 0-3 only move rows (8 rows of a tile each: global -> registers -> hi / lo
+// planes in LDS, scaled by the largest magnitude of their 8 rows, each register asked for its piece of the tile after next as soon as it is
+// converted), waves 4-7 only multiply (the bank's fragments - k_frag_bw16's [g][ct][t][plane][lane] - sit in their registers for the whole launch,
+// every fourth k-step of 16 channels each, partial tiles met in LDS) and write the finished rows.  One block barrier per tile: the row planes and
+// the partial tiles are both double buffered.  What the time is (s_memtime per wave and turn, -DRG16_TIMING + tools/rg16_timing.py): a mover and a
+// multiplier share each SIMD and their instructions do not overlap - a turn costs the SUM of the conversion (12 vector instructions per 16 bytes),
+// the 42 matrix instructions and the tile's write-out, ~4 900 cycles against ~4 500 for a tile at the HBM rate; the first three turns (cold
+// fragments, code and pages) cost ~7 000 each.  48.6 -> ~40 us per launch; the depth of the movers' ring (1, 2 or 3 tiles) does not matter.
+#ifdef RG16_TIMING
+__device__ unsigned long long g_rg16_ts[256][2][16][5];
+#define RG16_TS(role, turn, k) \
+    if (lane == 0 && (wave & 3) == 0 && (turn) < 16) g_rg16_ts[blockIdx.x][role][turn][k] = __builtin_amdgcn_s_memtime()
+#else
+#define RG16_TS(role, turn, k)
+#endif
+template <int NCT, int KS, int NV, int RING = 2>
+__global__ __launch_bounds__(512) void k_rowgemm16(const float* __restrict__ A, const uint4* __restrict__ Bf, float* __restrict__ C, int rpg, int tpg,
+                                                   int ntiles, int Q, int N, int64_t ldbf, int acc, const uint32_t* __restrict__ bmax) {
+    // NV: 16-byte loads per mover lane (8 rows of Q <= 32 NV floats); RW: partial-tile row stride, 4 rows apart = 32 banks apart
+    extern __shared__ __attribute__((aligned(16))) uint16_t ldsr[];        // 2 x (hi [32][RS], lo [32][RS]) halves; 2 x 4 x [32][RW] floats
+    __shared__ int sexp[2][4];                     // scale exponent of (buffer, 8-row group)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int RS = Q + 8, Q4 = Q >> 2, KT = Q >> 4;                         // rows 4 * odd dwords apart: conflict-free 16-byte operand reads
+    const int plane = 32 * RS, bufsz = 2 * plane;
+    const int RW = ((N + 15) & ~15) + 8;
+    float* red0 = (float*)(ldsr + 2 * bufsz);
+    const int nmine = blockIdx.x < ntiles ? (ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;     // tiles of this block: blockIdx.x + j gridDim.x
+    // RING: tiles a mover has in flight (register sets)
+    const int nturns = (nmine + RING) / RING * RING;   // nmine + 1 turns, rounded up to the movers' ring
+    if (wave < 4) {
+        // ---- movers ----
+        float4 v[RING][NV];
+        const int nf8 = 8 * Q4;
+        // where tile j's 8 rows of this wave lie: rows past the end of the group are never written out - their lanes re-read the last valid
+        // 16 bytes - and a turn past the block's last tile re-reads the first 16 bytes of A (no branch, no select: the same NV loads on every
+        // path, so the wait for one tile's registers leaves the tiles behind it in flight)
+        auto rows_of = [&](int j, const float4*& At, int& last) {
+            const int tile = blockIdx.x + (j < nmine ? j : 0) * gridDim.x, g = tile / tpg, r0 = (tile - g * tpg) * 32 + 8 * wave;
+            const int nf4 = j < nmine ? max(0, min(8, rpg - r0)) * Q4 : 0;
+            last = max(nf4, 1) - 1;
+            At = (const float4*)(A + (nf4 > 0 ? ((size_t)g * rpg + r0) * Q : (size_t)0));
+        };
+        // where a lane's pieces go in its wave's 8 rows of a plane (halves); the pieces past the 8 rows go to the 8 spare halves behind row 0
+        int lofs[NV];
+#pragma unroll
+        for (int i = 0; i < NV; i++) {
+            const int idx = lane + i * 64, row = idx / Q4, c4 = idx - row * Q4;
+            lofs[i] = idx < nf8 ? row * RS + c4 * 4 : Q;
+        }
+        // one turn: the tile in vs goes to buffer j & 1 as hi / lo planes, and every register is asked for its piece of tile j + RING as soon as
+        // it has been converted.  12 vector instructions per 16 bytes: packed multiply, packed conversions, the remainder x s - hi as a packed fma
+        auto turn = [&](float4* vs, int j) {
+            float mf = 0.0f;
+#pragma unroll
+            for (int i = 0; i < NV; i++) mf = fmaxf(fmaxf(fmaxf(fmaxf(mf, fabsf(vs[i].x)), fabsf(vs[i].y)), fabsf(vs[i].z)), fabsf(vs[i].w));
+            uint32_t m = __float_as_uint(mf);
+            for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d));
+            const int seA = f16x3_scale_exp(m);
+            RG16_TS(0, j, 1);
+            const float sA = __uint_as_float((uint32_t)(seA + 127) << 23);
+            uint16_t* buf = ldsr + (j & 1) * bufsz + 8 * wave * RS;
+            if (lane == 0) sexp[j & 1][wave] = seA;
+            const float4* An;
+            int lastn;
+            rows_of(j + RING, An, lastn);
+#pragma unroll
+            for (int i = 0; i < NV; i++) {
+                f32x2v p0 = {vs[i].x, vs[i].y}, p1 = {vs[i].z, vs[i].w};
+                p0 *= sA, p1 *= sA;
+                const f16x2v h0 = __builtin_convertvector(p0, f16x2v), h1 = __builtin_convertvector(p1, f16x2v);
+                const f32x2v r0 = p0 - __builtin_convertvector(h0, f32x2v), r1 = p1 - __builtin_convertvector(h1, f32x2v);
+                const f16x2v l0 = __builtin_convertvector(r0, f16x2v), l1 = __builtin_convertvector(r1, f16x2v);
+                uint16_t* d = buf + lofs[i];
+                *(uint2*)d = make_uint2(__builtin_bit_cast(uint32_t, h0), __builtin_bit_cast(uint32_t, h1));
+                *(uint2*)(d + plane) = make_uint2(__builtin_bit_cast(uint32_t, l0), __builtin_bit_cast(uint32_t, l1));
+                vs[i] = An[min(lane + i * 64, lastn)];
+            }
+        };
+#pragma unroll
+        for (int u = 0; u < RING; u++) {
+            const float4* At;
+            int last;
+            rows_of(u, At, last);
+#pragma unroll
+            for (int i = 0; i < NV; i++) v[u][i] = At[min(lane + i * 64, last)];
+        }
+        for (int j3 = 0; j3 < nturns; j3 += RING) {   // turn j: tile j into buffer j & 1 (the multipliers are on tile j - 1)
+#pragma unroll
+            for (int u = 0; u < RING; u++) {
+                RG16_TS(0, j3 + u, 0);
+                turn(v[u], j3 + u);                // (a turn past the last tile converts what the filler loads brought: finite, never read)
+                RG16_TS(0, j3 + u, 2);
+                __syncthreads();
+                RG16_TS(0, j3 + u, 3);
+            }
+        }
+    } else {
+        // ---- multipliers ----
+        const int cw = wave - 4, ctid = tid - 256;
+        const int seB = f16x3_scale_exp(*bmax);
+        const float iB = __uint_as_float((uint32_t)(127 - seB) << 23);
+        uint4 bfr[KS][2 * NCT];
+        auto bload = [&](int g) {
+            const uint4* bp = Bf + (size_t)g * ldbf + lane;
+#pragma unroll
+            for (int k = 0; k < KS; k++) {
+                const int t = min(cw + 4 * k, KT - 1);
+#pragma unroll
+                for (int ct = 0; ct < NCT; ct++)
+                    bfr[k][2 * ct] = bp[(size_t)((ct * KT + t) * 2) * 64], bfr[k][2 * ct + 1] = bp[(size_t)((ct * KT + t) * 2 + 1) * 64];
+            }
+        };
+        int cur_g = (int)blockIdx.x / tpg;         // the first tile's bank: on its way while the movers fetch that tile
+        bload(cur_g);
+        int qofs[2];                               // where this thread's 16-byte pieces of a finished tile start in the partial tiles
+#pragma unroll
+        for (int it = 0; it < 2; it++) {
+            const int e = (ctid + 256 * it) * 4, row = e / N;
+            qofs[it] = row * RW + (e - row * N);
+        }
+        const int arow = lane & 31, acol = 8 * (lane >> 5);
+        for (int j = 0; j < nturns; j++) {         // turn j: tile j - 1 out of buffer (j - 1) & 1
+            const int jt = j - 1;
+            const bool work = jt >= 0 && jt < nmine;
+            RG16_TS(1, j, 0);
+            const int tile = blockIdx.x + (work ? jt : 0) * gridDim.x, g = tile / tpg, r0 = (tile - g * tpg) * 32;
+            if (work) {
+                if (g != cur_g) {                  // (never when the bank is shared)
+                    bload(g);
+                    cur_g = g;
+                }
+                f32x16 accM[NCT], accS[NCT];
+                const uint16_t* ap = ldsr + (jt & 1) * bufsz + arow * RS + acol;
+                {                                  // the first k-step (cw < 4 <= KT) starts the sums from the constant 0
+                    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    const f16x8v Ah = __builtin_bit_cast(f16x8v, *(const uint4*)(ap + 16 * cw));
+                    const f16x8v Al = __builtin_bit_cast(f16x8v, *(const uint4*)(ap + 16 * cw + plane));
+#pragma unroll
+                    for (int ct = 0; ct < NCT; ct++) {
+                        const f16x8v Bh = __builtin_bit_cast(f16x8v, bfr[0][2 * ct]), Bl = __builtin_bit_cast(f16x8v, bfr[0][2 * ct + 1]);
+                        accM[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bh, zero, 0, 0, 0);
+                        accS[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bl, zero, 0, 0, 0);
+                        accS[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, Bh, accS[ct], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int k = 1; k < KS; k++) {
+                    const int t = cw + 4 * k;
+                    if (t < KT) {
+                        const f16x8v Ah = __builtin_bit_cast(f16x8v, *(const uint4*)(ap + 16 * t));
+                        const f16x8v Al = __builtin_bit_cast(f16x8v, *(const uint4*)(ap + 16 * t + plane));
+#pragma unroll
+                        for (int ct = 0; ct < NCT; ct++) {
+                            const f16x8v Bh = __builtin_bit_cast(f16x8v, bfr[k][2 * ct]), Bl = __builtin_bit_cast(f16x8v, bfr[k][2 * ct + 1]);
+                            accM[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bh, accM[ct], 0, 0, 0);
+                            accS[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bl, accS[ct], 0, 0, 0);
+                            accS[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, Bh, accS[ct], 0, 0, 0);
+                        }
+                    }
+                }
+                // register r of lane l is row (r & 3) + 8 (r >> 2) + 4 (l >> 5): rows of 8-row group r >> 2, scaled back by that group's factor
+                float iA[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) iA[q] = __uint_as_float((uint32_t)(127 - sexp[jt & 1][q]) << 23);
+                float* red = red0 + (j & 1) * (128 * RW);
+#pragma unroll
+                for (int ct = 0; ct < NCT; ct++)
+                    if (ct * 32 + (lane & 31) < N) {
+#pragma unroll
+                        for (int r = 0; r < 16; r++)
+                            red[(cw * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * RW + ct * 32 + (lane & 31)] = ((accM[ct][r] + accS[ct][r]) * iA[r >> 2]) * iB;
+                    }
+            }
+            RG16_TS(1, j, 1);
+            __syncthreads();                       // the one barrier of a turn: tile j is in its planes, tile j - 1's partial sums in theirs
+            RG16_TS(1, j, 2);
+            const float* red = red0 + (j & 1) * (128 * RW);
+            if (work) {
+                const int nrow = min(32, rpg - r0);
+                float* Cs = C + ((size_t)g * rpg + r0) * N;
+                const int total = nrow * N;        // one contiguous span of the output
+                if ((N & 3) == 0 && (((uintptr_t)Cs) & 15) == 0) {
+#pragma unroll
+                    for (int it = 0; it < 2; it++) {   // (32 N / 4 <= 512 pieces of 16 bytes)
+                        const int e = (ctid + 256 * it) * 4;
+                        if (e >= total) break;
+                        const float* q = red + qofs[it];
+                        const float4 p0 = *(const float4*)q, p1 = *(const float4*)(q + 32 * RW), p2 = *(const float4*)(q + 64 * RW), p3 = *(const float4*)(q + 96 * RW);
+                        float4 o = make_float4((p0.x + p1.x) + (p2.x + p3.x), (p0.y + p1.y) + (p2.y + p3.y), (p0.z + p1.z) + (p2.z + p3.z),
+                                               (p0.w + p1.w) + (p2.w + p3.w));
+                        float4* dst = (float4*)(Cs + e);
+                        if (acc) {
+                            const float4 t = *dst;
+                            o.x += t.x, o.y += t.y, o.z += t.z, o.w += t.w;
+                        }
+                        *dst = o;
+                    }
+                } else {
+                    for (int e = ctid; e < total; e += 256) {
+                        const int row = e / N, col = e - row * N;
+                        const float* q = red + row * RW + col;
+                        const float o = (q[0] + q[32 * RW]) + (q[64 * RW] + q[96 * RW]);
+                        Cs[e] = acc ? Cs[e] + o : o;
+                    }
+                }
+            }
+            RG16_TS(1, j, 3);
+        }
+    }
+}
+#ifdef RG16_TIMING
+extern "C" int motifs_debug_rg16_ts(void* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rg16_ts), sizeof(g_rg16_ts)); }
+#endif
+static bool launch_rowgemm16(Engine& e, const float* A, const float* Bm, float* C, const ToepGeom& rg, int acc, int groups, long rpg, int tpg) {
+    static const bool f32_only = getenv("MOTIFS_ROWGEMM_F32") != nullptr || getenv("MOTIFS_ANA_F32") != nullptr;     // A/B: the float32 matrix instruction
+    static const long min_tiles = getenv("MOTIFS_ROWGEMM_F16_MIN_TILES") ? atol(getenv("MOTIFS_ROWGEMM_F16_MIN_TILES")) : 1024;
+    const long ntiles = (long)groups * tpg;
+    if (f32_only || ntiles < min_tiles || ntiles > (1l << 30) || rpg > (1l << 30)) return false;
+    const int KT = rg.Q / 16, NCT = (rg.N + 31) / 32;
+    const size_t lds = (size_t)2 * 2 * 32 * (rg.Q + 8) * 2 + (size_t)2 * 4 * 32 * (((rg.N + 15) & ~15) + 8) * 4;
+    if (lds + 64 > 160 * 1024) return false;
+    const size_t perf16 = (size_t)NCT * KT * 128;                     // uint4 per bank
+    bool fresh16;
+    float* Bf16 = e.relayout(Bm, 8, rg.Q, rg.N, 0, perf16 * groups * 4 + 4, fresh16);
+    if (!Bf16) return true;
+    uint32_t* bm = (uint32_t*)(Bf16 + perf16 * groups * 4);
+    if (fresh16) {
+        dev_zero(e.st, (float*)bm, 1);
+        hipLaunchKernelGGL(k_absmax, dim3(nblocks((size_t)groups * rg.Q * rg.N / 4 + 1, 256, 512)), dim3(256), 0, e.st, Bm, (size_t)groups * rg.Q * rg.N, (size_t)0, 1, bm);
+        hipLaunchKernelGGL(k_frag_bw16, dim3(nblocks(perf16 * groups)), dim3(256), 0, e.st, Bm, groups, rg.Q, rg.N, bm, (uint4*)Bf16);
+    }
+    const dim3 grid((unsigned)std::min<long>(ntiles, 256));           // one block per CU, there for the whole launch
+    const int64_t ldbf = rg.ldb == 0 ? 0 : (int64_t)perf16;
+    auto go = [&](auto kern) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, grid, dim3(512), lds, e.st, A, (const uint4*)Bf16, C, (int)rpg, tpg, (int)ntiles, rg.Q, rg.N, ldbf, acc, bm);
+    };
+    const int KS = (KT + 3) / 4;                   // k-steps per multiplier wave; 16-byte loads per mover lane: Q / 32
+    if (NCT == 1 && rg.Q <= 416) go(k_rowgemm16<1, 7, 13>);
+    else if (NCT == 1) go(k_rowgemm16<1, 8, 15>);
+    else if (rg.Q <= 416) go(k_rowgemm16<2, 7, 13>);
+    else go(k_rowgemm16<2, 8, 15>);
+    (void)KS;
+    return true;
+}
 template <int KT>
 __global__ __launch_bounds__(256) void k_toep_wide16(const float* __restrict__ A, const uint4* __restrict__ Bf, float* __restrict__ C, ToepGeom gm,
                                                      int acc, int tps, int64_t ldbf, int SO, const uint32_t* __restrict__ bmax) {
@@ -2741,13 +2995,15 @@ static bool launch_toep_wide(Engine& e, const float* A, const float* Bm, float* 
     if (!Bf) return true;
     if (fresh) hipLaunchKernelGGL(k_frag_bw, dim3(nblocks(perf * gB)), dim3(256), 0, e.st, Bm, gB, gm.Q, gm.N, Bf);
     const int tps = (gm.P + 31) / 32;
-    const int cs = (long)gm.S * tps < 256 ? std::min(4, NCT) : 1;      // few reads: four blocks per row tile, a wave per column tile
+    static const bool f32_only = getenv("MOTIFS_TOEP_F32") != nullptr || getenv("MOTIFS_ANA_F32") != nullptr;   // A/B: the float32 matrix instruction
+    static const long min_jobs16 = getenv("MOTIFS_TOEP_F16_MIN_JOBS") ? atol(getenv("MOTIFS_TOEP_F16_MIN_JOBS")) : 1024;   // (tests: 1)
+    const bool want16 = !f32_only && (long)gm.S * tps >= min_jobs16 && gm.Q % 16 == 0 && gm.sa > 0;
+    const int cs = !want16 && (long)gm.S * tps < 256 ? std::min(4, NCT) : 1;      // few reads: four blocks per row tile, a wave per column tile
     const dim3 grid((unsigned)((long)gm.S * tps * cs));
     const int SO = ((gm.N + 15) & ~15) + 8;        // 4 rows apart = 32 banks apart: the two lane halves of a tile store never meet
     const size_t lds = (size_t)32 * SO * 4;
     const int64_t ldbf = gm.ldb == 0 ? 0 : (int64_t)perf;
-    static const bool f32_only = getenv("MOTIFS_TOEP_F32") != nullptr || getenv("MOTIFS_ANA_F32") != nullptr;   // A/B: the float32 matrix instruction
-    if (!f32_only && cs == 1 && (long)gm.S * tps >= 1024 && gm.Q % 16 == 0 && gm.sa > 0 && 31 * gm.sa + gm.Q <= 32 * SO) {
+    if (want16 && 31 * gm.sa + gm.Q <= 32 * SO) {
         const int KT = gm.Q / 16;
         const size_t perf16 = (size_t)NCT * KT * 128;                 // uint4 per bank
         bool fresh16;

@@ -318,6 +318,8 @@ def test_f16x3_syntax_gemm_meets_the_oracle(ctx, pkg, tmp_path):
     e = dict(os.environ)
     e.pop("MOTIFS_ANA_F32", None)
     e["MOTIFS_ANA_F16_MIN_JOBS"] = "1"
+    e["MOTIFS_ROWGEMM_F16_MIN_TILES"] = "1"        # and the D-layer GEMMs in the same form (k_rowgemm16, k_toep_wide16)
+    e["MOTIFS_TOEP_F16_MIN_JOBS"] = "1"
     subprocess.run([sys.executable, os.path.join(HERE, "_df_literal_helper.py"), path], check=True, env=e, timeout=300)
     out = np.load(path)
     g = np.load(os.path.join(HERE, "golden", "model_cfg2.npz"))
@@ -339,13 +341,21 @@ def test_step_sizes_take_different_kernels_and_agree(ctx, pkg, G):
     split row walks below 192 reads, the fused tall form to ~100 reads, fused bank forms for small banks, ...).  The one-mini-batch
     forms are held against the float64 oracle (test_cfg2_golden); here a launch of G mini-batches at the configs[1] shape - 16: the
     middle forms, 40: the large-step forms, 64: the step bench.py times - against G launches of one: the same losses, and the sum of the gradients."""
-    md, sy = pkg.model, pkg.synth
-    hp = md.Hyperparam(filter_len=12, M=200)
+    sy = pkg.synth
+    hp = mo.Hyperparam(filter_len=12, M=200)
     L = 200
-    cdl = md.ucdl(hp, L, ctx=ctx, seed=3, arena_bytes=int((0.3 * G + 2) * (1 << 30)))
+    # the state of the configs[1] fixture: its codes survive the shrinkage (loss ~150 of 200; at the library's own init every code dies in
+    # the first pass and the code-image GEMMs would multiply zeros)
+    gold = np.load(os.path.join(HERE, "golden", "model_cfg2.npz"))
+    cdl_o = mo.UCDL(hp, np.random.default_rng(0)).to(torch.float64)
+    for n in mo.PARAM_VECS + ["D", "F"]:
+        setattr(cdl_o, n, torch.tensor(gold["init_" + n].astype(np.float64)))
+    cdl_o.lambda_sparsity_warmup, cdl_o.lambda_stepsize_warmup, cdl_o.omega_stepsize_warmup = [float(x) for x in gold["warm"]]
+    cdl = to_model(pkg, ctx, hp, L, cdl_o, arena=int((0.3 * G + 2) * (1 << 30)))
     try:
         codes = sy.gen_codes(G * hp.batch_size, L, 91, n_plant=5, k=12)
         l_all, g_all = gpu_loss_grad(pkg, ctx, cdl, codes, G)
+        assert np.all(l_all < 190.0), "the codes died: this test would compare zeros"
         l_one, g_sum = [], np.zeros(cdl.model.nP, dtype=np.float64)
         for g in range(G):
             l, gr = gpu_loss_grad(pkg, ctx, cdl, codes[g * hp.batch_size:(g + 1) * hp.batch_size], 1)
