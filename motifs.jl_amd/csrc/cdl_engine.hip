@@ -3305,6 +3305,222 @@ __global__ __launch_bounds__(NW * 64) void k_rowwgrad_lds(const float* __restric
         }
     }
 }
+// ---- the same filter gradient on the binary16 matrix instruction, three products per term, waves in two roles (see k_rowgemm16) ----
+// The float32 kernel above is bound by the matrix pipe where two of its blocks share a CU (384 reads over 256 CUs: 7 200 instructions of 32
+// cycles on four pipes = 24 us of its 48).  Here a GROUP's B R rows are cut into tiles of 32 and dealt to nbg blocks, one block of 8 waves per CU:
+// waves 0-3 move (8 rows of the A tile and of the C tile each: global -> registers -> hi / lo planes in LDS, ROW-major, so the loads stay
+// 16-byte coalesced), waves 4-7 multiply: the operands of part[q][n] = sum_r A[r][q] C[r][n] run down the rows, and ds_read_b64_tr_b16 hands
+// a lane 4 rows of one column (tools/ubench/tr_read_probe.hip) - two such reads are the 8 consecutive k of a 16x16x32 operand.  The sums of a
+// block stay in its multipliers' registers over all its tiles (25 x 3 tiles of 16 x 16 over four waves) and leave once, as one partial bank
+// per block.  Scales: the reduction runs ACROSS rows, so a tile's rows share one power of two per operand - the largest magnitude the block has
+// seen so far (LDS atomic max, then the first of the turn's two barriers); when it grows the multipliers rescale their sums (factors <= 1).
+typedef __fp16 h16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+template <int QW, int NV>
+__global__ __launch_bounds__(512) void k_rowwgrad16(const float* __restrict__ A, const float* __restrict__ C, float* __restrict__ part, int R, int Q, int N,
+                                                    int tps, int B, int nbg, int tpb, RowSrc cs) {
+    constexpr int CS = 56, NB = 3;                 // C planes' row stride (halves); 16-column blocks of the 48 columns
+    extern __shared__ __attribute__((aligned(16))) uint16_t ldsw[];        // 2 x (A hi, lo [32][RS]) halves, 2 x (C hi, lo [32][CS])
+    __shared__ uint32_t wmax[2][2];                // (turn parity) -> the largest |A|, |C| this block has met up to that turn's tile (bits)
+    __shared__ int sexp[2][2];                     // (buffer) -> scale exponents of A and C
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int RS = Q + 8, Q4 = Q >> 2, QB = Q >> 4, N4 = N >> 2;
+    const int planeA = 32 * RS, bufA = 2 * planeA, planeC = 32 * CS, bufC = 2 * planeC;
+    uint16_t* ldsC = ldsw + 2 * bufA;
+    const int g = blockIdx.x / nbg, piece = blockIdx.x - g * nbg;
+    const int T = B * tps, t0 = piece * tpb, nmine = max(0, min(T, t0 + tpb) - t0);
+    const int nturns = (nmine + 2) / 2 * 2;        // nmine + 1 turns, rounded up to the movers' two register sets
+    if (tid < 4) wmax[tid >> 1][tid & 1] = 0;
+    __syncthreads();
+    if (wave < 4) {
+        // ---- movers ----
+        float4 v[2][NV], vc[2][2];                 // two tiles on their way (register sets)
+        const int nf8 = 8 * Q4, nc8 = 8 * N4;
+        int lofs[NV];
+#pragma unroll
+        for (int i = 0; i < NV; i++) {
+            const int idx = lane + i * 64, row = idx / Q4, c4 = idx - row * Q4;
+            lofs[i] = idx < nf8 ? row * RS + c4 * 4 : Q;       // (pieces past the 8 rows: the 8 spare halves behind row 0)
+        }
+        int crow[2], cc4[2];
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int idx = lane + i * 64;
+            crow[i] = idx / N4, cc4[i] = idx - crow[i] * N4;
+        }
+        // the same NV + 2 loads on every path (a turn past the block's last tile re-reads the first 16 bytes of A and of C): the wait for one
+        // tile's registers then leaves the other tile's loads in flight
+        auto gload = [&](float4* va, float4* vcs, int j) -> int {
+            int okm = 0;
+            const bool live = j < nmine;
+            const int tt = t0 + (live ? j : 0), sl = tt / tps, r0 = (tt - sl * tps) * 32 + 8 * wave;
+            const size_t s = (size_t)g * B + sl;
+            // A: rows past the read's end re-read its last valid 16 bytes (their C rows are zeros)
+            const int nf4 = live ? max(0, min(8, R - r0)) * Q4 : 0, last = max(nf4, 1) - 1;
+            const float4* At = (const float4*)(A + (nf4 > 0 ? (s * R + r0) * Q : (size_t)0));
+#pragma unroll
+            for (int i = 0; i < NV; i++) va[i] = At[min(lane + i * 64, last)];
+            const float4* Cg = (const float4*)(C + (cs.mode == 0 ? s * R * N : s * (size_t)cs.ld));
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                const int r = r0 + crow[i], c = cc4[i];
+                bool ok = live && lane + i * 64 < nc8 && r < R;
+                size_t at = (size_t)r * N4 + c;
+                if (cs.mode == 1) {
+                    const int ip = c / cs.n4s, row = r - ip - cs.off;
+                    ok = ok && row >= 0 && row < cs.P;
+                    at = (size_t)row * cs.n4s + (c - ip * cs.n4s);
+                } else if (cs.mode == 2) {
+                    const int e = cs.a0 + r * cs.sa + 4 * c;
+                    ok = ok && e >= 0 && e + 3 < cs.amax;
+                    at = (size_t)(e >> 2);
+                }
+                vcs[i] = Cg[ok ? at : 0];          // (what is not ok is zeroed when the tile is converted, not here: nothing waits on a load yet)
+                okm |= ok ? 1 << i : 0;
+            }
+            return okm;
+        };
+        // the largest magnitudes of the tile in a register set, pushed (with everything before it: `sofar`) into the slot of its turn's parity:
+        // every mover reads a turn's slot after the barrier in front of that turn and nobody writes it during the turn, so the four waves
+        // convert a tile with one scale
+        auto push_max = [&](const float4* va, const float4* vcs, int okm, int j, uint32_t sofarA, uint32_t sofarC) {
+            float ma = 0.0f, mc = 0.0f;
+#pragma unroll
+            for (int i = 0; i < NV; i++) ma = fmaxf(fmaxf(fmaxf(fmaxf(ma, fabsf(va[i].x)), fabsf(va[i].y)), fabsf(va[i].z)), fabsf(va[i].w));
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+                if (okm >> i & 1) mc = fmaxf(fmaxf(fmaxf(fmaxf(mc, fabsf(vcs[i].x)), fabsf(vcs[i].y)), fabsf(vcs[i].z)), fabsf(vcs[i].w));
+            uint32_t ua = max(__float_as_uint(ma), sofarA), uc = max(__float_as_uint(mc), sofarC);
+            for (int d = 32; d >= 1; d >>= 1) ua = max(ua, (uint32_t)__shfl_xor((int)ua, d)), uc = max(uc, (uint32_t)__shfl_xor((int)uc, d));
+            if (lane == 0) {
+                atomicMax(&wmax[j & 1][0], ua);
+                atomicMax(&wmax[j & 1][1], uc);
+            }
+        };
+        int okc[2];
+        okc[0] = gload(v[0], vc[0], 0);
+        okc[1] = gload(v[1], vc[1], 1);
+        if (nmine > 0) push_max(v[0], vc[0], okc[0], 0, 0u, 0u);
+        __syncthreads();
+        for (int j2 = 0; j2 < nturns; j2 += 2) {   // turn j: tile j into buffer j & 1 (the multipliers are on tile j - 1)
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int j = j2 + u;
+                float4* va = v[u];
+                float4* vcs = vc[u];
+                const uint32_t mA = wmax[u][0], mC = wmax[u][1];
+                if (j < nmine) {
+                    const int seA = f16x3_scale_exp(mA), seC = f16x3_scale_exp(mC);
+                    if (tid == 0) sexp[u][0] = seA, sexp[u][1] = seC;
+                    const float sA = __uint_as_float((uint32_t)(seA + 127) << 23), sC = __uint_as_float((uint32_t)(seC + 127) << 23);
+                    uint16_t* buf = ldsw + u * bufA + 8 * wave * RS;
+#pragma unroll
+                    for (int i = 0; i < NV; i++) {
+                        f32x2v p0 = {va[i].x, va[i].y}, p1 = {va[i].z, va[i].w};
+                        p0 *= sA, p1 *= sA;
+                        const f16x2v h0 = __builtin_convertvector(p0, f16x2v), h1 = __builtin_convertvector(p1, f16x2v);
+                        const f32x2v r0 = p0 - __builtin_convertvector(h0, f32x2v), r1 = p1 - __builtin_convertvector(h1, f32x2v);
+                        const f16x2v l0 = __builtin_convertvector(r0, f16x2v), l1 = __builtin_convertvector(r1, f16x2v);
+                        uint16_t* d = buf + lofs[i];
+                        *(uint2*)d = make_uint2(__builtin_bit_cast(uint32_t, h0), __builtin_bit_cast(uint32_t, h1));
+                        *(uint2*)(d + planeA) = make_uint2(__builtin_bit_cast(uint32_t, l0), __builtin_bit_cast(uint32_t, l1));
+                    }
+                    uint16_t* cbuf = ldsC + u * bufC + 8 * wave * CS;
+#pragma unroll
+                    for (int i = 0; i < 2; i++) {
+                        if (lane + i * 64 < nc8) {
+                            const float sz = (okc[u] >> i & 1) ? sC : 0.0f;
+                            f32x2v p0 = {vcs[i].x, vcs[i].y}, p1 = {vcs[i].z, vcs[i].w};
+                            p0 *= sz, p1 *= sz;
+                            const f16x2v h0 = __builtin_convertvector(p0, f16x2v), h1 = __builtin_convertvector(p1, f16x2v);
+                            const f32x2v r0 = p0 - __builtin_convertvector(h0, f32x2v), r1 = p1 - __builtin_convertvector(h1, f32x2v);
+                            const f16x2v l0 = __builtin_convertvector(r0, f16x2v), l1 = __builtin_convertvector(r1, f16x2v);
+                            uint16_t* d = cbuf + crow[i] * CS + cc4[i] * 4;
+                            *(uint2*)d = make_uint2(__builtin_bit_cast(uint32_t, h0), __builtin_bit_cast(uint32_t, h1));
+                            *(uint2*)(d + planeC) = make_uint2(__builtin_bit_cast(uint32_t, l0), __builtin_bit_cast(uint32_t, l1));
+                        }
+                    }
+                }
+                okc[u] = gload(va, vcs, j + 2);    // in flight over this barrier and the other tile's turn
+                if (j + 1 < nmine) push_max(v[u ^ 1], vc[u ^ 1], okc[u ^ 1], j + 1, mA, mC);    // (requested a turn ago)
+                __syncthreads();
+            }
+        }
+    } else {
+        // ---- multipliers ----
+        const int cw = wave - 4;
+        f32x4 acc[QW][NB];
+#pragma unroll
+        for (int k = 0; k < QW; k++)
+#pragma unroll
+            for (int nb = 0; nb < NB; nb++) acc[k][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        int curA = 0, curC = 0;
+        bool scaled = false;
+        // a lane's piece of a transposed read: row 8 (lane >> 4) + ((lane & 15) >> 2) of the block, columns 4 (lane & 3) .. + 3
+        const int trow = 8 * (lane >> 4) + ((lane & 15) >> 2), tcol = 4 * (lane & 3);
+        const int aoff = trow * RS + tcol + 16 * cw, coff = trow * CS + tcol;
+        typedef __attribute__((address_space(3))) h16x4* lds_h4;
+        auto tr8 = [&](const uint16_t* p, int rowstride) -> f16x8v {      // 8 consecutive rows of one column: two transposed reads
+            const h16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_h4)(p)), hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_h4)(p + 4 * rowstride));
+            const uint2 a = __builtin_bit_cast(uint2, lo), b = __builtin_bit_cast(uint2, hi);
+            return __builtin_bit_cast(f16x8v, make_uint4(a.x, a.y, b.x, b.y));
+        };
+        __syncthreads();                           // (the movers' first maxima)
+        for (int j = 0; j < nturns; j++) {         // turn j: tile j - 1 out of buffer (j - 1) & 1
+            const int jt = j - 1, b = jt & 1;
+            const bool work = jt >= 0 && jt < nmine;
+            const uint16_t* ap = ldsw + b * bufA + aoff;
+            const uint16_t* cp = ldsC + b * bufC + coff;
+            f16x8v ch[NB], cl[NB];
+            auto qblocks = [&](int k0, int k1) {
+#pragma unroll
+                for (int k = k0; k < k1; k++) {
+                    if (cw + 4 * k < QB) {
+                        const f16x8v ah = tr8(ap + 64 * k, RS), al = tr8(ap + 64 * k + planeA, RS);
+#pragma unroll
+                        for (int nb = 0; nb < NB; nb++) acc[k][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, ch[nb], acc[k][nb], 0, 0, 0);
+#pragma unroll
+                        for (int nb = 0; nb < NB; nb++) acc[k][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, cl[nb], acc[k][nb], 0, 0, 0);
+#pragma unroll
+                        for (int nb = 0; nb < NB; nb++) acc[k][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, ch[nb], acc[k][nb], 0, 0, 0);
+                    }
+                }
+            };
+            if (work) {
+                const int eA = sexp[b][0], eC = sexp[b][1];
+                if (scaled && (eA != curA || eC != curC)) {        // a larger magnitude has turned up: the sums so far go to the new (smaller) scale
+                    const int de = (eA - curA) + (eC - curC);
+                    const float f = de < -126 ? 0.0f : __uint_as_float((uint32_t)(de + 127) << 23);
+#pragma unroll
+                    for (int k = 0; k < QW; k++)
+#pragma unroll
+                        for (int nb = 0; nb < NB; nb++) acc[k][nb] *= f;
+                }
+                curA = eA, curC = eC, scaled = true;
+#pragma unroll
+                for (int nb = 0; nb < NB; nb++) ch[nb] = tr8(cp + 16 * nb, CS), cl[nb] = tr8(cp + 16 * nb + planeC, CS);
+                qblocks(0, QW);
+            }
+            __syncthreads();
+        }
+        // one partial bank per block: part[blockIdx.x][q][n]; register r of lane l is (q = 4 (l >> 4) + r, n = l & 15) of its tile
+        const float iA = __uint_as_float((uint32_t)(127 - curA) << 23), iC = __uint_as_float((uint32_t)(127 - curC) << 23);
+        float* out = part + (size_t)blockIdx.x * Q * N;
+#pragma unroll
+        for (int k = 0; k < QW; k++) {
+            const int qb = cw + 4 * k;
+            if (qb < QB) {
+#pragma unroll
+                for (int nb = 0; nb < NB; nb++) {
+                    const int n = 16 * nb + (lane & 15);
+                    if (n < N) {
+#pragma unroll
+                        for (int r = 0; r < 4; r++) out[(size_t)(16 * qb + 4 * (lane >> 4) + r) * N + n] = (acc[k][nb][r] * iA) * iC;
+                    }
+                }
+            }
+        }
+    }
+}
 // blocks per sequence of k_rowwgrad_lds: 1 when the sequences alone fill the chip
 static int rowwgrad_split(const ToepGeom& rg) {
     const int tiles = (rg.P + 31) / 32;
@@ -3318,9 +3534,34 @@ static bool rowwgrad_lds_ok(const float* A, const ToepGeom& rg) {
     if ((rg.Q & 15) || rg.Q > 480 || rg.Q < 64 || rg.N < 33 || rg.N > 48 || (rg.N & 3)) return false;
     return (((uintptr_t)A) & 15) == 0;
 }
-static bool launch_rowwgrad_lds(Engine& e, const float* A, const float* C, float* part, const ToepGeom& rg, const RowSrc* src = nullptr) {
+// nparts: partial banks per group that `part` holds afterwards (rg.B * rowwgrad_split(rg) reserved by the caller)
+static bool launch_rowwgrad_lds(Engine& e, const float* A, const float* C, float* part, const ToepGeom& rg, const RowSrc* src = nullptr, int* nparts = nullptr) {
     if (!rowwgrad_lds_ok(A, rg) || (((uintptr_t)C) & 15)) return false;
     const RowSrc cs = src ? *src : RowSrc{0, 0, 0, 0, 0, 0, 0, 0};
+    if (nparts) *nparts = rg.B * rowwgrad_split(rg);
+    {
+        static const bool f32_only = getenv("MOTIFS_ROWWGRAD_F32") != nullptr || getenv("MOTIFS_ANA_F32") != nullptr;   // A/B: the float32 matrix instruction
+        static const long min_tiles = getenv("MOTIFS_ROWWGRAD_F16_MIN_TILES") ? atol(getenv("MOTIFS_ROWWGRAD_F16_MIN_TILES")) : 1024;
+        const int tps = (rg.P + 31) / 32, G = rg.S / rg.B, T = rg.B * tps;
+        const size_t lds16 = (size_t)2 * 2 * 32 * (rg.Q + 8) * 2 + (size_t)2 * 2 * 32 * 56 * 2;
+        if (!f32_only && nparts && (long)G * T >= min_tiles && lds16 + 64 <= 160 * 1024) {
+            // one block per CU where the groups allow it, each with a run of a group's tiles and one partial bank
+            int nbg = std::max(1, std::min(T, (256 + G / 2) / G));
+            nbg = std::min(nbg, *nparts);
+            const int tpb = (T + nbg - 1) / nbg;
+            nbg = (T + tpb - 1) / tpb;
+            auto go = [&](auto kern) {
+                (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);
+                hipLaunchKernelGGL(kern, dim3((unsigned)(G * nbg)), dim3(512), lds16, e.st, A, C, part, rg.P, rg.Q, rg.N, tps, rg.B, nbg, tpb, cs);
+            };
+            const int QB = rg.Q / 16;
+            if (QB <= 28 && rg.Q <= 416) go(k_rowwgrad16<7, 13>);
+            else if (QB <= 28) go(k_rowwgrad16<7, 15>);
+            else go(k_rowwgrad16<8, 15>);
+            *nparts = nbg;
+            return true;
+        }
+    }
     auto pad16 = [](int x) { return x + ((16 - x % 32) + 32) % 32; };     // smallest stride >= x that is 16 mod 32
     const int ST = pad16(rg.Q), SN = pad16(48);
     const size_t lds = (size_t)32 * (ST + SN) * 4;
@@ -3458,8 +3699,8 @@ static void launch_wgrad(Engine& e, const float* A, const float* C, float* dB, c
             int nparts = rg.B * TS;                // partial banks per group
             const RowSrc scat{1, gm.N / 4, gm.a0 / gm.sa, gm.P, 0, 0, 0, gm.ldc};
             if (in_kernel) {
-                (void)launch_rowwgrad_lds(e, A, C, part, rg, &scat);
-            } else if (legacy_rows || !launch_rowwgrad_lds(e, A, dW, part, rg)) {
+                (void)launch_rowwgrad_lds(e, A, C, part, rg, &scat, &nparts);
+            } else if (legacy_rows || !launch_rowwgrad_lds(e, A, dW, part, rg, nullptr, &nparts)) {
                 hipLaunchKernelGGL(k_wgrad_mfma, dim3((rg.Q + 127) / 128, gm.S, (rg.N + 31) / 32), dim3(256), 0, st, A, dW, part, r1, 0);
                 nparts = rg.B;
             }
@@ -3489,11 +3730,12 @@ static void launch_wgrad(Engine& e, const float* A, const float* C, float* dB, c
                                rowwgrad_lds_ok(C, rg) && (((uintptr_t)A) & 15) == 0;
         const RowSrc win{2, 0, 0, 0, gm.a0, gm.sa, gm.amax, gm.lda};
         if (!in_kernel) hipLaunchKernelGGL(k_windows, dim3(nblocks((size_t)gm.S * gm.P * gm.Q)), dim3(256), 0, st, A, gm, Wn);
-        if (in_kernel ? launch_rowwgrad_lds(e, C, A, part, rg, &win) : launch_rowwgrad_lds(e, C, Wn, part, rg)) {
+        int nparts = 0;
+        if (in_kernel ? launch_rowwgrad_lds(e, C, A, part, rg, &win, &nparts) : launch_rowwgrad_lds(e, C, Wn, part, rg, nullptr, &nparts)) {
             if (G * ((gm.N + 31) / 32) >= 128)
-                hipLaunchKernelGGL(k_sum_segments_T<32>, dim3((gm.N + 31) / 32, G), dim3(256), 0, st, part, gm.Q, gm.N, gm.B * rowwgrad_split(rg), dB, acc);
+                hipLaunchKernelGGL(k_sum_segments_T<32>, dim3((gm.N + 31) / 32, G), dim3(256), 0, st, part, gm.Q, gm.N, nparts, dB, acc);
             else
-                hipLaunchKernelGGL(k_sum_segments_T<4>, dim3((gm.N + 3) / 4, G), dim3(256), 0, st, part, gm.Q, gm.N, gm.B * rowwgrad_split(rg), dB, acc);
+                hipLaunchKernelGGL(k_sum_segments_T<4>, dim3((gm.N + 3) / 4, G), dim3(256), 0, st, part, gm.Q, gm.N, nparts, dB, acc);
             return;
         }
     }

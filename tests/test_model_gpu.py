@@ -320,6 +320,7 @@ def test_f16x3_syntax_gemm_meets_the_oracle(ctx, pkg, tmp_path):
     e["MOTIFS_ANA_F16_MIN_JOBS"] = "1"
     e["MOTIFS_ROWGEMM_F16_MIN_TILES"] = "1"        # and the D-layer GEMMs in the same form (k_rowgemm16, k_toep_wide16)
     e["MOTIFS_TOEP_F16_MIN_JOBS"] = "1"
+    e["MOTIFS_ROWWGRAD_F16_MIN_TILES"] = "1"       # and their filter gradients (k_rowwgrad16)
     subprocess.run([sys.executable, os.path.join(HERE, "_df_literal_helper.py"), path], check=True, env=e, timeout=300)
     out = np.load(path)
     g = np.load(os.path.join(HERE, "golden", "model_cfg2.npz"))
