@@ -371,6 +371,17 @@ __global__ void k_lin3(const float* x, float a, const float* y, const float* yth
                        float* out, uint32_t* amax) {
     const size_t base = (size_t)blockIdx.y * per;
     const float t = ythr ? ythr[blockIdx.y] : 0.0f;
+    // The image's largest magnitude (for the binary16 GEMM's scale) without a pass of its own: a wave leaves its maximum in LDS, the LAST wave of
+    // the block to arrive (an LDS counter, no barrier at the end) carries the block's to memory - and only if it beats what the maximum stood
+    // at when the block began (asked for at the start: a load at the END of every wave was a trip to L2 that nothing hid, +12-18 us per
+    // launch at 64 mini-batches).
+    __shared__ uint32_t bmax, bcnt;
+    uint32_t seen = 0;
+    if (amax) {
+        if (threadIdx.x == 0) bmax = 0, bcnt = 0;
+        seen = __hip_atomic_load(amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+    }
     uint32_t m = 0;
     for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < per; j += (size_t)gridDim.x * blockDim.x) {
         const size_t i = base + j;
@@ -379,9 +390,15 @@ __global__ void k_lin3(const float* x, float a, const float* y, const float* yth
         out[i] = o;
         m = max(m, __float_as_uint(o) & 0x7fffffffu);
     }
-    if (amax) {                                     // per wave, no block barrier: the atomic itself only when it can raise the maximum
+    if (amax) {
         for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d));
-        if ((threadIdx.x & 63) == 0 && m > __hip_atomic_load(amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(amax, m);
+        if ((threadIdx.x & 63) == 0) {
+            atomicMax(&bmax, m);
+            if (atomicAdd(&bcnt, 1u) == (blockDim.x >> 6) - 1) {       // (a wave's LDS operations complete in order: every maximum is in)
+                const uint32_t mb = atomicMax(&bmax, 0u);
+                if (mb > seen && mb > __hip_atomic_load(amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(amax, mb);
+            }
+        }
     }
 }
 // VJP of k_lin3: d{x,y,z} (+)= {a, b*[y >= thr], c} * go, go read once
@@ -741,7 +758,8 @@ Tensor Engine::lin3(Tensor x, float a, Tensor y, float b, Tensor z, float c, con
     const int G = ythr ? groups : 1;
     const size_t per = x->n / G;
     const dim3 grid(nblocks(per, 256, std::max<size_t>(256 * 32 / G, 1)), G);
-    uint32_t* am = out->n >= AMAX_MIN_N ? (uint32_t*)zeros(1) : nullptr;   // (images of small steps never reach the binary16 GEMM)
+    static const bool no_amax = getenv("MOTIFS_NO_LIN3_AMAX") != nullptr;     // A/B: k_absmax passes instead
+    uint32_t* am = out->n >= AMAX_MIN_N && !no_amax ? (uint32_t*)zeros(1) : nullptr;   // (images of small steps never reach the binary16 GEMM)
     if (failed) return out;
     if (am) absmax_of[out->v] = am;
     hipLaunchKernelGGL(k_lin3, grid, dim3(256), 0, st, x->v, a, y->v, ythr, b, z ? z->v : nullptr, c, per, out->v, am);
