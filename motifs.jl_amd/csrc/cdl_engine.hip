@@ -2632,15 +2632,39 @@ __global__ __launch_bounds__(256) void k_toep_wide(const float* __restrict__ A, 
 // inside one block, so the windows are scaled by the largest magnitude of the BLOCK's own span (found while it is staged in LDS; no pass over
 // the signal) and the bank by its own (cached with its fragments).  9 instructions of 32 cycles per 32 x 32 tile instead of 24 of 64.
 // Bf16[g][ct][t][plane][lane] = 8 halves: B[g][16 t + 8 kb + u][min(32 ct + n, N - 1)] * 2^seB, lane = (n, kb)
-__global__ void k_frag_bw16(const float* __restrict__ Bm, int G, int Q, int N, const uint32_t* __restrict__ bmax, uint4* __restrict__ out) {
-    const float sB = __uint_as_float((uint32_t)(f16x3_scale_exp(*bmax) + 127) << 23);
-    const int KT = Q / 16, NCT = (N + 31) / 32;
-    const size_t per = (size_t)NCT * KT * 128, total = per * G;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const size_t g = i / per, r = i - g * per;
-        const int lane = (int)(r & 63), plane = (int)((r >> 6) & 1);
-        const size_t ctt = r >> 7;
-        const int t = (int)(ctt % KT), ct = (int)(ctt / KT);
+// FRAG_SPLIT blocks per group: each finds the group's largest magnitude for itself (its scale; the bank is a few thousand floats in L2), leaves it
+// in bmax[g] for the consumers, and writes its share of the fragments - one launch where a zero fill, a maximum pass and the re-layout were three.
+constexpr int FRAG_SPLIT = 8;
+__global__ __launch_bounds__(256) void k_frag_bw16(const float* __restrict__ Bm, int Q, int N, uint32_t* __restrict__ bmax, uint4* __restrict__ out) {
+    __shared__ uint32_t wm[4];
+    const int g = blockIdx.x / FRAG_SPLIT, part = blockIdx.x - g * FRAG_SPLIT, tid = threadIdx.x, n = Q * N;
+    const float* B = Bm + (size_t)g * n;
+    uint32_t m = 0;
+    if ((n & 3) == 0 && (((uintptr_t)B) & 15) == 0) {              // eight 16-byte loads in flight (one load per turn was 75 trips to L2 in a row)
+        const float4* B4 = (const float4*)B;
+        for (int i0 = tid; i0 < n / 4; i0 += 256 * 8) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = B4[min(i0 + 256 * u, n / 4 - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                m = max(max(m, max(__float_as_uint(v[u].x) & 0x7fffffffu, __float_as_uint(v[u].y) & 0x7fffffffu)),
+                        max(__float_as_uint(v[u].z) & 0x7fffffffu, __float_as_uint(v[u].w) & 0x7fffffffu));
+        }
+    } else {
+        for (int i = tid; i < n; i += 256) m = max(m, __float_as_uint(B[i]) & 0x7fffffffu);
+    }
+    for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d));
+    if ((tid & 63) == 0) wm[tid >> 6] = m;
+    __syncthreads();
+    m = max(max(wm[0], wm[1]), max(wm[2], wm[3]));
+    if (tid == 0 && part == 0) bmax[g] = m;
+    const float sB = __uint_as_float((uint32_t)(f16x3_scale_exp(m) + 127) << 23);
+    const int KT = Q / 16, NCT = (N + 31) / 32, per = NCT * KT * 128;
+    for (int r = part * 256 + tid; r < per; r += 256 * FRAG_SPLIT) {
+        const int lane = r & 63, plane = (r >> 6) & 1;
+        const int ctt = r >> 7;
+        const int t = ctt % KT, ct = ctt / KT;
         const int col = min(32 * ct + (lane & 31), N - 1), kb = lane >> 5;
         uint32_t w[4];
 #pragma unroll
@@ -2649,14 +2673,14 @@ __global__ void k_frag_bw16(const float* __restrict__ Bm, int G, int Q, int N, c
 #pragma unroll
             for (int v = 0; v < 2; v++) {
                 const int q = 16 * t + 8 * kb + 2 * u + v;
-                const float x = Bm[g * (size_t)Q * N + (size_t)q * N + col] * sB;
+                const float x = B[(size_t)q * N + col] * sB;
                 const _Float16 hi = (_Float16)x;
                 const _Float16 lo = (_Float16)(x - (float)hi);
                 hh[v] = (uint32_t)__builtin_bit_cast(uint16_t, plane ? lo : hi);
             }
             w[u] = hh[0] | (hh[1] << 16);
         }
-        out[i] = make_uint4(w[0], w[1], w[2], w[3]);
+        out[(size_t)g * per + r] = make_uint4(w[0], w[1], w[2], w[3]);
     }
 }
 // ---- k_rowgemm_lds on the same instruction: C[r][n] = sum_q A[r][q] B[q][n], rows of Q floats read once ----
@@ -2763,10 +2787,10 @@ __global__ __launch_bounds__(512) void k_rowgemm16(const float* __restrict__ A, 
     } else {
         // ---- multipliers ----
         const int cw = wave - 4, ctid = tid - 256;
-        const int seB = f16x3_scale_exp(*bmax);
-        const float iB = __uint_as_float((uint32_t)(127 - seB) << 23);
+        float iB = 1.0f;
         uint4 bfr[KS][2 * NCT];
         auto bload = [&](int g) {
+            iB = __uint_as_float((uint32_t)(127 - f16x3_scale_exp(bmax[ldbf ? g : 0])) << 23);
             const uint4* bp = Bf + (size_t)g * ldbf + lane;
 #pragma unroll
             for (int k = 0; k < KS; k++) {
@@ -2887,14 +2911,10 @@ static bool launch_rowgemm16(Engine& e, const float* A, const float* Bm, float* 
     if (lds + 64 > 160 * 1024) return false;
     const size_t perf16 = (size_t)NCT * KT * 128;                     // uint4 per bank
     bool fresh16;
-    float* Bf16 = e.relayout(Bm, 8, rg.Q, rg.N, 0, perf16 * groups * 4 + 4, fresh16);
+    float* Bf16 = e.relayout(Bm, 8, rg.Q, rg.N, 0, perf16 * groups * 4 + ((groups + 3) & ~3), fresh16);
     if (!Bf16) return true;
-    uint32_t* bm = (uint32_t*)(Bf16 + perf16 * groups * 4);
-    if (fresh16) {
-        dev_zero(e.st, (float*)bm, 1);
-        hipLaunchKernelGGL(k_absmax, dim3(nblocks((size_t)groups * rg.Q * rg.N / 4 + 1, 256, 512)), dim3(256), 0, e.st, Bm, (size_t)groups * rg.Q * rg.N, (size_t)0, 1, bm);
-        hipLaunchKernelGGL(k_frag_bw16, dim3(nblocks(perf16 * groups)), dim3(256), 0, e.st, Bm, groups, rg.Q, rg.N, bm, (uint4*)Bf16);
-    }
+    uint32_t* bm = (uint32_t*)(Bf16 + perf16 * groups * 4);            // a scale per group behind the fragments
+    if (fresh16) hipLaunchKernelGGL(k_frag_bw16, dim3(groups * FRAG_SPLIT), dim3(256), 0, e.st, Bm, rg.Q, rg.N, bm, (uint4*)Bf16);
     const dim3 grid((unsigned)std::min<long>(ntiles, 256));           // one block per CU, there for the whole launch
     const int64_t ldbf = rg.ldb == 0 ? 0 : (int64_t)perf16;
     auto go = [&](auto kern) {
@@ -2938,7 +2958,7 @@ __global__ __launch_bounds__(256) void k_toep_wide16(const float* __restrict__ A
     for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d));
     if (lane == 0) wmax[wave] = m;
     __syncthreads();
-    const int seA = f16x3_scale_exp(max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]))), seB = f16x3_scale_exp(*bmax);
+    const int seA = f16x3_scale_exp(max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]))), seB = f16x3_scale_exp(bmax[ldbf ? s / gm.B : 0]);
     const float sA = __uint_as_float((uint32_t)(seA + 127) << 23);
     f16x8v ah[KT], al[KT];
     {
@@ -3025,14 +3045,10 @@ static bool launch_toep_wide(Engine& e, const float* A, const float* Bm, float* 
         const int KT = gm.Q / 16;
         const size_t perf16 = (size_t)NCT * KT * 128;                 // uint4 per bank
         bool fresh16;
-        float* Bf16 = e.relayout(Bm, 8, gm.Q, gm.N, 0, perf16 * gB * 4 + 4, fresh16);
+        float* Bf16 = e.relayout(Bm, 8, gm.Q, gm.N, 0, perf16 * gB * 4 + ((gB + 3) & ~3), fresh16);
         if (!Bf16) return true;
-        uint32_t* bm = (uint32_t*)(Bf16 + perf16 * gB * 4);
-        if (fresh16) {
-            dev_zero(e.st, (float*)bm, 1);
-            hipLaunchKernelGGL(k_absmax, dim3(nblocks((size_t)gB * gm.Q * gm.N / 4 + 1, 256, 512)), dim3(256), 0, e.st, Bm, (size_t)gB * gm.Q * gm.N, (size_t)0, 1, bm);
-            hipLaunchKernelGGL(k_frag_bw16, dim3(nblocks(perf16 * gB)), dim3(256), 0, e.st, Bm, gB, gm.Q, gm.N, bm, (uint4*)Bf16);
-        }
+        uint32_t* bm = (uint32_t*)(Bf16 + perf16 * gB * 4);            // a scale per group behind the fragments
+        if (fresh16) hipLaunchKernelGGL(k_frag_bw16, dim3(gB * FRAG_SPLIT), dim3(256), 0, e.st, Bm, gm.Q, gm.N, bm, (uint4*)Bf16);
         const int64_t ldbf16 = gm.ldb == 0 ? 0 : (int64_t)perf16;
 #define TOEPWIDE16(K) hipLaunchKernelGGL((k_toep_wide16<K>), grid, dim3(256), lds, e.st, A, (const uint4*)Bf16, C, gm, acc, tps, ldbf16, SO, bm)
         if (KT == 2) TOEPWIDE16(2);
