@@ -29,6 +29,8 @@ def stats(got, want):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--runs", type=int, default=3)
+    ap.add_argument("--name", default="r04_parity_errors", help="profiles/<name>.json (e.g. a second table with the MOTIFS_*_F16_MIN_* switches at 1: "
+                    "every golden through the binary16 GEMMs)")
     args = ap.parse_args()
     import torch
 
@@ -128,11 +130,11 @@ def main():
         cdl.model.close()
         merge("configs[3] shape (500 bp, 512 filters of 20), 1 mini-batch", rec)
     ctx.close()
-    res = {"runs": args.runs, "what": "largest error over the runs; gradients: |got - want|_inf / |want|_inf and the largest element-wise relative error over the "
+    res = {"runs": args.runs, "switches": {k: v for k, v in os.environ.items() if k.startswith("MOTIFS_")}, "what": "largest error over the runs; gradients: |got - want|_inf / |want|_inf and the largest element-wise relative error over the "
                                       "entries above 1e-3 of the largest; float64 oracle (oracle/model_oracle.py)", "cases": out}
     for d in ("profiles", "gpurun_out"):       # (gpurun_out/ is what travels back from the GPU box)
         if os.path.isdir(os.path.join(ROOT, d)):
-            with open(os.path.join(ROOT, d, "r04_parity_errors.json"), "w") as fh:
+            with open(os.path.join(ROOT, d, args.name + ".json"), "w") as fh:
                 json.dump(res, fh, indent=1, default=float)
     print("| case | loss rel | worst gradient, inf / max | worst gradient, element-wise (entries > 1e-3 max) | other |")
     print("|---|---|---|---|---|")
