@@ -336,6 +336,48 @@ def test_f16x3_syntax_gemm_meets_the_oracle(ctx, pkg, tmp_path):
         assert_grad(got[n], g[f"grad0_{n}"].astype(np.float64), n)
 
 
+def test_binary16_gemms_on_other_shapes(ctx, pkg, tmp_path):
+    """The same switches on the three mid-shape fixtures and the configs[0]-shape one (other template instances of the binary16 GEMMs: one and
+    two column tiles, 40- / 36- / 48-wide filter gradients, banks of 64-128 channels, two mini-batches per launch), against the float64
+    oracle's losses and gradients at the usual tolerances."""
+    import subprocess
+    import sys
+    path = str(tmp_path / "f16forms.npz")
+    e = dict(os.environ)
+    for k in ("MOTIFS_ANA_F32", "MOTIFS_TOEP_F32", "MOTIFS_ROWGEMM_F32", "MOTIFS_ROWWGRAD_F32"):
+        e.pop(k, None)
+    for k in ("MOTIFS_ANA_F16_MIN_JOBS", "MOTIFS_TOEP_F16_MIN_JOBS", "MOTIFS_ROWGEMM_F16_MIN_TILES", "MOTIFS_ROWWGRAD_F16_MIN_TILES"):
+        e[k] = "1"
+    subprocess.run([sys.executable, os.path.join(HERE, "_f16_forms_helper.py"), path], check=True, env=e, timeout=300)
+    out = np.load(path)
+
+    def split(flat, hp):
+        nD, nF = hp.M * 4 * hp.filter_len, hp.K * 2 * hp.M * hp.h
+        got = {"D": flat[:nD], "F": flat[nD:nD + nF]}
+        o = nD + nF
+        for name, n in zip(pkg_vec_fields(), pkg_vec_sizes(hp)):
+            got[name] = flat[o:o + n]
+            o += n
+        return got
+
+    gm = np.load(os.path.join(HERE, "golden", "model_mid.npz"))
+    for i in range(3):
+        fl, M, h, K, q, bp = [int(x) for x in gm["shapes"][i]]
+        hp = mo.Hyperparam(filter_len=fl, M=M, h=h, K=K, q=q, batch_size=3, num_pass_xyz=2, num_pass_df=2)
+        for k in range(2):
+            assert abs(out[f"mid{i}_loss"][k] - gm[f"s{i}_loss{k}"]) <= LOSS_RTOL * gm[f"s{i}_loss{k}"]
+        got = split(out[f"mid{i}_flat"], hp)
+        for n in NAMES:
+            assert_grad(got[n], gm[f"s{i}_grad_{n}"].astype(np.float64), n)
+    g1 = np.load(os.path.join(HERE, "golden", "model_cfg1.npz"))
+    hp = mo.Hyperparam(filter_len=8, M=32)
+    for k in range(2):
+        assert abs(out["cfg0_loss"][k] - g1[f"loss{k}"]) <= LOSS_RTOL * g1[f"loss{k}"]
+    got = split(out["cfg0_flat"], hp)
+    for n in NAMES:
+        assert_grad(got[n], g1[f"grad0_{n}"] + g1[f"grad1_{n}"], n)
+
+
 @pytest.mark.parametrize("G", [16, 40, 64])
 def test_step_sizes_take_different_kernels_and_agree(ctx, pkg, G):
     """The engine picks its kernel forms by step size (per-read sparse gradients to 24 mini-batches, 2-row synthesis blocks and
