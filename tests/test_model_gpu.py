@@ -378,7 +378,7 @@ def test_binary16_gemms_on_other_shapes(ctx, pkg, tmp_path):
         assert_grad(got[n], g1[f"grad0_{n}"] + g1[f"grad1_{n}"], n)
 
 
-@pytest.mark.parametrize("G", [16, 40, 64])
+@pytest.mark.parametrize("G", [16, 32, 40, 64])
 def test_step_sizes_take_different_kernels_and_agree(ctx, pkg, G):
     """The engine picks its kernel forms by step size (per-read sparse gradients to 24 mini-batches, 2-row synthesis blocks and
     split row walks below 192 reads, the fused tall form to ~100 reads, fused bank forms for small banks, ...).  The one-mini-batch
