@@ -2714,7 +2714,8 @@ __global__ __launch_bounds__(512) void k_rowgemm16(const float* __restrict__ A, 
     const int plane = 32 * RS, bufsz = 2 * plane;
     const int RW = ((N + 15) & ~15) + 8;
     float* red0 = (float*)(ldsr + 2 * bufsz);
-    const int nmine = blockIdx.x < ntiles ? (ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;     // tiles of this block: blockIdx.x + j gridDim.x
+    // tiles of this block: a run of consecutive ones, t0 + j (with a bank per group a strided deal changed the bank - 100 KB of fragments - at every tile)
+    const int tpb = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x, t0 = blockIdx.x * tpb, nmine = max(0, min(ntiles, t0 + tpb) - t0);
     // RING: tiles a mover has in flight (register sets)
     const int nturns = (nmine + RING) / RING * RING;   // nmine + 1 turns, rounded up to the movers' ring
     if (wave < 4) {
@@ -2725,7 +2726,7 @@ __global__ __launch_bounds__(512) void k_rowgemm16(const float* __restrict__ A, 
         // 16 bytes - and a turn past the block's last tile re-reads the first 16 bytes of A (no branch, no select: the same NV loads on every
         // path, so the wait for one tile's registers leaves the tiles behind it in flight)
         auto rows_of = [&](int j, const float4*& At, int& last) {
-            const int tile = blockIdx.x + (j < nmine ? j : 0) * gridDim.x, g = tile / tpg, r0 = (tile - g * tpg) * 32 + 8 * wave;
+            const int tile = t0 + (j < nmine ? j : 0), g = tile / tpg, r0 = (tile - g * tpg) * 32 + 8 * wave;
             const int nf4 = j < nmine ? max(0, min(8, rpg - r0)) * Q4 : 0;
             last = max(nf4, 1) - 1;
             At = (const float4*)(A + (nf4 > 0 ? ((size_t)g * rpg + r0) * Q : (size_t)0));
@@ -2800,7 +2801,7 @@ __global__ __launch_bounds__(512) void k_rowgemm16(const float* __restrict__ A, 
                     bfr[k][2 * ct] = bp[(size_t)((ct * KT + t) * 2) * 64], bfr[k][2 * ct + 1] = bp[(size_t)((ct * KT + t) * 2 + 1) * 64];
             }
         };
-        int cur_g = (int)blockIdx.x / tpg;         // the first tile's bank: on its way while the movers fetch that tile
+        int cur_g = t0 / tpg;                      // the first tile's bank: on its way while the movers fetch that tile
         bload(cur_g);
         int qofs[2];                               // where this thread's 16-byte pieces of a finished tile start in the partial tiles
 #pragma unroll
@@ -2813,7 +2814,7 @@ __global__ __launch_bounds__(512) void k_rowgemm16(const float* __restrict__ A, 
             const int jt = j - 1;
             const bool work = jt >= 0 && jt < nmine;
             RG16_TS(1, j, 0);
-            const int tile = blockIdx.x + (work ? jt : 0) * gridDim.x, g = tile / tpg, r0 = (tile - g * tpg) * 32;
+            const int tile = t0 + (work ? jt : 0), g = tile / tpg, r0 = (tile - g * tpg) * 32;
             if (work) {
                 if (g != cur_g) {                  // (never when the bank is shared)
                     bload(g);
@@ -2915,7 +2916,8 @@ static bool launch_rowgemm16(Engine& e, const float* A, const float* Bm, float* 
     if (!Bf16) return true;
     uint32_t* bm = (uint32_t*)(Bf16 + perf16 * groups * 4);            // a scale per group behind the fragments
     if (fresh16) hipLaunchKernelGGL(k_frag_bw16, dim3(groups * FRAG_SPLIT), dim3(256), 0, e.st, Bm, rg.Q, rg.N, bm, (uint4*)Bf16);
-    const dim3 grid((unsigned)std::min<long>(ntiles, 256));           // one block per CU, there for the whole launch
+    const long tpb = (ntiles + 255) / 256;
+    const dim3 grid((unsigned)((ntiles + tpb - 1) / tpb));            // one block per CU, there for the whole launch, each with a run of tpb tiles
     const int64_t ldbf = rg.ldb == 0 ? 0 : (int64_t)perf16;
     auto go = [&](auto kern) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
