@@ -1350,6 +1350,8 @@ __global__ __launch_bounds__(VF_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8
     }
 }
 
+// the four-reads kernel's one-hot images (16 per block) against the LDS its blocks per CU leave each other
+static size_t cand_q_lds_cap(int wpe) { return (size_t)(160 * 1024 / wpe) - 1024; }
 template <int T, int PG>
 static hipError_t launch_cand_tp(const CandArgs& a, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
     const int ntg = (a.d.used_tiles + PG - 1) / PG;           // tile groups that hold PWMs
@@ -1357,13 +1359,21 @@ static hipError_t launch_cand_tp(const CandArgs& a, hipStream_t st, hipEvent_t e
     const size_t lds_q = (size_t)4 * 4 * quad_pitch(a.d.ohlen) * 8;
     // four reads per wave while the LDS images leave the CU as many blocks as the registers do (4, 3 or 2 per CU)
     constexpr int wpe = (T * PG <= 12) ? 4 : (T * PG <= 16 && PG > 1) ? 3 : 2;
-    if (a.uniform_eps && lds_q <= std::min<size_t>(64 * 1024, 160 * 1024 / wpe)) {
+    if (a.uniform_eps && lds_q <= cand_q_lds_cap(wpe)) {
         CandDims d = a.d;
         const bool compact = PG == 4 && a.centries != nullptr;
         // quads per wave: many small blocks balance the CUs best (N = 100k: 1 or 2 per wave 0.337 ms, 3: 0.354, 8: 0.390)
         d.spw = (int)std::max<int64_t>(1, std::min<int64_t>(8, a.d.N / (16 * 8192)));
         const int64_t per_block = (int64_t)(4 / tgb) * 4 * d.spw;
         dim3 grid((unsigned)((d.N + per_block - 1) / per_block), (unsigned)((ntg + tgb - 1) / tgb), 1);
+        if (lds_q > 64 * 1024) {                   // (reads of ~500 positions at two blocks per CU: 65 KB of one-hot images per block)
+            if constexpr (PG == 4) {
+                (void)hipFuncSetAttribute((const void*)scan_cand_kernel_q<T, PG, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
+                (void)hipFuncSetAttribute((const void*)scan_cand_kernel_q<T, PG, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
+            }
+            (void)hipFuncSetAttribute((const void*)scan_cand_kernel_q<T, PG, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
+            (void)hipFuncSetAttribute((const void*)scan_cand_kernel_q<T, PG, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
+        }
         if (compact) {
             if constexpr (PG == 4) {
                 if (tgb == 1) hipExtLaunchKernelGGL((scan_cand_kernel_q<T, PG, 1, true>), grid, dim3(256), (uint32_t)lds_q, st, ev0, ev1, 0, a.afrag, a.codes, a.cells, a.centries, d, a.afrag2, a.cells2, a.centries2);
@@ -1401,7 +1411,7 @@ bool cand_two_strands_ok(const CandArgs& a) {
     const int T = a.lenp / 4;
     const int wpe = (T * 4 <= 12) ? 4 : (T * 4 <= 16) ? 3 : 2;
     const size_t lds_q = (size_t)4 * 4 * quad_pitch(a.d.ohlen) * 8;
-    return lds_q <= std::min<size_t>(64 * 1024, 160 * 1024 / wpe);
+    return lds_q <= cand_q_lds_cap(wpe);
 }
 
 // ev0 / ev1 (optional): events that take the kernel's own start and stop time stamps (hipExtLaunchKernelGGL): timing the
