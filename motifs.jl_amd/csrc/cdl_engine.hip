@@ -364,7 +364,7 @@ __global__ void k_resid_sumsq_bwd(const float* gout, const float* x, const float
 // a*x + b*y + c*z in one pass (z optional), one grid row per group of `per` elements.
 // ythr (optional): cat_ZY's median mask folded in as a threshold per group, y counts where y >= ythr[group]
 // (a constant in the backward, @ignore model.jl:208) - no 0/1 mask is ever written or read.
-constexpr size_t AMAX_MIN_N = (size_t)8 << 20;    // floats: images this large may feed k_ana_f16x3 (1024+ row tiles)
+constexpr size_t AMAX_MIN_N = (size_t)8 << 20;    // floats: below this (~18 mini-batches) a pass of k_absmax per image is cheaper than keeping the maximum here
 // amax (optional, pre-zeroed): the bits of the largest |out| - the image this forms is the syntax-layer GEMM's operand, whose binary16
 // form (k_ana_f16x3) is scaled by it; one atomic per block, and only when it can raise the maximum
 __global__ void k_lin3(const float* x, float a, const float* y, const float* ythr, float b, const float* z, float c, size_t per,
@@ -2005,7 +2005,7 @@ static bool launch_ana_f16x3(Engine& e, const float* A, const float* Bm, float* 
     if ((gm.sa & 15) || (gm.a0 & 3) || (gm.lda & 3) || (((uintptr_t)A) & 15)) return false;
     // steps of few reads keep the float32 form (its split over channel chunks); MOTIFS_ANA_F16_MIN_JOBS lowers the bar (tests: the
     // one-mini-batch goldens through this kernel)
-    static const long min_jobs = getenv("MOTIFS_ANA_F16_MIN_JOBS") ? atol(getenv("MOTIFS_ANA_F16_MIN_JOBS")) : 1024;
+    static const long min_jobs = getenv("MOTIFS_ANA_F16_MIN_JOBS") ? atol(getenv("MOTIFS_ANA_F16_MIN_JOBS")) : 256;      // measured: pays from 8 mini-batches (288 row tiles), costs 4-7 % at 1-4
     if ((long)gm.S * ((gm.P + 31) / 32) < min_jobs) return false;
     const int gB = gm.ldb == 0 ? 1 : gm.S / gm.B;
     const size_t perf = (size_t)(gm.Q / 16) * 128;                        // uint4 per bank
@@ -2904,7 +2904,7 @@ extern "C" int motifs_debug_rg16_ts(void* out) { return (int)hipMemcpyFromSymbol
 #endif
 static bool launch_rowgemm16(Engine& e, const float* A, const float* Bm, float* C, const ToepGeom& rg, int acc, int groups, long rpg, int tpg) {
     static const bool f32_only = getenv("MOTIFS_ROWGEMM_F32") != nullptr || getenv("MOTIFS_ANA_F32") != nullptr;     // A/B: the float32 matrix instruction
-    static const long min_tiles = getenv("MOTIFS_ROWGEMM_F16_MIN_TILES") ? atol(getenv("MOTIFS_ROWGEMM_F16_MIN_TILES")) : 1024;
+    static const long min_tiles = getenv("MOTIFS_ROWGEMM_F16_MIN_TILES") ? atol(getenv("MOTIFS_ROWGEMM_F16_MIN_TILES")) : 768;       // measured: -1 % at 576 tiles, +1 % at 864
     const long ntiles = (long)groups * tpg;
     if (f32_only || ntiles < min_tiles || ntiles > (1l << 30) || rpg > (1l << 30)) return false;
     const int KT = rg.Q / 16, NCT = (rg.N + 31) / 32;
@@ -3036,7 +3036,7 @@ static bool launch_toep_wide(Engine& e, const float* A, const float* Bm, float* 
     if (fresh) hipLaunchKernelGGL(k_frag_bw, dim3(nblocks(perf * gB)), dim3(256), 0, e.st, Bm, gB, gm.Q, gm.N, Bf);
     const int tps = (gm.P + 31) / 32;
     static const bool f32_only = getenv("MOTIFS_TOEP_F32") != nullptr || getenv("MOTIFS_ANA_F32") != nullptr;   // A/B: the float32 matrix instruction
-    static const long min_jobs16 = getenv("MOTIFS_TOEP_F16_MIN_JOBS") ? atol(getenv("MOTIFS_TOEP_F16_MIN_JOBS")) : 1024;   // (tests: 1)
+    static const long min_jobs16 = getenv("MOTIFS_TOEP_F16_MIN_JOBS") ? atol(getenv("MOTIFS_TOEP_F16_MIN_JOBS")) : 768;   // (tests: 1; measured: -2 % at 576 jobs, +2 % at 864)
     const bool want16 = !f32_only && (long)gm.S * tps >= min_jobs16 && gm.Q % 16 == 0 && gm.sa > 0;
     const int cs = !want16 && (long)gm.S * tps < 256 ? std::min(4, NCT) : 1;      // few reads: four blocks per row tile, a wave per column tile
     const dim3 grid((unsigned)((long)gm.S * tps * cs));
@@ -3577,7 +3577,7 @@ static bool launch_rowwgrad_lds(Engine& e, const float* A, const float* C, float
     if (nparts) *nparts = rg.B * rowwgrad_split(rg);
     {
         static const bool f32_only = getenv("MOTIFS_ROWWGRAD_F32") != nullptr || getenv("MOTIFS_ANA_F32") != nullptr;   // A/B: the float32 matrix instruction
-        static const long min_tiles = getenv("MOTIFS_ROWWGRAD_F16_MIN_TILES") ? atol(getenv("MOTIFS_ROWWGRAD_F16_MIN_TILES")) : 1024;
+        static const long min_tiles = getenv("MOTIFS_ROWWGRAD_F16_MIN_TILES") ? atol(getenv("MOTIFS_ROWWGRAD_F16_MIN_TILES")) : 512;       // measured: level at 288 tiles, +1 % at 576, +2 % at 864
         const int tps = (rg.P + 31) / 32, G = rg.S / rg.B, T = rg.B * tps;
         const size_t lds16 = (size_t)2 * 2 * 32 * (rg.Q + 8) * 2 + (size_t)2 * 2 * 32 * 56 * 2;
         if (!f32_only && nparts && (long)G * T >= min_tiles && lds16 + 64 <= 160 * 1024) {
