@@ -485,23 +485,51 @@ __global__ void k_zy_step(const float* ZY, const float* g1, const float* FX, con
 }
 // its VJP: one pass over the image for the four tensor gradients and the three scalar gradients
 // (dsc[0..2] = d pen, d lst, d ls; block sums in double, one float atomic each per block)
+template <int V>   // V = 4: 16-byte accesses (n % 4 == 0, 16-byte aligned tensors); V = 1: scalar
 __global__ void k_zy_step_bwd(const float* go, const float* out, const float* ZY, const float* g1, const float* FX, const float* ab,
                               const float* pen, const float* lst, const float* ls, size_t n, float* dZY, int aZY, float* dg1, int ag1,
                               float* dFX, int aFX, float* dab, int aab, float* dpen, float* dlst, float* dls) {
+    struct VF {
+        float e[V];
+    };
     const float p = *pen, s = *lst, l = *ls;
     double sp = 0, ss = 0, sl = 0;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const float du = out[i] > 0.0f ? go[i] : 0.0f;
-        const float inner = ZY[i] - (FX[i] + (ab ? ab[i] : 0.0f));
-        const float grad = g1[i] + inner * p;
-        if (dZY) dZY[i] = (aZY ? dZY[i] : 0.0f) + du * (1.0f - s * p);
-        if (dg1) dg1[i] = (ag1 ? dg1[i] : 0.0f) - s * du;
-        const float dfx = s * p * du;
-        if (dFX) dFX[i] = (aFX ? dFX[i] : 0.0f) + dfx;
-        if (dab) dab[i] = (aab ? dab[i] : 0.0f) + dfx;
-        sp -= (double)du * (double)(s * inner);
-        ss -= (double)du * (double)(grad + l);
-        sl -= (double)du * (double)s;
+    auto ld = [&](const float* q, size_t i) {
+        VF r;
+        if (V == 4) {
+            const float4 x = *(const float4*)(q + i);
+            r.e[0] = x.x, r.e[1 % V] = x.y, r.e[2 % V] = x.z, r.e[3 % V] = x.w;
+        } else {
+            r.e[0] = q[i];
+        }
+        return r;
+    };
+    auto stv = [&](float* q, size_t i, const VF& r) {
+        if (V == 4) *(float4*)(q + i) = make_float4(r.e[0], r.e[1 % V], r.e[2 % V], r.e[3 % V]);
+        else q[i] = r.e[0];
+    };
+    for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * V; i < n; i += (size_t)gridDim.x * blockDim.x * V) {
+        VF z{};
+        const VF vo = ld(out, i), vgo = ld(go, i), vzy = ld(ZY, i), vfx = ld(FX, i), vab = ab ? ld(ab, i) : z, vg1 = ld(g1, i);
+        VF oZY = (dZY && aZY) ? ld(dZY, i) : z, og1 = (dg1 && ag1) ? ld(dg1, i) : z, oFX = (dFX && aFX) ? ld(dFX, i) : z, oab = (dab && aab) ? ld(dab, i) : z;
+#pragma unroll
+        for (int u = 0; u < V; u++) {
+            const float du = vo.e[u] > 0.0f ? vgo.e[u] : 0.0f;
+            const float inner = vzy.e[u] - (vfx.e[u] + vab.e[u]);
+            const float grad = vg1.e[u] + inner * p;
+            oZY.e[u] = oZY.e[u] + du * (1.0f - s * p);
+            og1.e[u] = og1.e[u] - s * du;
+            const float dfx = s * p * du;
+            oFX.e[u] = oFX.e[u] + dfx;
+            oab.e[u] = oab.e[u] + dfx;
+            sp -= (double)du * (double)(s * inner);
+            ss -= (double)du * (double)(grad + l);
+            sl -= (double)du * (double)s;
+        }
+        if (dZY) stv(dZY, i, oZY);
+        if (dg1) stv(dg1, i, og1);
+        if (dFX) stv(dFX, i, oFX);
+        if (dab) stv(dab, i, oab);
     }
     for (int d = 32; d >= 1; d >>= 1) {
         sp += __shfl_xor(sp, d);
@@ -826,8 +854,16 @@ Tensor Engine::zy_step(Tensor ZY, Tensor g1, Tensor FX, Tensor ab, Tensor pen, T
             float* ds = lst->needs_grad ? grad(lst) : nullptr;
             float* dl = ls->needs_grad ? grad(ls) : nullptr;
             if (failed) return;
-            hipLaunchKernelGGL(k_zy_step_bwd, dim3(nblocks(out->n, 256 * 8, 2048)), dim3(256), 0, st, out->g, out->v, ZY->v, g1->v, FX->v,
-                               ab ? ab->v : nullptr, pen->v, lst->v, ls->v, out->n, d0, a0, d1, a1, d2, a2, d3, a3, dp, ds, dl);
+            auto al16 = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
+            const bool v4 = (out->n & 3) == 0 && al16(out->g) && al16(out->v) && al16(ZY->v) && al16(g1->v) && al16(FX->v) && al16(ab ? ab->v : nullptr) &&
+                            al16(d0) && al16(d1) && al16(d2) && al16(d3);
+            // (at most 1024 blocks: each ends with three atomics on three addresses)
+            if (v4)
+                hipLaunchKernelGGL(k_zy_step_bwd<4>, dim3(nblocks(out->n / 4, 256 * 4, 1024)), dim3(256), 0, st, out->g, out->v, ZY->v, g1->v, FX->v,
+                                   ab ? ab->v : nullptr, pen->v, lst->v, ls->v, out->n, d0, a0, d1, a1, d2, a2, d3, a3, dp, ds, dl);
+            else
+                hipLaunchKernelGGL(k_zy_step_bwd<1>, dim3(nblocks(out->n, 256 * 8, 2048)), dim3(256), 0, st, out->g, out->v, ZY->v, g1->v, FX->v,
+                                   ab ? ab->v : nullptr, pen->v, lst->v, ls->v, out->n, d0, a0, d1, a1, d2, a2, d3, a3, dp, ds, dl);
         });
     return out;
 }
