@@ -4763,7 +4763,7 @@ NzView Engine::nz_build(const float* data, int S, int n_per) {
         failed = true;
         return v;
     }
-    hipLaunchKernelGGL(k_build_nz, dim3(S), dim3(S >= 256 ? 256 : 1024), 0, st, data, n_per, cnt, ent);
+    hipLaunchKernelGGL(k_build_nz, dim3(S), dim3(S >= 1024 ? 256 : 1024), 0, st, data, n_per, cnt, ent);
     v.cnt = cnt;
     v.ent = ent;
     return v;
@@ -5112,7 +5112,8 @@ __global__ __launch_bounds__(1024) void k_topq_mask(const float* X, float* bitma
     for (int i = threadIdx.x; i < n; i += blockDim.x) bitmat[(size_t)blockIdx.x * n + i] = xs[i] >= thr ? 1.0f : 0.0f;
 }
 void topq_mask(hipStream_t st, const float* X, float* bitmat, int S, int n_per_seq, int q) {
-    hipLaunchKernelGGL(k_topq_mask, dim3(S), dim3(S >= 256 ? 256 : 1024), 0, st, X, bitmat, n_per_seq, q);   // few reads: more waves per read
+    // (16 waves per read up to 1024 reads: a block's phases are latency-bound, and 384 blocks of 4 waves left the chip idle - 28.8 -> 16.5 us for k_x_project)
+    hipLaunchKernelGGL(k_topq_mask, dim3(S), dim3(S >= 1024 ? 256 : 1024), 0, st, X, bitmat, n_per_seq, q);
 }
 
 // update_X's tail in one launch (model.jl:253 then project_X, :181-192): the gradient step Xu = X - ost * xg (xg == null: Xu = X,
@@ -5216,7 +5217,7 @@ Tensor Engine::x_project(Tensor X, Tensor xg, Tensor ost, int S, int q, float sc
     }
     int* mc = c + S + 64;
     uint2* men = en + (size_t)S * n;
-    hipLaunchKernelGGL(k_x_project, dim3(S), dim3(S >= 256 ? 256 : 1024), (size_t)n * 4, st, X->v, xg ? xg->v : nullptr, xg ? ost->v : nullptr, n, q,
+    hipLaunchKernelGGL(k_x_project, dim3(S), dim3(S >= 1024 ? 256 : 1024), (size_t)n * 4, st, X->v, xg ? xg->v : nullptr, xg ? ost->v : nullptr, n, q,
                        out->v, bitm->v, c, en, mc, men, scale);
     out->gmask = bitm->v;          // every gradient into the projected codes passes this mask on its way back
     out->nz_cnt = c, out->nz_ent = en;
