@@ -5177,15 +5177,41 @@ __global__ __launch_bounds__(1024) void k_x_project(const float* __restrict__ X,
     }
 }
 // VJP: g = bitmat .* d out;  dX (+)= g;  d xg (+)= -ost * g;  d ost += -sum(g .* xg)
+template <int V>   // V = 4: 16-byte accesses (n % 4 == 0, 16-byte aligned tensors); V = 1: scalar
 __global__ void k_x_project_bwd(const float* go, const float* bit, const float* xg, const float* ost, size_t n, float* dX, int aX, float* dxg,
                                 int axg, float* dost, float scale) {
+    struct VF {
+        float e[V];
+    };
+    auto ld = [&](const float* q, size_t i) {
+        VF r;
+        if (V == 4) {
+            const float4 x = *(const float4*)(q + i);
+            r.e[0] = x.x, r.e[1 % V] = x.y, r.e[2 % V] = x.z, r.e[3 % V] = x.w;
+        } else {
+            r.e[0] = q[i];
+        }
+        return r;
+    };
+    auto stv = [&](float* q, size_t i, const VF& r) {
+        if (V == 4) *(float4*)(q + i) = make_float4(r.e[0], r.e[1 % V], r.e[2 % V], r.e[3 % V]);
+        else q[i] = r.e[0];
+    };
     const float o = ost ? *ost : 0.0f;
     double so = 0;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const float g = bit[i] * go[i];
-        if (dX) dX[i] = (aX ? dX[i] : 0.0f) + (scale == 1.0f ? g : scale * g);
-        if (dxg) dxg[i] = (axg ? dxg[i] : 0.0f) - o * g;
-        if (xg) so -= (double)g * (double)xg[i];
+    for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * V; i < n; i += (size_t)gridDim.x * blockDim.x * V) {
+        VF z{};
+        const VF vb = ld(bit, i), vg = ld(go, i), vx = xg ? ld(xg, i) : z;
+        VF oX = (dX && aX) ? ld(dX, i) : z, oxg = (dxg && axg) ? ld(dxg, i) : z;
+#pragma unroll
+        for (int u = 0; u < V; u++) {
+            const float g = vb.e[u] * vg.e[u];
+            oX.e[u] = oX.e[u] + (scale == 1.0f ? g : scale * g);
+            oxg.e[u] = oxg.e[u] - o * g;
+            if (xg) so -= (double)g * (double)vx.e[u];
+        }
+        if (dX) stv(dX, i, oX);
+        if (dxg) stv(dxg, i, oxg);
     }
     if (!dost) return;
     for (int d = 32; d >= 1; d >>= 1) so += __shfl_xor(so, d);
@@ -5230,8 +5256,13 @@ Tensor Engine::x_project(Tensor X, Tensor xg, Tensor ost, int S, int q, float sc
             float* d1 = xg && xg->needs_grad ? grad_first(xg, a1) : nullptr;
             float* dq = xg && ost->needs_grad ? grad(ost) : nullptr;
             if (failed) return;
-            hipLaunchKernelGGL(k_x_project_bwd, dim3(nblocks(out->n, 256, 1024)), dim3(256), 0, st, out->g, bitm->v, xg ? xg->v : nullptr,
-                               xg ? ost->v : nullptr, out->n, d0, a0, d1, a1, dq, scale);
+            auto al16 = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
+            if ((out->n & 3) == 0 && al16(out->g) && al16(bitm->v) && al16(xg ? xg->v : nullptr) && al16(d0) && al16(d1))
+                hipLaunchKernelGGL(k_x_project_bwd<4>, dim3(nblocks(out->n / 4, 256, 512)), dim3(256), 0, st, out->g, bitm->v, xg ? xg->v : nullptr,
+                                   xg ? ost->v : nullptr, out->n, d0, a0, d1, a1, dq, scale);
+            else
+                hipLaunchKernelGGL(k_x_project_bwd<1>, dim3(nblocks(out->n, 256, 1024)), dim3(256), 0, st, out->g, bitm->v, xg ? xg->v : nullptr,
+                                   xg ? ost->v : nullptr, out->n, d0, a0, d1, a1, dq, scale);
         });
     return out;
 }
