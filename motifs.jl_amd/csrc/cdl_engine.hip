@@ -418,6 +418,17 @@ __global__ void k_lin3_bwd(const float* go, size_t per, float a, float* dx, int 
 __global__ void k_thrmul(const float* src, const float* sel, const float* thr, float c, size_t per, float* out, int acc) {
     const size_t base = (size_t)blockIdx.y * per;
     const float t = thr[blockIdx.y];
+    if ((per & 3) == 0 && ((((uintptr_t)src) | ((uintptr_t)sel) | ((uintptr_t)out)) & 15) == 0) {       // 16-byte accesses
+        for (size_t j = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; j < per; j += (size_t)gridDim.x * blockDim.x * 4) {
+            const size_t i = base + j;
+            const float4 s4 = *(const float4*)(sel + i), x4 = *(const float4*)(src + i);
+            float4 o = acc ? *(const float4*)(out + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float v0 = s4.x >= t ? c * x4.x : 0.0f, v1 = s4.y >= t ? c * x4.y : 0.0f, v2 = s4.z >= t ? c * x4.z : 0.0f, v3 = s4.w >= t ? c * x4.w : 0.0f;
+            o.x = acc ? o.x + v0 : v0, o.y = acc ? o.y + v1 : v1, o.z = acc ? o.z + v2 : v2, o.w = acc ? o.w + v3 : v3;
+            *(float4*)(out + i) = o;
+        }
+        return;
+    }
     for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < per; j += (size_t)gridDim.x * blockDim.x) {
         const size_t i = base + j;
         const float v = sel[i] >= t ? c * src[i] : 0.0f;
