@@ -4718,10 +4718,130 @@ static bool sp_wgrad_by_reads(Engine& e, const SpDims& d, int G, size_t lds) {
     }
     return true;
 }
+// S2 / S3 for steps of many mini-batches with FOUR adjacent columns per lane: the one-column forms above spend ~20 instructions per entry and lane
+// on one multiply-add (the walk is bound by instruction issue: 50 us at 64 mini-batches with 24 waves per CU); here a lane takes 16 bytes of the
+// image row per entry and its LDS accumulators are float4 [K][64] (one 16-byte read-modify-write per entry), eight image values in flight.  A
+// wave covers 256 columns; blocks are one wave.  The sums of a column run over the entries in list order, as before.
+__global__ __launch_bounds__(64) void k_sp_wgrad_syn4(NzView nz, const float* __restrict__ dOut, float* __restrict__ dF, SpDims d) {
+    extern __shared__ float4 acc4[];                     // [K][64]
+    const int g = blockIdx.z, ip = blockIdx.y, lane = threadIdx.x, W4 = d.W >> 2, j4 = blockIdx.x * 64 + lane;
+    const int jc = min(j4, W4 - 1);                      // clamp: out-of-range lanes compute, do not store
+    for (int k = 0; k < d.K; k++) acc4[k * 64 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int b = 0; b < d.B; b++) {
+        const int s = g * d.B + b;
+        const float4* ds = (const float4*)(dOut + (size_t)s * d.c * d.W + (size_t)(d.h - 1 - ip) * d.W) + jc;
+        const int cnt = nz.cnt[s];
+        const uint2* es = nz.ent + (size_t)s * nz.cap;
+        uint2 nx[8];                                     // the NEXT eight entries are asked for while this round's image values are on their way
+#pragma unroll
+        for (int u = 0; u < 8; u++) nx[u] = es[min(u, max(cnt - 1, 0))];
+        for (int z = 0; z < cnt; z += 8) {               // wave-uniform
+            uint2 en[8];
+            float4 val[8];
+            int kk[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) en[u] = nx[u];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int p = (int)__umulhi(en[u].x, kmagic(d.K));
+                kk[u] = (int)(en[u].x - (unsigned)p * d.K);
+                val[u] = ds[(size_t)p * W4];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) nx[u] = es[min(z + 8 + u, cnt - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (z + u < cnt) {
+                    const float v = __uint_as_float(en[u].y);
+                    float4 a = acc4[kk[u] * 64 + lane];
+                    a.x = fmaf(v, val[u].x, a.x), a.y = fmaf(v, val[u].y, a.y), a.z = fmaf(v, val[u].z, a.z), a.w = fmaf(v, val[u].w, a.w);
+                    acc4[kk[u] * 64 + lane] = a;
+                }
+        }
+    }
+    if (j4 < W4) {
+        float4* dFg = (float4*)(dF + (size_t)g * d.h * d.K * d.W + (size_t)ip * d.K * d.W) + j4;
+        for (int k0 = 0; k0 < d.K; k0 += 8) {            // eight rows of the bank in flight (one at a time: K trips to memory in a row)
+            float4 t[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) t[u] = dFg[(size_t)min(k0 + u, d.K - 1) * W4];
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (k0 + u < d.K) {
+                    const float4 a = acc4[(k0 + u) * 64 + lane];
+                    t[u].x += a.x, t[u].y += a.y, t[u].z += a.z, t[u].w += a.w;
+                    dFg[(size_t)(k0 + u) * W4] = t[u];
+                }
+        }
+    }
+}
+__global__ __launch_bounds__(64) void k_sp_wgrad_ana4(const float* __restrict__ img, NzView nz, float* __restrict__ dB, SpDims d, int acc) {
+    extern __shared__ float4 acc4[];                     // [K][64]
+    const int g = blockIdx.z, i = blockIdx.y, lane = threadIdx.x, W4 = d.W >> 2, j4 = blockIdx.x * 64 + lane;
+    const int jc = min(j4, W4 - 1);
+    for (int k = 0; k < d.K; k++) acc4[k * 64 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int b = 0; b < d.B; b++) {
+        const int s = g * d.B + b;
+        const float4* is = (const float4*)(img + (size_t)s * d.c * d.W + (size_t)i * d.W) + jc;
+        const int cnt = nz.cnt[s];
+        const uint2* es = nz.ent + (size_t)s * nz.cap;
+        uint2 nx[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) nx[u] = es[min(u, max(cnt - 1, 0))];
+        for (int z = 0; z < cnt; z += 8) {
+            uint2 en[8];
+            float4 val[8];
+            int kk[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) en[u] = nx[u];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int p = (int)__umulhi(en[u].x, kmagic(d.K));
+                kk[u] = (int)(en[u].x - (unsigned)p * d.K);
+                val[u] = is[(size_t)p * W4];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) nx[u] = es[min(z + 8 + u, cnt - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (z + u < cnt) {
+                    const float v = __uint_as_float(en[u].y);
+                    float4 a = acc4[kk[u] * 64 + lane];
+                    a.x = fmaf(v, val[u].x, a.x), a.y = fmaf(v, val[u].y, a.y), a.z = fmaf(v, val[u].z, a.z), a.w = fmaf(v, val[u].w, a.w);
+                    acc4[kk[u] * 64 + lane] = a;
+                }
+        }
+    }
+    // the block's outputs [256 columns][K] are one contiguous span of dB[g][i][j][k]: written by all lanes in address order
+    __builtin_amdgcn_s_waitcnt(0xc07f);                  // (one wave: the LDS writes above are complete before the reads below)
+    const int j0 = blockIdx.x * 256, nj = min(256, d.W - j0);
+    float* span = dB + (size_t)g * d.h * d.W * d.K + ((size_t)i * d.W + j0) * d.K;
+    const float* accf = (const float*)acc4;
+    const int total = nj * d.K;
+    for (int idx0 = lane; idx0 < total; idx0 += 64 * 8) {      // eight pieces in flight
+        float old8[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) old8[u] = (acc && idx0 + 64 * u < total) ? span[idx0 + 64 * u] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int idx = idx0 + 64 * u;
+            if (idx < total) {
+                const int jj = (int)__umulhi((unsigned)idx, kmagic(d.K)), k = idx - jj * d.K;
+                span[idx] = old8[u] + accf[(k * 64 + (jj >> 2)) * 4 + (jj & 3)];
+            }
+        }
+    }
+}
+static bool sp_wgrad_four_columns(const SpDims& d, const float* a, const float* b) {
+    static const bool off = getenv("MOTIFS_SP_WGRAD_1COL") != nullptr;      // A/B: one column per lane
+    return !off && (d.W & 3) == 0 && (size_t)d.K * 64 * 16 <= 64 * 1024 && ((((uintptr_t)a) | ((uintptr_t)b)) & 15) == 0;
+}
 static void launch_sp_wgrad_syn(Engine& e, NzView nz, const float* dOut, float* dF, const SpDims& d, int G) {
     const size_t lds = (size_t)d.B * d.K * 128 * 4;
     if (sp_wgrad_by_reads(e, d, G, lds))
         hipLaunchKernelGGL(k_sp_wgrad_syn_reads, dim3((d.W + 127) / 128, d.h, G), dim3(128 * d.B), lds, e.st, nz, dOut, dF, d);
+    else if (sp_wgrad_four_columns(d, dOut, dF))
+        hipLaunchKernelGGL(k_sp_wgrad_syn4, dim3((d.W + 255) / 256, d.h, G), dim3(64), (size_t)d.K * 64 * 16, e.st, nz, dOut, dF, d);
     else
         hipLaunchKernelGGL(k_sp_wgrad_syn, dim3((d.W + 127) / 128, d.h, G), dim3(128), (size_t)d.K * 128 * 4, e.st, nz, dOut, dF, d);
 }
@@ -4729,6 +4849,8 @@ static void launch_sp_wgrad_ana(Engine& e, const float* img, NzView nz, float* d
     const size_t lds = (size_t)d.B * 128 * (d.K + 1) * 4;
     if (sp_wgrad_by_reads(e, d, G, lds))
         hipLaunchKernelGGL(k_sp_wgrad_ana_reads, dim3((d.W + 127) / 128, d.h, G), dim3(128 * d.B), lds, e.st, img, nz, dB, d, acc);
+    else if (sp_wgrad_four_columns(d, img, dB))
+        hipLaunchKernelGGL(k_sp_wgrad_ana4, dim3((d.W + 255) / 256, d.h, G), dim3(64), (size_t)d.K * 64 * 16, e.st, img, nz, dB, d, acc);
     else
         hipLaunchKernelGGL(k_sp_wgrad_ana, dim3((d.W + 127) / 128, d.h, G), dim3(128), (size_t)128 * (d.K + 1) * 4, e.st, img, nz, dB, d, acc);
 }
