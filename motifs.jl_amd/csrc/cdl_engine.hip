@@ -5428,7 +5428,11 @@ static __device__ __forceinline__ void med_hist_block(const float* __restrict__ 
     const uint32_t dmask = (1u << med_bits(pass)) - 1u;
     const uint32_t mask = pass == 0 ? 0u : (0xffffffffu << (shift + med_bits(pass)));
     const float* xs = x + (size_t)g * n;
-    // consecutive entries of a lane often share the leading digit: runs are counted in registers, one atomic per run
+    // consecutive entries of a lane often share the leading digit: runs are counted in registers, one atomic per run.  While both middle elements
+    // share their higher digits (p0 == p1: nearly always) one histogram serves both (med_select_core reads it twice): half the LDS atomics and
+    // half of the flush - the second pass's blocks each leave ~2 400 non-zero counters, 10 M global atomics per launch at 64 mini-batches,
+    // which is what made it 65 us against the third pass's 28
+    const bool same = pass == 0 || p0 == p1;
     uint32_t run_d = 0xffffffffu, run_c = 0;
     auto take = [&](float v) {
         if (!(v > 0.0f)) return;
@@ -5442,7 +5446,7 @@ static __device__ __forceinline__ void med_hist_block(const float* __restrict__ 
                 run_d = d, run_c = 1;
             }
         }
-        if (pass != 0 && (key & mask) == p1) atomicAdd(&h[1][d], 1u);
+        if (pass != 0 && !same && (key & mask) == p1) atomicAdd(&h[1][d], 1u);
     };
     if ((n & 3) == 0 && (((uintptr_t)xs) & 15) == 0) {
         const float4* x4 = (const float4*)xs;
@@ -5455,7 +5459,7 @@ static __device__ __forceinline__ void med_hist_block(const float* __restrict__ 
     }
     if (run_c) atomicAdd(&h[0][run_d], run_c);
     __syncthreads();
-    for (int i = threadIdx.x; i < 2 * MED_BINS; i += 256) {
+    for (int i = threadIdx.x; i < (same ? 1 : 2) * MED_BINS; i += 256) {
         const uint32_t c = (&h[0][0])[i];
         if (c) atomicAdd(&hist[(size_t)g * 2 * MED_BINS + i], c);
     }
@@ -5467,8 +5471,11 @@ static __device__ __forceinline__ void med_hist_block(const float* __restrict__ 
 static __device__ void med_select_core(MedState& sst, const uint32_t* h, int pass, uint32_t* part) {
     const int tid = threadIdx.x, shift = med_shift(pass);
     __syncthreads();                                // sst as the caller left it is visible
+    // while the lower and the upper middle element share their higher digits they look at the same entries: one histogram was counted for both
+    const bool one_hist = pass == 0 || sst.pref[0] == sst.pref[1];
+    __syncthreads();                                // (read before the first selection changes pref[0])
     for (int sel = 0; sel < 2; sel++) {
-        const uint32_t* hh = h + (pass == 0 ? 0 : sel * MED_BINS);
+        const uint32_t* hh = h + (one_hist ? 0 : sel * MED_BINS);
         uint32_t loc[8], sum = 0;
 #pragma unroll
         for (int j = 0; j < 8; j++) {
@@ -5565,7 +5572,10 @@ void median_threshold(hipStream_t st, const float* ZY, float* thr, int G, int n_
     // blocks per group: 64 when the groups fill the chip, up to 256 for a step of few mini-batches
     const unsigned nb = (unsigned)std::min<size_t>((n_per_group + 256 * 16 - 1) / (256 * 16), G >= 4 ? 64 : 256);
     if (!have_pass0) hipLaunchKernelGGL(k_med_hist0, dim3(nb, G), dim3(256), 0, st, ZY, n_per_group, h0);   // else: counted by the kernel that wrote the codes
-    hipLaunchKernelGGL(k_med_pass, dim3(nb, G), dim3(256), 0, st, ZY, n_per_group, s0, h0, h1, 1, s1);
+    // the second digit's pass leaves up to 2048 non-zero counters per block to add to the group's: with the chip full anyway, half the blocks
+    // (50.7 -> 37.1 us at 64 mini-batches; a quarter: 41.1)
+    const unsigned nb1 = (size_t)G * nb >= 2048 ? nb / 2 : nb;
+    hipLaunchKernelGGL(k_med_pass, dim3(nb1, G), dim3(256), 0, st, ZY, n_per_group, s0, h0, h1, 1, s1);
     hipLaunchKernelGGL(k_med_pass, dim3(nb, G), dim3(256), 0, st, ZY, n_per_group, s1, h1, h2, 2, s2);
     hipLaunchKernelGGL(k_med_final, dim3(G), dim3(256), 0, st, s2, h2, thr);
 }
