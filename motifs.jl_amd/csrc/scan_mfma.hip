@@ -1552,7 +1552,7 @@ template <int LEN, int CGC>
 static hipError_t launch_emit_cg_t(const FillArgs& a, hipStream_t st) {
     const size_t lds = (size_t)VF_WAVES * (CG_WIN + CG_WIN / 4) * 4 + (size_t)VF_WAVES * (512 / CGC) * a.ncg * 2 + (size_t)VF_WAVES * (512 / CGC / 32 + 1) * 17 * 4;
     if (lds > 160 * 1024 - 1024 || a.ncg > 16) return hipErrorInvalidValue;
-    const unsigned grid = (unsigned)std::min<int64_t>((a.nrows + VF_WAVES - 1) / VF_WAVES, 256 * 8);
+    const unsigned grid = (unsigned)std::min<int64_t>((a.nrows + VF_WAVES - 1) / VF_WAVES, 256 * 16);    // (1024 / 2048 / 4096 / 16384 blocks: 4.54 / 4.10 / 3.97 / 4.00 ms at configs[4])
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)emit_records_cg<LEN, CGC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((emit_records_cg<LEN, CGC>), dim3(grid), dim3(VF_THREADS), lds, st, a, stage_row_reads(a.nch));
     return hipGetLastError();
