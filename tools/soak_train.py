@@ -2,6 +2,7 @@
 a soak of the large-step kernels over changing magnitudes.  usage: python tools/soak_train.py [steps] [G]"""
 import os
 import sys
+import time
 
 import numpy as np
 
@@ -24,14 +25,17 @@ loss = torch.zeros(G, dtype=torch.float32, device="cuda")
 grad = torch.zeros(cdl.model.nP, dtype=torch.float32, device="cuda")
 dcodes = torch.zeros(lib.Context.codes_bytes(S, L), dtype=torch.uint8, device="cuda")
 first = last = None
+times = []
 for it in range(steps):
     codes = sy.gen_codes(S, L, 1000 + it, n_plant=5, k=12)
     raw = torch.from_numpy(codes).cuda()
     torch.cuda.synchronize()
     ctx.encode_dev(raw.data_ptr(), lib.DATA_CODES_U8, S, L, dcodes.data_ptr())
+    t0 = time.perf_counter()
     cdl.model.loss_grad_dev(dcodes.data_ptr(), G, loss.data_ptr(), grad.data_ptr())
     cdl.model.adabelief_dev(grad.data_ptr(), 1.0 / G)
     ctx.synchronize()
+    times.append(time.perf_counter() - t0)
     l = loss.cpu().numpy()
     g = grad.cpu().numpy()
     assert np.isfinite(l).all() and np.isfinite(g).all(), (it, l[:4])
@@ -40,5 +44,6 @@ for it in range(steps):
     last = float(l.mean())
     if it % 25 == 0:
         print(f"step {it}: mean loss {last:.4f}  |grad|max {np.abs(g).max():.3e}", flush=True)
-print(f"soak ok: {steps} steps of {G} mini-batches, mean loss {first:.3f} -> {last:.3f}")
+print(f"soak ok: {steps} steps of {G} mini-batches, mean loss {first:.3f} -> {last:.3f}; ms per step: steps 5-25 {1e3 * np.median(times[5:25]):.2f} (codes mostly dead), "
+      f"last 20 {1e3 * np.median(times[-20:]):.2f} (codes alive)")
 assert last < first
