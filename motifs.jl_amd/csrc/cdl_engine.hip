@@ -670,7 +670,7 @@ __global__ void k_zy_step2(const float* ZY, const float* g1, const float* FX, co
 // VJP: go = d out (may be null), gab = d abn (may be null).  inner = 2 ZY - 2 FX - abp.
 // g3 (optional) = d of the combination img = FX + b3*[out >= thr]*out + abn formed after the step (lin3_zy): its
 // three contributions (to d out, d abn and d FX) are folded in here instead of a pass of their own.
-template <int V>   // V = 4: 16-byte accesses (per % 4 == 0, 16-byte aligned tensors); V = 1: scalar
+template <int V>   // V = 4: 16-byte accesses (per % 4 == 0, 16-byte aligned tensors); V = 8: two of them per lane (per % 8 == 0); V = 1: scalar
 __global__ void k_zy_step2_bwd(const float* go, const float* gab, const float* g3, float b3, const float* thr, const float* out,
                                const float* ZY, const float* g1, const float* FX, const float* abp, const float* pen, const float* lst,
                                const float* ls, size_t per, float* dZY, int aZY, float* dg1, int ag1, float* dFX, int aFX, float* dabp,
@@ -684,7 +684,10 @@ __global__ void k_zy_step2_bwd(const float* go, const float* gab, const float* g
     double sp = 0, ss = 0, sl = 0;
     auto ld = [&](const float* q, size_t i) {
         VF r;
-        if (V == 4) {
+        if (V == 8) {                              // two 16-byte pieces 4 KB apart per lane: a wave's two loads of a stream cover 2 x 1 KB
+            const float4 x = *(const float4*)(q + i), y = *(const float4*)(q + i + 4);
+            r.e[0] = x.x, r.e[1 % V] = x.y, r.e[2 % V] = x.z, r.e[3 % V] = x.w, r.e[4 % V] = y.x, r.e[5 % V] = y.y, r.e[6 % V] = y.z, r.e[7 % V] = y.w;
+        } else if (V == 4) {
             const float4 x = *(const float4*)(q + i);
             r.e[0] = x.x, r.e[1 % V] = x.y, r.e[2 % V] = x.z, r.e[3 % V] = x.w;
         } else {
@@ -693,7 +696,10 @@ __global__ void k_zy_step2_bwd(const float* go, const float* gab, const float* g
         return r;
     };
     auto st = [&](float* q, size_t i, const VF& r) {
-        if (V == 4) *(float4*)(q + i) = make_float4(r.e[0], r.e[1 % V], r.e[2 % V], r.e[3 % V]);
+        if (V == 8) {
+            *(float4*)(q + i) = make_float4(r.e[0], r.e[1 % V], r.e[2 % V], r.e[3 % V]);
+            *(float4*)(q + i + 4) = make_float4(r.e[4 % V], r.e[5 % V], r.e[6 % V], r.e[7 % V]);
+        } else if (V == 4) *(float4*)(q + i) = make_float4(r.e[0], r.e[1 % V], r.e[2 % V], r.e[3 % V]);
         else q[i] = r.e[0];
     };
     for (size_t j = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * V; j < per; j += (size_t)gridDim.x * blockDim.x * V) {
@@ -976,7 +982,12 @@ std::pair<Tensor, Tensor> Engine::zy_step2(Tensor ZY, Tensor g1, Tensor FX, Tens
             auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
             const bool v4 = (per & 3) == 0 && al16(out->g) && al16(abn->g) && al16(g3) && al16(out->v) && al16(ZY->v) && al16(g1->v) &&
                             al16(FX->v) && al16(abp ? abp->v : nullptr) && al16(d0) && al16(d1) && al16(d2) && al16(d3);
-            if (v4)
+            // 32 bytes per lane and stream where the image allows it and the step is large (twelve streams per thread: 276 -> 267 us at 64 mini-batches)
+            if (v4 && (per & 7) == 0 && out->n >= ((size_t)8 << 20))
+                hipLaunchKernelGGL(k_zy_step2_bwd<8>, dim3(nblocks(per / 8, 256 * 4, std::max<size_t>(2048 / G, 1)), G), dim3(256), 0, st, out->g, abn->g,
+                                   g3, out->fl_b, g3 ? out->fl_thr : nullptr, out->v, ZY->v, g1->v, FX->v, abp ? abp->v : nullptr, pen->v, lst->v,
+                                   ls->v, per, d0, a0, d1, a1, d2, a2, d3, a3, dp, ds, dl);
+            else if (v4)
                 hipLaunchKernelGGL(k_zy_step2_bwd<4>, dim3(nblocks(per / 4, 256 * 4, std::max<size_t>(2048 / G, 1)), G), dim3(256), 0, st, out->g, abn->g,
                                    g3, out->fl_b, g3 ? out->fl_thr : nullptr, out->v, ZY->v, g1->v, FX->v, abp ? abp->v : nullptr, pen->v, lst->v,
                                    ls->v, per, d0, a0, d1, a1, d2, a2, d3, a3, dp, ds, dl);
