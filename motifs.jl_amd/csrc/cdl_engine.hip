@@ -4721,7 +4721,7 @@ __global__ __launch_bounds__(1024) void k_sp_wgrad_ana_reads(const float* __rest
 // up to 24 mini-batches: the per-read form (5.51 against 5.70 ms per step at 16, 6.93 against 7.02 at 24, even at 32, 13.75 against
 // 13.34 at 64); more: a block per (columns, row, mini-batch) fills the chip by itself
 static bool sp_wgrad_by_reads(Engine& e, const SpDims& d, int G, size_t lds) {
-    static const int max_g = getenv("MOTIFS_WGRAD_READS_MAX_G") ? atoi(getenv("MOTIFS_WGRAD_READS_MAX_G")) : 24;
+    static const int max_g = getenv("MOTIFS_WGRAD_READS_MAX_G") ? atoi(getenv("MOTIFS_WGRAD_READS_MAX_G")) : 20;      // (against the four-column form: +2 % at 16 mini-batches, -2 % at 24)
     if (G > max_g || d.B < 2 || d.B > 8 || lds > (size_t)150 << 10) return false;
     if (!e.wgrad_reads_attr_set) {
         (void)hipFuncSetAttribute((const void*)k_sp_wgrad_syn_reads, hipFuncAttributeMaxDynamicSharedMemorySize, 150 << 10);
