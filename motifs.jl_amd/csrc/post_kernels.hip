@@ -42,6 +42,22 @@ __global__ void k_minmax(const HitRec* hits, const uint16_t* scores, int64_t n, 
         if (k > kmax[m]) atomicMax(&kmax[m], k);
     }
 }
+// the same with a block's bounds in LDS (K <= 4096 PWMs): the pre-check above is two global loads per record behind the record's own
+__global__ __launch_bounds__(256) void k_minmax_lds(const HitRec* hits, const uint16_t* scores, int64_t n, int K, uint32_t* kmin, uint32_t* kmax) {
+    extern __shared__ uint32_t sb[];               // [K] minima, [K] maxima (order keys)
+    for (int i = threadIdx.x; i < K; i += 256) sb[i] = hkey(0x7c00u), sb[K + i] = hkey(0xfc00u);
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t m = hits[i].m - 1, k = hkey(scores[i]);
+        if (k < sb[m]) atomicMin(&sb[m], k);
+        if (k > sb[K + m]) atomicMax(&sb[K + m], k);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < K; i += 256) {
+        if (sb[i] < kmin[i]) atomicMin(&kmin[i], sb[i]);
+        if (sb[K + i] > kmax[i]) atomicMax(&kmax[i], sb[K + i]);
+    }
+}
 __global__ void k_minmax_out(const uint32_t* kmin, const uint32_t* kmax, int K, uint16_t* mn, uint16_t* mx) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < K) {
@@ -217,7 +233,10 @@ int motifs_hits_minmax_dev(motifs_ctx* c, const motifs_hit* hits_dev, const uint
     uint32_t* kmin = (uint32_t*)c->small.p;
     uint32_t* kmax = kmin + K;
     hipLaunchKernelGGL(k_minmax_init, dim3((K + 255) / 256), dim3(256), 0, c->stream, kmin, kmax, K);
-    if (n > 0)
+    if (n >= 2048 && K <= 4096)
+        hipLaunchKernelGGL(k_minmax_lds, dim3((unsigned)std::min<int64_t>((n + 256 * 16 - 1) / (256 * 16), 2048)), dim3(256), (size_t)K * 8, c->stream,
+                           (const HitRec*)hits_dev, scores_dev, n, K, kmin, kmax);
+    else if (n > 0)
         hipLaunchKernelGGL(k_minmax, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 8192)), dim3(256), 0, c->stream,
                            (const HitRec*)hits_dev, scores_dev, n, kmin, kmax);
     hipLaunchKernelGGL(k_minmax_out, dim3((K + 255) / 256), dim3(256), 0, c->stream, kmin, kmax, K, min_dev, max_dev);
