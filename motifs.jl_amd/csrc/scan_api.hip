@@ -340,6 +340,9 @@ static void scan_args(motifs_ctx* c, const BankSlot& bank, int K, const uint8_t*
     a.d.batch = batch;
     a.d.ohlen = (Lout + 31) / 32 * 32 + bank.lenp;
     a.d.used_tiles = (K + 31) / 32;
+    a.d.nseg = 1;
+    a.d.seg_tiles = (Lout + 7) / 8;
+    a.d.ohseg = a.d.ohlen;
     {
         int64_t spw = ns * (bank.ntiles / PG) / 16384;
         a.d.spw = (int)std::max<int64_t>(1, std::min<int64_t>(spw, 8));   // measured: 4-8 reads per wave best, 16 is 12 % slower

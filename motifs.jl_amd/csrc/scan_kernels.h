@@ -101,6 +101,10 @@ struct CandDims {
                               // chunk groups: (batch, group, l, read, chunk in group), so that a group's cells are contiguous for its consumer)
     int ohlen;                // positions in a read's one-hot LDS image (covers every window tile + the PWM length)
     int used_tiles;           // tiles that hold at least one PWM: ceil(K / 32)
+    // four-reads kernel only (set by its launcher): a block takes `seg_tiles` window tiles of 8 starts of its reads (grid z = segment) and stages
+    // `ohseg` positions of their images - long reads then leave the CU as many blocks as the registers do, and a small shard has
+    // enough blocks to even out its last round.  nseg = 1: the whole read (seg_tiles = all tiles, ohseg = ohlen).
+    int nseg, seg_tiles, ohseg;
 };
 struct CandArgs {
     const uint4* afrag;       // [tiles][T][64] PWM fragments (A operand)

@@ -257,11 +257,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((T * PG <= 
     constexpr int QPB = 4 / TGB;                     // quads of reads per block
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int w = lane & 31, h = lane >> 5, rq = w >> 3, wq = w & 7;
-    const int opitch = quad_pitch(d.ohlen);
+    const int opitch = quad_pitch(d.ohseg);
     uint2* oh = oh_all + (size_t)wave * 4 * opitch;
     const int slot = wave % QPB;
     const int tg = blockIdx.y * TGB + wave / QPB;
     if (tg * PG >= d.used_tiles) return;
+    // the block's segment of the reads: window tiles [wt0, wt0 + ntile), image positions [p0, p0 + ohs)
+    const int wt0 = (int)blockIdx.z * d.seg_tiles;
+    const int ntile = min(d.seg_tiles, (d.Lout + 7) / 8 - wt0);
+    if (ntile <= 0) return;
+    const int p0 = wt0 * 8, ohs = d.nseg == 1 ? d.ohlen : ntile * 8 + 4 * T;
     const int tile0 = tg * PG;
     const int chunk = tile0 >> 2, word0 = tile0 & 3;
     const int ng = d.used_tiles - tile0 < PG ? d.used_tiles - tile0 : PG;   // wave-uniform
@@ -280,7 +285,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((T * PG <= 
     load_bank(afrag);
 
     const unsigned lb = xcd_swz(blockIdx.x, gridDim.x);
-    const int ntile = (d.Lout + 7) / 8;
     const size_t lstride4 = (size_t)d.batch * (COMPACT ? d.cgc : d.nch) * 4;      // words between the cells of l and l + 1
     const uint2* ohl = oh + rq * opitch + wq + 2 * h;
     // (ordering batch, read in batch) of the wave's first read; later quads advance it without dividing
@@ -291,19 +295,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((T * PG <= 
         if (nq >= d.N) break;
         // stage the one-hot images: 4 halves per position (1.0 at the base; all zero for code 4, padding and reads past N);
         // a lane turns one dword of codes into four positions
+        // (the four reads' code words are requested together: one trip to memory per round of 256 positions, not four)
+        for (int p4 = lane; p4 * 4 < ohs; p4 += 64) {
+            const int pa = p4 + p0 / 4;              // the dword of the read this image dword comes from
+            const int keep = d.L - pa * 4;           // positions of this dword inside the read
+            uint32_t wv4[4];
 #pragma unroll
-        for (int rr = 0; rr < 4; rr++) {
-            const uint32_t* srow = (const uint32_t*)(codes + (nq + rr) * d.pitch);
-            const bool row = nq + rr < d.N;
-            for (int p4 = lane; p4 * 4 < d.ohlen; p4 += 64) {
-                const int keep = d.L - p4 * 4;       // positions of this dword inside the read
-                uint32_t wv = 0x04040404u;
-                if (row && keep > 0) {
-                    wv = srow[p4];
-                    if (keep < 4) {
-                        const uint32_t mk = (1u << (8 * keep)) - 1u;
-                        wv = (wv & mk) | (0x04040404u & ~mk);
-                    }
+            for (int rr = 0; rr < 4; rr++) {
+                const uint32_t* srow = (const uint32_t*)(codes + (nq + rr) * d.pitch);
+                wv4[rr] = (nq + rr < d.N && keep > 0) ? srow[pa] : 0x04040404u;
+            }
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++) {
+                uint32_t wv = wv4[rr];
+                if (keep > 0 && keep < 4) {
+                    const uint32_t mk = (1u << (8 * keep)) - 1u;
+                    wv = (wv & mk) | (0x04040404u & ~mk);
                 }
                 const uint32_t sh = wv << 4;         // 16 * code per byte; code 4 -> shift 63: the 1.0 leaves the word
                 uint64_t one[4];
@@ -327,18 +334,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((T * PG <= 
         // (chunk groups, d.cgc < d.nch: a batch's cells are group-major - (group, l, read, chunk in group))
         const size_t cell0 = COMPACT ? (((size_t)bql * (d.nch / d.cgc) + chunk / d.cgc) * d.Lout * d.batch + (size_t)rl) * d.cgc + chunk % d.cgc
                                      : ((size_t)bql * d.Lout * d.batch + (size_t)rl) * d.nch + chunk;
-        uint32_t* cp = cells + cell0 * 4 + word0 + (size_t)wq * lstride4 + (PG == 4 ? 2 * h : PG == 2 ? h : 0);
         const size_t tile_step = 8 * lstride4;
+        uint32_t* cp = cells + cell0 * 4 + word0 + (size_t)wq * lstride4 + (PG == 4 ? 2 * h : PG == 2 ? h : 0) + (size_t)wt0 * tile_step;
         // compact entries: a 32-bit running entry index (entries of a super-batch number < 2^32) instead of a second 64-bit pointer
-        const uint32_t ei0 = COMPACT ? (uint32_t)(cell0 * 2 + h + (size_t)wq * (lstride4 / 2)) * 2u : 0u;   // BYTE offset of the lane's entry (< 2^32)
         const uint32_t ei_step = (uint32_t)(4 * lstride4) * 2u;
+        const uint32_t ei0 = COMPACT ? (uint32_t)(cell0 * 2 + h + (size_t)wq * (lstride4 / 2)) * 2u + (uint32_t)wt0 * ei_step : 0u;   // BYTE offset of the lane's entry (< 2^32)
         for (int strand = 0; strand < nstrand; strand++) {        // wave-uniform
             uint32_t* const cells_s = strand ? cells2 : cells;
             uint16_t* const centries_s = strand ? centries2 : centries;
             if (nstrand == 2 && (strand || s)) load_bank(strand ? afrag2 : afrag);  // (the first quad's forward bank is already in the registers)
             uint32_t ei = ei0;
             auto store_cells = [&](int l0, uint32_t wa, uint32_t wb) {
-                const bool live = rowl && l0 + wq < d.Lout;
+                const bool live = rowl && p0 + l0 + wq < d.Lout;
                 if (COMPACT && PG == 4) {
                     uint32_t cnt;
                     const uint32_t e = half_cell_entry(wa, wb, cnt);
@@ -1352,20 +1359,49 @@ __global__ __launch_bounds__(VF_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8
 
 // the four-reads kernel's one-hot images (16 per block) against the LDS its blocks per CU leave each other
 static size_t cand_q_lds_cap(int wpe) { return (size_t)(160 * 1024 / wpe) - 1024; }
+// Segments of window tiles per read (grid z of scan_cand_kernel_q).  More than one when (a) the whole images do not fit beside the
+// other blocks of the CU (reads past ~600 positions at two blocks per CU: at BASELINE configs[4]'s 1000 positions the one-read
+// kernel ran before, 11.9 ms of candidates per 25 000 reads against 10.1 with two segments), or (b) the launch does not fill the CU
+// slots once (1 024 reads: 28 -> 15 us; 4 096: 41 -> 38).  Past one round segments cost more than they balance (12 500 reads, 1 563
+// blocks on 1 024 slots: 96 us with one segment, 100 with four - a first round takes 61 us where a later one takes 45 because its
+// blocks stage and multiply in step, and segments do not change that).  MOTIFS_CAND_SEGS forces a count (A/B runs).
+static int cand_q_segments(const CandDims& d, int lenp, int wpe, int64_t blocks) {
+    const int nt = (d.Lout + 7) / 8;
+    auto lds_of = [&](int ns) {
+        const int st = (nt + ns - 1) / ns;
+        return (size_t)4 * 4 * quad_pitch(ns == 1 ? d.ohlen : st * 8 + lenp) * 8;
+    };
+    int ns = 1;
+    while (ns < nt && lds_of(ns) > cand_q_lds_cap(wpe)) ns++;
+    static const int want = getenv("MOTIFS_CAND_SEGS") ? atoi(getenv("MOTIFS_CAND_SEGS")) : 0;
+    if (want > 0) return std::min(nt, std::max(ns, want));
+    const int64_t slots = (int64_t)256 * wpe;
+    while (blocks * (ns + 1) <= slots && ns < 8 && (nt + ns) / (ns + 1) >= 4) ns++;
+    return ns;
+}
 template <int T, int PG>
 static hipError_t launch_cand_tp(const CandArgs& a, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
     const int ntg = (a.d.used_tiles + PG - 1) / PG;           // tile groups that hold PWMs
     const int tgb = (a.uniform_eps && ntg == 1) ? 1 : 2;
-    const size_t lds_q = (size_t)4 * 4 * quad_pitch(a.d.ohlen) * 8;
-    // four reads per wave while the LDS images leave the CU as many blocks as the registers do (4, 3 or 2 per CU)
+    // four reads per wave, the LDS images leaving the CU as many blocks as the registers do (4, 3 or 2 per CU)
     constexpr int wpe = (T * PG <= 12) ? 4 : (T * PG <= 16 && PG > 1) ? 3 : 2;
-    if (a.uniform_eps && lds_q <= cand_q_lds_cap(wpe)) {
+    static const bool one_read = getenv("MOTIFS_CAND_ONE_READ") != nullptr;      // A/B: scan_cand_kernel_u (one strand per launch only)
+    if (a.uniform_eps && !(one_read && !a.afrag2)) {
         CandDims d = a.d;
         const bool compact = PG == 4 && a.centries != nullptr;
         // quads per wave: many small blocks balance the CUs best (N = 100k: 1 or 2 per wave 0.337 ms, 3: 0.354, 8: 0.390)
         d.spw = (int)std::max<int64_t>(1, std::min<int64_t>(8, a.d.N / (16 * 8192)));
         const int64_t per_block = (int64_t)(4 / tgb) * 4 * d.spw;
-        dim3 grid((unsigned)((d.N + per_block - 1) / per_block), (unsigned)((ntg + tgb - 1) / tgb), 1);
+        const unsigned gx = (unsigned)((d.N + per_block - 1) / per_block), gy = (unsigned)((ntg + tgb - 1) / tgb);
+        d.nseg = cand_q_segments(a.d, 4 * T, wpe, (int64_t)gx * gy);
+        if (d.nseg > 1) {
+            const int nt = (d.Lout + 7) / 8;
+            d.seg_tiles = (nt + d.nseg - 1) / d.nseg;
+            d.nseg = (nt + d.seg_tiles - 1) / d.seg_tiles;
+            d.ohseg = d.seg_tiles * 8 + 4 * T;
+        }
+        const size_t lds_q = (size_t)4 * 4 * quad_pitch(d.ohseg) * 8;
+        dim3 grid(gx, gy, (unsigned)d.nseg);
         if (lds_q > 64 * 1024) {                   // (reads of ~500 positions at two blocks per CU: 65 KB of one-hot images per block)
             if constexpr (PG == 4) {
                 (void)hipFuncSetAttribute((const void*)scan_cand_kernel_q<T, PG, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
@@ -1407,11 +1443,7 @@ int cand_tile_group(int lenp) { return lenp <= 20 ? 4 : lenp <= 32 ? 2 : 1; }
 bool cand_compact_ok(const CandArgs& a) { return a.uniform_eps && a.lenp <= 20; }
 // both strands of gpu_scan in one launch: the four-reads-per-wave kernel with compact entries (the condition of launch_cand_tp)
 bool cand_two_strands_ok(const CandArgs& a) {
-    if (!cand_compact_ok(a)) return false;
-    const int T = a.lenp / 4;
-    const int wpe = (T * 4 <= 12) ? 4 : (T * 4 <= 16) ? 3 : 2;
-    const size_t lds_q = (size_t)4 * 4 * quad_pitch(a.d.ohlen) * 8;
-    return lds_q <= cand_q_lds_cap(wpe);
+    return cand_compact_ok(a);           // (reads of any length: the kernel's blocks take segments of them)
 }
 
 // ev0 / ev1 (optional): events that take the kernel's own start and stop time stamps (hipExtLaunchKernelGGL): timing the

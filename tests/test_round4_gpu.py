@@ -258,3 +258,43 @@ def test_cfg4_rank_shard_full_size_properties(torch_cuda, ctx, pkg):
             assert np.array_equal(mine[order], oh) and np.array_equal(mys[order], os_), (rc, r0)
         del hits, hsc, nn_all
         torch.cuda.empty_cache()
+
+
+# ---- segments of window tiles in the four-reads candidate kernel ---------------------------------------------------------------
+@pytest.mark.parametrize("N,L,K,lo,hi,batch", [
+    (37, 333, 100, 12, 12, 16),       # 46 KB of one-hot images against the 39 KB a block may take at four blocks per CU: two segments
+    (9, 1501, 260, 8, 16, 5000),      # a long read, mixed lengths, 188 window tiles (the last one partial) in several segments
+    (64, 200, 200, 12, 12, 5000),     # a launch of 8 blocks: segments to fill the CU slots
+    (203, 1000, 130, 17, 20, 50),     # configs[4]'s read length, reads not a multiple of 4, several ordering batches
+])
+def test_segments_of_window_tiles(torch_cuda, ctx, pkg, N, L, K, lo, hi, batch):
+    """scan_cand_kernel_q's blocks take a segment of a read's window tiles when the whole one-hot images do not fit beside the CU's other
+    blocks (long reads) or the launch does not fill the CU slots once; the cells they write - and so the records - are those of
+    whole reads: the single-strand entry and the both-strands entry (one candidate launch for the two banks) against the CPU port."""
+    sy, lib, torch = pkg.synth, pkg._lib, torch_cuda
+    codes = sy.gen_codes(N, L, 61000 + L, n_plant=4, k=min(12, lo))
+    codes[N // 3, L // 2] = 4
+    codes[N - 1, L - 1] = 4
+    pwms, lens = sy.gen_pwm_bank(K, 62000 + L, len_lo=lo, len_hi=hi, alpha=0.35)
+    bank = sy.pad_bank(pwms, lens)
+    want = [fast_oracle_hits(bank, lens, codes, bool(rc), batch) for rc in (0, 1)]
+    assert min(len(w[0]) for w in want) > 100
+    for rc in (0, 1):
+        h, s, counts = dev_scan_hits(torch, ctx, pkg, bank, lens, codes, bool(rc), batch, want_counts=True)
+        assert ctx.scan_plan()["compact"]
+        assert np.array_equal(h, want[rc][0]) and np.array_equal(s, want[rc][1])
+        assert np.array_equal(counts, np.bincount(want[rc][0][:, 0] - 1, minlength=K))
+    raw = torch.from_numpy(codes).cuda()
+    dcodes = torch.zeros(lib.Context.codes_bytes(N, L), dtype=torch.uint8, device="cuda")
+    ctx.encode_dev(raw.data_ptr(), lib.DATA_CODES_U8, N, L, dcodes.data_ptr())
+    need = ctx.pwm_scan_hits_both_dev(bank, lens, dcodes.data_ptr(), N, L, None, None, 0, batch=batch)
+    assert list(need) == [len(w[0]) for w in want]
+    cap = max(need)
+    hits = [torch.zeros((cap, 3), dtype=torch.int32, device="cuda") for _ in range(2)]
+    scs = [torch.zeros(cap, dtype=torch.int16, device="cuda") for _ in range(2)]
+    got = ctx.pwm_scan_hits_both_dev(bank, lens, dcodes.data_ptr(), N, L, [t.data_ptr() for t in hits], [t.data_ptr() for t in scs], cap, batch=batch)
+    ctx.synchronize()
+    assert got == need
+    for rc in (0, 1):
+        assert np.array_equal(hits[rc][:got[rc]].cpu().numpy().astype(np.uint32), want[rc][0])
+        assert np.array_equal(scs[rc][:got[rc]].cpu().numpy().view(np.uint16), want[rc][1])
