@@ -266,6 +266,7 @@ def test_cfg4_rank_shard_full_size_properties(torch_cuda, ctx, pkg):
     (9, 1501, 260, 8, 16, 5000),      # a long read, mixed lengths, 188 window tiles (the last one partial) in several segments
     (64, 200, 200, 12, 12, 5000),     # a launch of 8 blocks: segments to fill the CU slots
     (203, 1000, 130, 17, 20, 50),     # configs[4]'s read length, reads not a multiple of 4, several ordering batches
+    (3, 20011, 60, 9, 12, 5000),      # a contig-sized read: 2 500 window tiles in ~70 segments
 ])
 def test_segments_of_window_tiles(torch_cuda, ctx, pkg, N, L, K, lo, hi, batch):
     """scan_cand_kernel_q's blocks take a segment of a read's window tiles when the whole one-hot images do not fit beside the CU's other
