@@ -24,11 +24,14 @@ def scan_to_device(ctx, pkg, bank, lens, codes, rc):
     return dcodes, hits, sc, n
 
 
-@pytest.mark.parametrize("K,lo,hi", [(9, 5, 9), (150, 6, 12)])
+# (the count matrices fetch a window as 4, 6 or 8 dwords by the longest PWM: 12 / 20 / 28 positions; byte by byte past that)
+@pytest.mark.parametrize("K,lo,hi", [(9, 5, 9), (150, 6, 12), (40, 14, 20), (20, 22, 27), (6, 30, 33)])
 def test_consumers_match_oracle(ctx, pkg, K, lo, hi):
     sy, post = pkg.synth, pkg.post
     N, L = 300, 60
     codes = sy.gen_codes(N, L, 31 + K, n_plant=3, k=8)
+    codes[5, 7] = 4                      # an N inside windows that still score: no count from that position
+    codes[N - 1, L - 1] = 4
     pwms, lens = sy.gen_pwm_bank(K, 32 + K, len_lo=lo, len_hi=hi, alpha=0.45)
     bank = sy.pad_bank(pwms, lens)
     maxlen = int(lens.max())
