@@ -88,6 +88,8 @@ struct motifs_ctx {
     motifs::DevBuf centries;        // matrix-core scan: compact 16-bit entries of the candidate cells (scan_mfma.hip)
     bool compact_cells = true;      // MOTIFS_DENSE_CELLS=1 turns them off (the round-2 round trip through the 128-bit cells)
     motifs::DevBuf cnt2, centries2; // the reverse strand's cells / entries when one candidate launch serves both strands of gpu_scan
+    motifs::DevBuf cm_lens;         // motifs_hits_count_matrices_dev: the PWM lengths of the last call (uploaded again only when they change)
+    std::vector<int32_t> cm_lens_host;
     int cg_chunks = -1;             // chunk groups of the re-scoring (scan_mfma.hip): -1 = when the table does not fit the LDS; MOTIFS_CG_CHUNKS overrides
     bool dense_fused = true;        // a17's tensor in one kernel (scan_dense.hip); MOTIFS_DENSE_FUSED=0: candidate kernel + stage_hits<.., 2>
     int32_t scan_plan[4] = {0, 0, 0, 0};   // motifs_ctx_scan_plan

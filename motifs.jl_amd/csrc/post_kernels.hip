@@ -47,10 +47,22 @@ __global__ __launch_bounds__(256) void k_minmax_lds(const HitRec* hits, const ui
     extern __shared__ uint32_t sb[];               // [K] minima, [K] maxima (order keys)
     for (int i = threadIdx.x; i < K; i += 256) sb[i] = hkey(0x7c00u), sb[K + i] = hkey(0xfc00u);
     __syncthreads();
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const uint32_t m = hits[i].m - 1, k = hkey(scores[i]);
-        if (k < sb[m]) atomicMin(&sb[m], k);
-        if (k > sb[K + m]) atomicMax(&sb[K + m], k);
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x; i0 < n; i0 += 4 * stride) {       // four records requested together
+        uint32_t m4[4];
+        uint16_t s4[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int64_t i = min(i0 + u * stride, n - 1);          // (a clamped turn repeats the last record: bounds unchanged)
+            m4[u] = hits[i].m - 1;
+            s4[u] = scores[i];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t m = m4[u], k = hkey(s4[u]);
+            if (k < sb[m]) atomicMin(&sb[m], k);
+            if (k > sb[K + m]) atomicMax(&sb[K + m], k);
+        }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < K; i += 256) {
@@ -83,27 +95,44 @@ __global__ void k_thr_hist(const HitRec* hits, const uint16_t* scores, int64_t n
 }
 // the same with the counters (and the thresholds) in LDS: one global atomic per record onto K (T + 1) addresses was what the pass cost (3.6 ms for
 // 28.5 M records against 8 600 counters at configs[1]); a block's non-zero counters are added to the global ones once, at its end
-__global__ __launch_bounds__(256) void k_thr_hist_lds(const HitRec* hits, const uint16_t* scores, int64_t n, const uint16_t* thr, int K, int T,
+__global__ __launch_bounds__(1024) void k_thr_hist_lds(const HitRec* hits, const uint16_t* scores, int64_t n, const uint16_t* thr, int K, int T,
                                                       unsigned long long* hist) {
     extern __shared__ uint32_t sh[];               // [K (T + 1)] counters, then [K T] thresholds (halves)
     const int nb = K * (T + 1);
     uint16_t* st = (uint16_t*)(sh + nb);
-    for (int i = threadIdx.x; i < nb; i += 256) sh[i] = 0;
-    for (int i = threadIdx.x; i < K * T; i += 256) st[i] = thr[i];
+    for (int i = threadIdx.x; i < nb; i += blockDim.x) sh[i] = 0;
+    for (int i = threadIdx.x; i < K * T; i += blockDim.x) st[i] = thr[i];
     __syncthreads();
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const uint32_t m = hits[i].m - 1;
-        const float s = h2f(scores[i]);
-        const uint16_t* t = st + (size_t)m * T;
-        int lo = 0, hi = T;
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (h2f(t[mid]) < s) lo = mid + 1; else hi = mid;
+    // four records per thread and turn, requested together (one at a time the pass waited on ~110 dependent trips to memory per thread)
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int top = 1;
+    while (top * 2 <= T) top *= 2;
+    for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += 4 * stride) {
+        uint32_t m4[4];
+        uint16_t s4[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int64_t i = i0 + u * stride;
+            m4[u] = i < n ? hits[i].m - 1 : 0u;
+            s4[u] = i < n ? scores[i] : (uint16_t)0xfc00u;        // -Inf: below every threshold, counted nowhere
         }
-        if (lo > 0) atomicAdd(&sh[m * (T + 1) + lo], 1u);
+        // thresholds strictly below the score, by steps of falling powers of two: the same trips for every record, so the four searches
+        // interleave (a while (lo < hi) per record ran them one after the other)
+        int lo4[4] = {0, 0, 0, 0};
+        for (int step = top; step; step >>= 1) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int np = lo4[u] + step;
+                const float tv = h2f(st[(size_t)m4[u] * T + min(np, T) - 1]);
+                if (np <= T && tv < h2f(s4[u])) lo4[u] = np;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (lo4[u] > 0 && i0 + u * stride < n) atomicAdd(&sh[m4[u] * (T + 1) + lo4[u]], 1u);
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < nb; i += 256)
+    for (int i = threadIdx.x; i < nb; i += blockDim.x)
         if (sh[i]) atomicAdd(&hist[i], (unsigned long long)sh[i]);
 }
 __global__ void k_thr_suffix(const unsigned long long* hist, int K, int T, int64_t* counts) {
@@ -218,14 +247,14 @@ __global__ __launch_bounds__(256) void k_count_mats(const HitRec* hits, int64_t 
 // dword would have held lies past the window.  28 M records of a configs[1] strand: 0.84 ms with the byte loads, 0.24 now; by blocks
 // (one LDS copy of the matrices each, flushed with one global atomic per non-zero counter): 2 048: 0.27, 1 024: 0.24, 512: 0.34 ms.
 template <int NW>
-__global__ __launch_bounds__(256) void k_count_mats_w(const HitRec* hits, int64_t n, const uint8_t* codes, int pitch, int64_t n0,
+__global__ __launch_bounds__(1024) void k_count_mats_w(const HitRec* hits, int64_t n, const uint8_t* codes, int pitch, int64_t n0,
                                                       const int32_t* lens, int K, int maxlen, int comp, unsigned int* counts) {
     extern __shared__ unsigned int lh[];
     const int bins = K * maxlen * 4;
-    for (int i = threadIdx.x; i < bins; i += 256) lh[i] = 0;
+    for (int i = threadIdx.x; i < bins; i += blockDim.x) lh[i] = 0;
     __syncthreads();
     const int dmax = pitch / 4 - 1;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const HitRec h = hits[i];
         const int m = (int)h.m - 1, len = lens[m], off = (int)h.l - 1;
         const uint32_t* rw = (const uint32_t*)(codes + ((int64_t)h.n - 1 - n0) * pitch);
@@ -250,7 +279,7 @@ __global__ __launch_bounds__(256) void k_count_mats_w(const HitRec* hits, int64_
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < bins; i += 256)
+    for (int i = threadIdx.x; i < bins; i += blockDim.x)
         if (lh[i]) atomicAdd(&counts[i], lh[i]);
 }
 
@@ -295,9 +324,14 @@ int motifs_hits_threshold_counts_dev(motifs_ctx* c, const motifs_hit* hits_dev, 
     unsigned long long* hist = (unsigned long long*)c->tilesum.p;
     MOTIFS_HIP_CHECK(hipMemsetAsync(hist, 0, (size_t)K * (T + 1) * 8, c->stream));
     const size_t lds = (size_t)K * (T + 1) * 4 + (size_t)K * T * 2;
-    if (n >= 2048 && lds <= 64 * 1024)            // (a block counts fewer than 2^32 records)
-        hipLaunchKernelGGL(k_thr_hist_lds, dim3((unsigned)std::min<int64_t>((n + 256 * 64 - 1) / (256 * 64), 1024)), dim3(256), lds, c->stream,
+    if (n >= 2048 && lds <= 64 * 1024) {          // (a block counts fewer than 2^32 records)
+        // 1 024-thread blocks, as many per CU as their LDS lets in (two at configs[1]: 51 KB each), in ONE round: more waves per CU behind
+        // fewer LDS copies to flush.  28.5 M records: 0.34 ms with 1 024 blocks of 256 threads, 0.22 with one round of them (768), 0.126 now.
+        const int bt = 1024;
+        const int64_t slots = 256 * std::min<int64_t>(2048 / bt, (160 * 1024) / (lds + 512));
+        hipLaunchKernelGGL(k_thr_hist_lds, dim3((unsigned)std::min<int64_t>((n + bt * 16 - 1) / (bt * 16), slots)), dim3(bt), lds, c->stream,
                            (const HitRec*)hits_dev, scores_dev, n, thr_dev, K, T, hist);
+    }
     else if (n > 0)
         hipLaunchKernelGGL(k_thr_hist, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 8192)), dim3(256), 0, c->stream,
                            (const HitRec*)hits_dev, scores_dev, n, thr_dev, T, hist);
@@ -341,29 +375,34 @@ int motifs_hits_count_matrices_dev(motifs_ctx* c, const motifs_hit* hits_dev, in
     MOTIFS_HIP_CHECK(hipSetDevice(c->device));
     std::vector<int32_t> l32(K);
     for (int k = 0; k < K; k++) l32[k] = (int32_t)lens[k];
-    MOTIFS_HIP_CHECK(c->lim.reserve((size_t)K * 4));
-    MOTIFS_HIP_CHECK(hipMemcpyAsync(c->lim.p, l32.data(), (size_t)K * 4, hipMemcpyHostToDevice, c->stream));
-    MOTIFS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (l32 != c->cm_lens_host) {                  // (posdicts2countmats is called per strand and per refinement round with the same motifs)
+        c->cm_lens_host.clear();
+        MOTIFS_HIP_CHECK(c->cm_lens.reserve((size_t)K * 4));
+        MOTIFS_HIP_CHECK(hipMemcpyAsync(c->cm_lens.p, l32.data(), (size_t)K * 4, hipMemcpyHostToDevice, c->stream));
+        MOTIFS_HIP_CHECK(hipStreamSynchronize(c->stream));
+        c->cm_lens_host = l32;
+    }
     const size_t bins = (size_t)K * maxlen * 4;
     const int use_lds = bins * 4 <= 48 * 1024;
     if (use_lds && maxlen <= 28 && ((uintptr_t)codes_dev & 3) == 0) {
         static const int nblk = getenv("MOTIFS_COUNT_MATS_BLOCKS") ? atoi(getenv("MOTIFS_COUNT_MATS_BLOCKS")) : 1024;
-        const dim3 grid((unsigned)std::min<int64_t>((n + 255) / 256, std::max(nblk, 1)));
+        const int cbt = 256;             // (512- and 1 024-thread blocks, 256-768 of them: 0.21-0.26 ms - the pass is bound by its LDS atomics)
+        const dim3 grid((unsigned)std::min<int64_t>((n + cbt - 1) / cbt, std::max(nblk, 1)));
         const int pitch = motifs_codes_pitch(L);
         if (maxlen <= 12)
-            hipLaunchKernelGGL(k_count_mats_w<4>, grid, dim3(256), bins * 4, c->stream, (const HitRec*)hits_dev, n, codes_dev, pitch, n0,
-                               (const int32_t*)c->lim.p, K, maxlen, comp, counts_dev);
+            hipLaunchKernelGGL(k_count_mats_w<4>, grid, dim3(cbt), bins * 4, c->stream, (const HitRec*)hits_dev, n, codes_dev, pitch, n0,
+                               (const int32_t*)c->cm_lens.p, K, maxlen, comp, counts_dev);
         else if (maxlen <= 20)
-            hipLaunchKernelGGL(k_count_mats_w<6>, grid, dim3(256), bins * 4, c->stream, (const HitRec*)hits_dev, n, codes_dev, pitch, n0,
-                               (const int32_t*)c->lim.p, K, maxlen, comp, counts_dev);
+            hipLaunchKernelGGL(k_count_mats_w<6>, grid, dim3(cbt), bins * 4, c->stream, (const HitRec*)hits_dev, n, codes_dev, pitch, n0,
+                               (const int32_t*)c->cm_lens.p, K, maxlen, comp, counts_dev);
         else
-            hipLaunchKernelGGL(k_count_mats_w<8>, grid, dim3(256), bins * 4, c->stream, (const HitRec*)hits_dev, n, codes_dev, pitch, n0,
-                               (const int32_t*)c->lim.p, K, maxlen, comp, counts_dev);
+            hipLaunchKernelGGL(k_count_mats_w<8>, grid, dim3(cbt), bins * 4, c->stream, (const HitRec*)hits_dev, n, codes_dev, pitch, n0,
+                               (const int32_t*)c->cm_lens.p, K, maxlen, comp, counts_dev);
         MOTIFS_HIP_CHECK(hipGetLastError());
         return MOTIFS_OK;
     }
     hipLaunchKernelGGL(k_count_mats, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 2048)), dim3(256), use_lds ? bins * 4 : 0, c->stream,
-                       (const HitRec*)hits_dev, n, codes_dev, motifs_codes_pitch(L), n0, (const int32_t*)c->lim.p, K, maxlen, comp,
+                       (const HitRec*)hits_dev, n, codes_dev, motifs_codes_pitch(L), n0, (const int32_t*)c->cm_lens.p, K, maxlen, comp,
                        use_lds, counts_dev);
     MOTIFS_HIP_CHECK(hipGetLastError());
     return MOTIFS_OK;

@@ -646,7 +646,7 @@ void motifs_ctx_destroy(motifs_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : {&c->tab, &c->lim, &c->cnt, &c->off, &c->tilesum, &c->small, &c->codes, &c->hits_tmp,
-                      &c->scores_tmp, &c->pwmcnt, &c->data_tmp, &c->afrag, &c->cinit, &c->staging, &c->rowx, &c->dp_scratch, &c->centries, &c->cnt2, &c->centries2})
+                      &c->scores_tmp, &c->pwmcnt, &c->data_tmp, &c->afrag, &c->cinit, &c->staging, &c->rowx, &c->dp_scratch, &c->centries, &c->cnt2, &c->centries2, &c->cm_lens})
         b->release();
     for (BankSlot& bs : c->bank_slot)
         for (DevBuf* b : {&bs.tab, &bs.lim, &bs.afrag, &bs.cinit, &bs.tabk}) b->release();
