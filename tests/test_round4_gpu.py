@@ -299,3 +299,26 @@ def test_segments_of_window_tiles(torch_cuda, ctx, pkg, N, L, K, lo, hi, batch):
     for rc in (0, 1):
         assert np.array_equal(hits[rc][:got[rc]].cpu().numpy().astype(np.uint32), want[rc][0])
         assert np.array_equal(scs[rc][:got[rc]].cpu().numpy().view(np.uint16), want[rc][1])
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_shapes_with_long_reads(torch_cuda, ctx, pkg, seed):
+    """Shapes drawn at random around the segment boundaries of the candidate kernel (reads of 150 - 3000 positions, PWMs of every template length
+    up to 20, banks of one to five chunks, ordering batches that do and do not divide the reads): both strands against the CPU port."""
+    rng = np.random.default_rng(8800 + seed)
+    L = int(rng.integers(150, 3000))
+    lo = int(rng.integers(6, 18))
+    hi = int(rng.integers(lo, 21))
+    K = int(rng.integers(20, 600))
+    N = int(rng.integers(1, max(2, 120000 // L)))
+    batch = int(rng.choice([5000, 7, 16, 33]))
+    sy = pkg.synth
+    codes = sy.gen_codes(N, L, 8900 + seed, n_plant=3, k=min(10, lo))
+    codes[N // 2, L // 2] = 4
+    pwms, lens = sy.gen_pwm_bank(K, 9000 + seed, len_lo=lo, len_hi=hi, alpha=0.35)
+    bank = sy.pad_bank(pwms, lens)
+    for rc in (False, True):
+        h, s, counts = dev_scan_hits(torch_cuda, ctx, pkg, bank, lens, codes, rc, batch, want_counts=True)
+        oh, os_ = fast_oracle_hits(bank, lens, codes, rc, batch)
+        assert np.array_equal(h, oh) and np.array_equal(s, os_), (N, L, K, lo, hi, batch)
+        assert np.array_equal(counts, np.bincount(oh[:, 0] - 1, minlength=K))
