@@ -90,7 +90,8 @@ static __device__ __forceinline__ void cand_read(const f16x8 (&A)[PG][T], const 
         if (PG == 4) {
             const auto s02 = __builtin_amdgcn_permlane32_swap(m[0], m[2], false, false);
             const auto s13 = __builtin_amdgcn_permlane32_swap(m[1], m[3], false, false);
-            emit(l0, s02[0] | (s02[1] << 16), s13[0] | (s13[1] << 16));                   // h=0: words 0,1; h=1: words 2,3
+            // (v_perm_b32: the low halves of the two words in one instruction)
+            emit(l0, __builtin_amdgcn_perm(s02[1], s02[0], 0x05040100u), __builtin_amdgcn_perm(s13[1], s13[0], 0x05040100u));   // h=0: words 0,1; h=1: words 2,3
         } else if (PG == 2) {
             const auto s01 = __builtin_amdgcn_permlane32_swap(m[0], m[1 % PG], false, false);
             emit(l0, s01[0] | (s01[1] << 16), 0u);                                        // h=0: word 0; h=1: word 1
@@ -345,7 +346,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((T * PG <= 
             if (nstrand == 2 && (strand || s)) load_bank(strand ? afrag2 : afrag);  // (the first quad's forward bank is already in the registers)
             uint32_t ei = ei0;
             auto store_cells = [&](int l0, uint32_t wa, uint32_t wb) {
-                const bool live = rowl && p0 + l0 + wq < d.Lout;
+                const bool live = rowl && wq < d.Lout - p0 - l0;                                      // (a scalar bound: no vector add per tile)
                 if (COMPACT && PG == 4) {
                     uint32_t cnt;
                     const uint32_t e = half_cell_entry(wa, wb, cnt);
