@@ -68,6 +68,47 @@ def test_consumers_match_oracle(ctx, pkg, K, lo, hi):
         assert np.array_equal(mats[k].view(np.uint16), w.view(np.uint16))
 
 
+def test_count_matrices_of_a_shard(ctx, pkg):
+    """A rank's shard: its code rows start at global read n0 + 1 and its records carry global read numbers; the matrices of the
+    shard are the oracle's over exactly those records.  The second call passes the code rows from an odd address (the dword-window
+    kernel asks for 4-byte alignment: the byte-by-byte kernel takes over) and must give the same counts."""
+    sy, post, lib = pkg.synth, pkg.post, pkg._lib
+    N, L, K, s0 = 500, 77, 60, 123
+    codes = sy.gen_codes(N, L, 77, n_plant=3, k=9)
+    codes[s0 + 5, 40] = 4
+    pwms, lens = sy.gen_pwm_bank(K, 78, len_lo=7, len_hi=15, alpha=0.4)
+    bank = sy.pad_bank(pwms, lens)
+    maxlen = int(lens.max())
+    ns = N - s0
+    raw = torch.from_numpy(codes[s0:]).cuda()
+    pad = 4
+    buf = torch.zeros(lib.Context.codes_bytes(ns, L) + 2 * pad, dtype=torch.uint8, device="cuda")
+    ctx.encode_dev(raw.data_ptr(), lib.DATA_CODES_U8, ns, L, buf.data_ptr())
+    want = np.zeros((K, maxlen, 4), dtype=np.float32)
+    strands = []
+    for rc in (False, True):
+        n = ctx.pwm_scan_hits_dev(bank, lens, buf.data_ptr(), ns, L, rc, None, None, 0, n0=s0)
+        hits = torch.zeros((max(n, 1), 3), dtype=torch.int32, device="cuda")
+        sc = torch.zeros(max(n, 1), dtype=torch.int16, device="cuda")
+        ctx.pwm_scan_hits_dev(bank, lens, buf.data_ptr(), ns, L, rc, hits.data_ptr(), sc.data_ptr(), n, n0=s0)
+        ctx.synchronize()
+        h = hits[:n].cpu().numpy().astype(np.int64)
+        assert n > 500 and h[:, 1].min() > s0 and h[:, 1].max() <= N
+        want += po.countmats(h[:, 0], h[:, 1], h[:, 2], rc, codes, lens, K, maxlen).astype(np.float32)
+        strands.append((hits, n, rc))
+    got = post.posdicts2countmats(ctx, strands, buf.data_ptr(), L, lens, maxlen, n0=s0)
+    # the same rows one byte further on: an odd address
+    nbytes = lib.Context.codes_bytes(ns, L)
+    odd = torch.zeros(nbytes + 2 * pad, dtype=torch.uint8, device="cuda")
+    odd[1:1 + nbytes] = buf[:nbytes]
+    torch.cuda.synchronize()
+    got_odd = post.posdicts2countmats(ctx, strands, odd.data_ptr() + 1, L, lens, maxlen, n0=s0)
+    for k in range(K):
+        w = (want[k, : int(lens[k]), :].T + np.float32(0.01)).astype(np.float16)
+        assert np.array_equal(got[k].view(np.uint16), w.view(np.uint16))
+        assert np.array_equal(got_odd[k].view(np.uint16), w.view(np.uint16))
+
+
 # ---- consumers of the code records (§8f-4) -----------------------------------------------------------------------
 def _random_code_records(pkg, nseq, seed, gap_every=0):
     rng = np.random.default_rng(seed)
