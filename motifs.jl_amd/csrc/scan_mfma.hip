@@ -237,6 +237,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((T * PG <= 
 // contiguously ran 0.343 ms against 0.381), and the per-read overhead (staging, cell address) is shared by 24 tiles
 // instead of 6.  The four images sit `opitch` apart in LDS, opitch = 8 (mod 32) positions = 64 (mod 256) bytes: the 8-byte
 // B-operand reads of a half wave then cover the 64 banks exactly once.
+// A-fragment registers (T * PG) up to which the four-reads kernel is held to three waves per SIMD (168 VGPRs).  20 = PWMs of 17-20 positions
+// (BASELINE configs[3] / [4]): the kernel wants 178 and is given 168 - ten dwords spill, all of them outside the tile loop - for a third wave
+// on the matrix pipe: candidates 3.30 -> 3.21 ms at the configs[3] shard, 10.45 -> 9.98 at configs[4] (16: two waves there).
+#ifndef CAND_Q_W3
+#define CAND_Q_W3 20
+#endif
 static __host__ __device__ inline int quad_pitch(int ohlen) { return ((((ohlen + 3) & ~3) - 8 + 31) & ~31) + 8; }
 
 // Compact entries (COMPACT, tile groups of 4 only): candidates are under 1 % of the (PWM, window) pairs, so a half cell - the 64
@@ -247,7 +253,7 @@ static __host__ __device__ inline int quad_pitch(int ohlen) { return ((((ohlen +
 // changes is the traffic of the round trip: 151 MB + the rare cells instead of 605 MB written and read back per strand of
 // BASELINE configs[1].
 template <int T, int PG, int TGB, bool COMPACT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((T * PG <= 12) ? 4 : (T * PG <= 16 && PG > 1) ? 3 : 2, 4))) void scan_cand_kernel_q(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((T * PG <= 12) ? 4 : (T * PG <= CAND_Q_W3 && PG > 1) ? 3 : 2, 4))) void scan_cand_kernel_q(
     const uint4* __restrict__ afrag, const uint8_t* __restrict__ codes, uint32_t* __restrict__ cells, uint16_t* __restrict__ centries, const CandDims d,
     const uint4* __restrict__ afrag2, uint32_t* __restrict__ cells2, uint16_t* __restrict__ centries2) {
     // afrag2 != nullptr (COMPACT only): the reverse strand's bank goes over the SAME staged reads right after the forward one's -
@@ -1385,7 +1391,7 @@ static hipError_t launch_cand_tp(const CandArgs& a, hipStream_t st, hipEvent_t e
     const int ntg = (a.d.used_tiles + PG - 1) / PG;           // tile groups that hold PWMs
     const int tgb = (a.uniform_eps && ntg == 1) ? 1 : 2;
     // four reads per wave, the LDS images leaving the CU as many blocks as the registers do (4, 3 or 2 per CU)
-    constexpr int wpe = (T * PG <= 12) ? 4 : (T * PG <= 16 && PG > 1) ? 3 : 2;
+    constexpr int wpe = (T * PG <= 12) ? 4 : (T * PG <= CAND_Q_W3 && PG > 1) ? 3 : 2;
     static const bool one_read = getenv("MOTIFS_CAND_ONE_READ") != nullptr;      // A/B: scan_cand_kernel_u (one strand per launch only)
     if (a.uniform_eps && !(one_read && !a.afrag2)) {
         CandDims d = a.d;
