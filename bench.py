@@ -779,7 +779,7 @@ def main():
             "traffic_source": traffic_src,
             "flops_per_launch": cand_flops,
             "avg_launch_ms": cand_ms,
-            "note": "per tile of a wave: 12 matrix instructions (384 cycles of the matrix pipe) and 89 vector instructions (one v_alignbit per sign "
+            "note": "per tile of a wave: 12 matrix instructions (384 cycles of the matrix pipe) and 86 vector instructions (one v_alignbit per sign "
                     "bit) on the same issue port, ISA count in DESIGN 2.7-2 - the two are level, which caps this fraction near 0.6",
         },
         "pass_hbm": {

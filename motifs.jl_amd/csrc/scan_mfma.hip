@@ -77,21 +77,26 @@ static __device__ __forceinline__ void cand_read(const f16x8 (&A)[PG][T], const 
 #pragma unroll
             for (int g = 0; g < NG; g++) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[g][t], B[t], acc[g], 0, 0, 0);
         uint32_t m[PG];           // bit r = accumulator r is a candidate (sign set: -(S + eps) < 0)
+        // PG == 4: the 16 sign bits of tile 1 (3) follow those of tile 0 (2) into the same word - m[0] = tile 0 << 16 | tile 1, m[2] likewise -
+        // so that ONE v_permlane32_swap hands every lane both halves of its two tiles
 #pragma unroll
         for (int g = 0; g < PG; g++) {
-            m[g] = 0;
+            const bool cont = PG == 4 && (g & 1);                 // continues the word of tile g - 1
+            if (!cont) m[g] = 0;
+            uint32_t& mg = m[cont ? g - 1 : g];
             if (g < NG) {
 #pragma unroll
-                for (int r = 15; r >= 0; r--) m[g] = __builtin_amdgcn_alignbit(m[g], __float_as_uint(acc[g][r]), 31);
+                for (int r = 15; r >= 0; r--) mg = __builtin_amdgcn_alignbit(mg, __float_as_uint(acc[g][r]), 31);
+            } else if (cont) {
+                mg <<= 16;
             }
         }
         // the other 16 PWMs of a tile sit in the other half of the wave: v_permlane32_swap hands lane (w, 0) both
         // halves of one tile and lane (w, 1) both halves of another, so all 64 lanes have words to deliver
         if (PG == 4) {
-            const auto s02 = __builtin_amdgcn_permlane32_swap(m[0], m[2], false, false);
-            const auto s13 = __builtin_amdgcn_permlane32_swap(m[1], m[3], false, false);
-            // (v_perm_b32: the low halves of the two words in one instruction)
-            emit(l0, __builtin_amdgcn_perm(s02[1], s02[0], 0x05040100u), __builtin_amdgcn_perm(s13[1], s13[0], 0x05040100u));   // h=0: words 0,1; h=1: words 2,3
+            const auto sw = __builtin_amdgcn_permlane32_swap(m[0], m[2], false, false);
+            // (v_perm_b32: the high halves of the two words = tile 0 / 2, the low halves = tile 1 / 3)
+            emit(l0, __builtin_amdgcn_perm(sw[1], sw[0], 0x07060302u), __builtin_amdgcn_perm(sw[1], sw[0], 0x05040100u));   // h=0: words 0,1; h=1: words 2,3
         } else if (PG == 2) {
             const auto s01 = __builtin_amdgcn_permlane32_swap(m[0], m[1 % PG], false, false);
             emit(l0, s01[0] | (s01[1] << 16), 0u);                                        // h=0: word 0; h=1: word 1
@@ -112,8 +117,8 @@ static __device__ __forceinline__ uint32_t half_cell_entry(uint32_t wa, uint32_t
     asm("v_ffbh_u32 %0, %1" : "=v"(lb) : "v"(wa));
     cnt = (uint32_t)__builtin_popcount(wa) + (uint32_t)__builtin_popcount(wb);
     const uint32_t first = min(fa, fb | 32u), lastp = min(la, lb | 32u);   // 0..63 whenever cnt >= 1 (garbage for an empty half cell)
-    const uint32_t low = cnt < 3u ? ((lastp << 6) | (first & 63u)) & 0xfffu : cnt;    // selects, not branches: this sits between MFMAs
-    return (min(cnt, 3u) << 12) | low;                                        // count 0: the low bits are ignored by the consumers
+    // selects, not branches: this sits between MFMAs.  Count 0: the low bits (the garbage, cut to 12 bits) are ignored by the consumers
+    return cnt < 3u ? (((lastp << 6) | first) & 0xfffu) | (cnt << 12) : (cnt | 0x3000u);
 }
 
 // UEPS: the bank was scaled by powers of two on the host so that the slack of tile g of a group is the inline constant
