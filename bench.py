@@ -151,6 +151,10 @@ def main():
     work_stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(work_stream)
     ctx.set_stream(work_stream.cuda_stream)
+    # gpu_scan over many shards: a call returns once its hit totals are known and its records follow in stream order
+    # (motifs_ctx_set_records_in_stream_order) - the host prepares step i + 1 under the record writes of step i; the timed region
+    # ends with a device synchronize, so every record of every step is written inside it
+    ctx.set_records_in_stream_order(True)
     reducer, reducer_note = par.make_reducer(ctx, prefer_rccl=not rehearse)
 
     # ---- synthetic inputs ------------------------------------------------------
@@ -765,6 +769,7 @@ def main():
             "hits_per_step": int(tot_hits.item()) if world == 1 else int(strong.get("hist_total_hits", 0)),
             "parallelism": f"sequence shards x{world}; per step one sum of the 2 x {K} hit histogram: {reducer.kind} ({reducer_note})",
             "untimed_preheat_steps": PREHEAT,
+            "records_in_stream_order": True,
         },
         "roofline": {
             "kernel": "scan_cand_kernel_q<3,4,2,compact> (v_mfma_f32_32x32x16_f16 candidate filter, four reads per wave; "

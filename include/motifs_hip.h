@@ -94,6 +94,12 @@ int motifs_ctx_synchronize(motifs_ctx* ctx);
 /* Upper bound in bytes for the scan's candidate / staging workspace (0 = the default, 8 GiB).  A scan that needs
  * more walks the reads in super-batches of whole ordering batches; the records do not depend on the bound. */
 int motifs_ctx_set_workspace_limit(motifs_ctx* ctx, size_t bytes);
+/* Records in stream order (off by default).  on != 0: motifs_pwm_scan_hits_both_dev returns as soon as the hit totals are known -
+ * the row scans have run - while the kernel that writes the records may still be running: hits / scores are complete for
+ * everything queued on the context's stream afterwards and after motifs_ctx_synchronize, as a hipMemcpyAsync's destination is.
+ * A host loop over many shards then prepares its next call under the record writes instead of after them (the single-launch
+ * plan only: a scan that needs several super-batches still returns when all of it is done). */
+int motifs_ctx_set_records_in_stream_order(motifs_ctx* ctx, int on);
 /* Per-kernel device time, measured with HIP events on the context stream
  * around every launch of that kernel (each timed launch synchronises, so leave
  * timing off outside measurements).  `slot` is a motifs_kernel_slot; *ms is the

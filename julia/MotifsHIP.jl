@@ -60,6 +60,9 @@ end
 use_private_stream!(c::Context) = check(ccall((:motifs_ctx_use_private_stream, lib), Cint, (Ptr{Cvoid},), c.h))
 set_workspace_limit!(c::Context, bytes::Integer) =
     check(ccall((:motifs_ctx_set_workspace_limit, lib), Cint, (Ptr{Cvoid}, Csize_t), c.h, bytes))
+# gpu_scan over many shards: return once the hit totals are known, the records complete in stream order (see the header)
+set_records_in_stream_order!(c::Context, on::Bool=true) =
+    check(ccall((:motifs_ctx_set_records_in_stream_order, lib), Cint, (Ptr{Cvoid}, Cint), c.h, on ? 1 : 0))
 # diagnostics: how the last hit-record scan was laid out (compact entries, chunks per chunk group, groups, launches)
 function scan_plan(c::Context)
     v = zeros(Int32, 4)

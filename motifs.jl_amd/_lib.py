@@ -61,6 +61,7 @@ SIGNATURES = {
     "motifs_dev_download": (_int, [_p, _p, _p, C.c_size_t]),
     "motifs_dev_memset": (_int, [_p, _p, _int, C.c_size_t]),
     "motifs_ctx_set_workspace_limit": (_int, [_p, C.c_size_t]),
+    "motifs_ctx_set_records_in_stream_order": (_int, [_p, _int]),
     "motifs_ctx_synchronize": (_int, [_p]),
     "motifs_ctx_enable_timing": (_int, [_p, _int]),
     "motifs_ctx_reset_timing": (_int, [_p]),
@@ -243,6 +244,10 @@ class Context:
     def set_workspace_limit(self, nbytes):
         """Bound of the scan's candidate/staging workspace (0 = default 8 GiB); larger scans run in super-batches."""
         check(lib().motifs_ctx_set_workspace_limit(self._h, int(nbytes)))
+
+    def set_records_in_stream_order(self, on=True):
+        """pwm_scan_hits_both_dev returns once the totals are known; the records are complete in stream order (see the header)."""
+        check(lib().motifs_ctx_set_records_in_stream_order(self._h, int(bool(on))))
 
     def synchronize(self):
         check(lib().motifs_ctx_synchronize(self._h))

@@ -95,6 +95,9 @@ struct motifs_ctx {
     int32_t scan_plan[4] = {0, 0, 0, 0};   // motifs_ctx_scan_plan
     bool pair_launches = true;      // both strands in one launch of stage_hits / row scans / emit_records too (MOTIFS_NO_PAIR_LAUNCHES=1: per strand)
     bool fuse_strands = true;       // MOTIFS_NO_STRAND_FUSION=1: one candidate launch per strand
+    bool records_async = false;     // motifs_ctx_set_records_in_stream_order: the both-strands scan returns once the totals are on the host
+    hipEvent_t ev_totals = nullptr; // ... recorded behind the row scans of that call
+    bool ev_totals_set = false;     // (this call recorded it)
     motifs::BankSlot bank_slot[2];  // [rc]
     void* pinned = nullptr;  // small pinned host block for totals / flags
     // pinned staging of the host-buffer entries (motifs_pwm_scan*): code rows on the way up, record chunks on the way down

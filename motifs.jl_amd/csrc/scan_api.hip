@@ -583,6 +583,10 @@ static int scan_hits_pair(motifs_ctx* c, BankSlot* const bs[2], int K, const uin
         KernelTimer t(c, KS_SCAN_OFFSETS);
         MOTIFS_HIP_CHECK(launch_stage_hits(f[0], emit ? 1 : 0, c->stream, &f[1]));
         MOTIFS_HIP_CHECK(launch_row_scan(f[0], c->stream, &f[1]));
+        if (c->records_async && c->ev_totals) {          // the totals are in pinned host memory once this is reached
+            MOTIFS_HIP_CHECK(hipEventRecord(c->ev_totals, c->stream));
+            c->ev_totals_set = true;
+        }
     }
     if (emit) {
         KernelTimer t(c, KS_SCAN_FILL);
@@ -655,6 +659,7 @@ void motifs_ctx_destroy(motifs_ctx* c) {
     if (c->pin_stage) (void)hipHostFree(c->pin_stage);
     resolve_timing(c);
     for (hipEvent_t e : c->free_events) (void)hipEventDestroy(e);
+    if (c->ev_totals) (void)hipEventDestroy(c->ev_totals);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -690,6 +695,14 @@ int motifs_ctx_get_stream(motifs_ctx* c, void** hip_stream_out) {
     return MOTIFS_OK;
 }
 
+int motifs_ctx_set_records_in_stream_order(motifs_ctx* c, int on) {
+    if (!c) return MOTIFS_ERR_INVALID;
+    MOTIFS_HIP_CHECK(hipSetDevice(c->device));
+    if (on && !c->ev_totals) MOTIFS_HIP_CHECK(hipEventCreateWithFlags(&c->ev_totals, hipEventDisableTiming));
+    c->records_async = on != 0;
+    return MOTIFS_OK;
+}
+
 int motifs_ctx_set_workspace_limit(motifs_ctx* c, size_t bytes) {
     if (!c) return MOTIFS_ERR_INVALID;
     c->ws_limit = bytes ? bytes : (size_t)8 << 30;
@@ -705,6 +718,14 @@ int motifs_ctx_synchronize(motifs_ctx* c) {
 int motifs_ctx_enable_timing(motifs_ctx* c, int on) {
     if (!c) return MOTIFS_ERR_INVALID;
     c->timing = on == 0 ? 0u : (on & 1) ? 0xffffffffu : ((uint32_t)on >> 1);
+    // events for the launches to come are made now: a timed launch that found the pool empty paid two hipEventCreate (~10 us of host
+    // time per step of bench.py's timed region, whose launches are all stamped before any is resolved)
+    if (c->timing && hipSetDevice(c->device) == hipSuccess)
+        while (c->free_events.size() < 128) {
+            hipEvent_t e = nullptr;
+            if (hipEventCreate(&e) != hipSuccess) break;
+            c->free_events.push_back(e);
+        }
     return MOTIFS_OK;
 }
 
@@ -1046,6 +1067,7 @@ int motifs_pwm_scan_hits_both_dev(motifs_ctx* c, const uint16_t* pwms_fp16, cons
         return MOTIFS_OK;
     }
     MOTIFS_HIP_CHECK(hipSetDevice(c->device));
+    c->ev_totals_set = false;
     if (per_pwm_counts2_dev) MOTIFS_HIP_CHECK(hipMemsetAsync(per_pwm_counts2_dev, 0, (size_t)2 * K * 8, c->stream));
     // One candidate launch for both strands when the four-reads kernel with compact entries serves both banks and the shard is one
     // super-batch: the reverse bank then goes over the reads the forward bank's waves have already staged (scan_mfma.hip).
@@ -1076,7 +1098,12 @@ int motifs_pwm_scan_hits_both_dev(motifs_ctx* c, const uint16_t* pwms_fp16, cons
                                          fuse ? rc + 1 : 0, fuse ? bs[1] : nullptr);
         if (rcode) return rcode;
     }
-    MOTIFS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (c->ev_totals_set) {        // records in stream order: wait for the row scans only (scan_hits_pair recorded the event behind them)
+        c->ev_totals_set = false;
+        MOTIFS_HIP_CHECK(hipEventSynchronize(c->ev_totals));
+    } else {
+        MOTIFS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    }
     const int64_t* h_total = (const int64_t*)c->pinned;
     for (int rc = 0; rc < 2; rc++) {
         n_out2[rc] = h_total[rc];

@@ -322,3 +322,44 @@ def test_random_shapes_with_long_reads(torch_cuda, ctx, pkg, seed):
         oh, os_ = fast_oracle_hits(bank, lens, codes, rc, batch)
         assert np.array_equal(h, oh) and np.array_equal(s, os_), (N, L, K, lo, hi, batch)
         assert np.array_equal(counts, np.bincount(oh[:, 0] - 1, minlength=K))
+
+
+def test_records_in_stream_order(torch_cuda, pkg):
+    """motifs_ctx_set_records_in_stream_order: the both-strands call returns when the totals are known, the records follow in stream
+    order.  Two shards scanned back to back without a host wait in between, into their own buffers, then one synchronize: both record sets
+    are the CPU port's (the second call's kernels queue behind the first call's record writes and reuse its workspaces)."""
+    sy, lib, torch = pkg.synth, pkg._lib, torch_cuda
+    c = lib.Context(0)
+    c.set_records_in_stream_order(True)
+    try:
+        N, L, K = 6000, 120, 200
+        pwms, lens = sy.gen_pwm_bank(K, 9300, len_lo=12, len_hi=12, alpha=0.3)
+        bank = sy.pad_bank(pwms, lens)
+        shards = []
+        for i in range(2):
+            codes = sy.gen_codes(N, L, 9400 + i, n_plant=4, k=12)
+            raw = torch.from_numpy(codes).cuda()
+            dcodes = torch.zeros(lib.Context.codes_bytes(N, L), dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()
+            c.encode_dev(raw.data_ptr(), lib.DATA_CODES_U8, N, L, dcodes.data_ptr())
+            need = c.pwm_scan_hits_both_dev(bank, lens, dcodes.data_ptr(), N, L, None, None, 0)
+            cap = max(need) + 8
+            hits = [torch.zeros((cap, 3), dtype=torch.int32, device="cuda") for _ in range(2)]
+            scs = [torch.zeros(cap, dtype=torch.int16, device="cuda") for _ in range(2)]
+            shards.append((codes, dcodes, need, cap, hits, scs))
+        c.synchronize()
+        torch.cuda.synchronize()
+        got = []
+        for codes, dcodes, need, cap, hits, scs in shards:          # no wait between the two calls
+            got.append(c.pwm_scan_hits_both_dev(bank, lens, dcodes.data_ptr(), N, L, [t.data_ptr() for t in hits], [t.data_ptr() for t in scs], cap))
+        assert c.scan_plan()["launches"] == 1
+        c.synchronize()
+        for (codes, dcodes, need, cap, hits, scs), g in zip(shards, got):
+            assert g == need
+            for rc in (0, 1):
+                oh, os_ = fast_oracle_hits(bank, lens, codes, bool(rc), 5000)
+                assert len(oh) == g[rc] > 1000
+                assert np.array_equal(hits[rc][:g[rc]].cpu().numpy().astype(np.uint32), oh)
+                assert np.array_equal(scs[rc][:g[rc]].cpu().numpy().view(np.uint16), os_)
+    finally:
+        c.close()

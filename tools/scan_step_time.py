@@ -20,6 +20,12 @@ codes = sy.gen_codes(N, L, sy.SEED_BASE + 2, n_plant=5, k=PL)
 pwms, lens = sy.gen_pwm_bank(K, sy.SEED_BASE + 2, len_lo=PL, len_hi=PL, alpha=0.3)
 bank = sy.pad_bank(pwms, lens)
 ctx = lib.Context(0)
+if os.environ.get("ASYNC") == "1":        # the call returns once the totals are known (motifs_ctx_set_records_in_stream_order)
+    ctx.set_records_in_stream_order(True)
+if os.environ.get("WSTREAM") == "1":      # as bench.py: one ordinary stream for torch and the library
+    _ws = torch.cuda.Stream()
+    torch.cuda.set_stream(_ws)
+    ctx.set_stream(_ws.cuda_stream)
 raw = torch.from_numpy(codes).cuda()
 dcodes = torch.zeros(lib.Context.codes_bytes(N, L), dtype=torch.uint8, device="cuda")
 torch.cuda.synchronize()
@@ -29,13 +35,23 @@ n = max(need)
 hits = [torch.empty((n + 16, 3), dtype=torch.int32, device="cuda") for _ in range(2)]
 sc = [torch.empty(n + 16, dtype=torch.int16, device="cuda") for _ in range(2)]
 args = (bank, lens, dcodes.data_ptr(), N, L, [h.data_ptr() for h in hits], [s.data_ptr() for s in sc], n + 16)
+if os.environ.get("COUNTS") == "1":       # with the 2 x K hit histogram, as bench.py's step asks for it
+    counts = torch.zeros((2, K), dtype=torch.int64, device="cuda")
+    args = args + (0, lib.SCAN_BATCH, counts.data_ptr())
+if os.environ.get("TIMED") == "1":        # as bench.py's timed region: the candidate kernel's launches stamped with HIP events
+    ctx.enable_timing(slots=[lib.KS_SCAN_COUNT])
 for _ in range(30):
     ctx.pwm_scan_hits_both_dev(*args)
 ts = []
+ctx.synchronize()
+t_all = time.perf_counter()
 for _ in range(reps):
     t0 = time.perf_counter()
     ctx.pwm_scan_hits_both_dev(*args)
     ts.append(time.perf_counter() - t0)
+ctx.synchronize()
+t_all = (time.perf_counter() - t_all) / reps
+print("per step over the whole loop (synchronised at its end): %.4f ms" % (1e3 * t_all))
 ctx.enable_timing(slots=[lib.KS_SCAN_COUNT, lib.KS_SCAN_OFFSETS, lib.KS_SCAN_FILL])
 ctx.reset_timing()
 for _ in range(10):
