@@ -410,6 +410,36 @@ def test_step_sizes_take_different_kernels_and_agree(ctx, pkg, G):
         cdl.model.close()
 
 
+@pytest.mark.parametrize("G", [24, 64])
+def test_multi_mini_batch_launch_meets_the_float64_oracle(ctx, pkg, G):
+    """The launches bench.py's train leg times, against the float64 oracle DIRECTLY (tests/golden/make_model_cfg2_multi_golden.py:
+    384 reads = 64 mini-batches at the configs[1] shape on the state of model_cfg2.npz).  Default switches: at 24 mini-batches the
+    per-mini-batch sparse filter gradients (k_sp_wgrad_syn4 / _ana4 start at 21), at 64 the binary16 forms of the four GEMMs at their own
+    thresholds, k_zy_step2_bwd<8> and the large-step k_lin3.  Every mini-batch's loss and the summed gradient (train.jl:42-44, one
+    gradient per mini-batch; a launch returns their sum) at the tolerances of test_cfg2_golden."""
+    gm = np.load(os.path.join(HERE, "golden", "model_cfg2_multi.npz"))
+    gold = np.load(os.path.join(HERE, "golden", "model_cfg2.npz"))
+    assert G in (int(gm["g_mid"]), len(gm["losses"]))
+    hp = mo.Hyperparam(filter_len=12, M=200)
+    L = 200
+    cdl_o = mo.UCDL(hp, np.random.default_rng(0)).to(torch.float64)
+    for n in mo.PARAM_VECS + ["D", "F"]:
+        setattr(cdl_o, n, torch.tensor(gold["init_" + n].astype(np.float64)))
+    cdl_o.lambda_sparsity_warmup, cdl_o.lambda_stepsize_warmup, cdl_o.omega_stepsize_warmup = [float(x) for x in gold["warm"]]
+    cdl = to_model(pkg, ctx, hp, L, cdl_o, arena=int((0.3 * G + 2) * (1 << 30)))
+    try:
+        codes = gm["codes"][: G * hp.batch_size]
+        loss, flat = gpu_loss_grad(pkg, ctx, cdl, codes, G)
+        want = gm["losses"][:G]
+        assert np.all(want < 190.0)
+        assert np.abs(loss.astype(np.float64) - want).max() <= LOSS_RTOL * want.max(), np.abs(loss - want).max() / want.max()
+        got = split_grad(cdl, flat)
+        for n in NAMES:
+            assert_grad(got[n], gm["grad%d_%s" % (G, n)].astype(np.float64), n)
+    finally:
+        cdl.model.close()
+
+
 def test_train_step_matches_adabelief_oracle(ctx, pkg):
     hp, codes, cdl_o = tiny(5, G=1)
     cdl = to_model(pkg, ctx, hp, codes.shape[1], cdl_o)
