@@ -221,6 +221,14 @@ def main():
         par.HostReducer(ctx).sum_i64_(tot_hits)
 
     kms = {"count": ctx.kernel_ms(lib.KS_SCAN_COUNT)}
+    # the library's DEFAULT mode for the same K steps (every call waits for its records, as all rounds before the fourth measured it)
+    ctx.set_records_in_stream_order(False)
+    for _ in range(args.warmup):
+        scan_step(weak)
+    dt_default, _ = timed_region(lambda: scan_step(weak), args.steps, sync, barrier)
+    if world > 1:
+        dt_default = float(par.host_all_reduce(torch.tensor([dt_default], dtype=torch.float64), dist.ReduceOp.MAX).item())
+    ctx.set_records_in_stream_order(True)
     ctx.enable_timing(slots=[lib.KS_SCAN_OFFSETS, lib.KS_SCAN_FILL])
     ctx.reset_timing()
     for _ in range(args.steps):
@@ -610,10 +618,26 @@ def main():
         if world > 1:
             tdt = float(par.host_all_reduce(torch.tensor([tdt], dtype=torch.float64), dist.ReduceOp.MAX).item())
         gms, gn = ctx.kernel_ms(lib.KS_TRAIN_STEP)
+        ista_ms, ista_n = ctx.kernel_ms(lib.KS_TRAIN_ISTA_BWD)      # event pairs around every launch of the step's largest kernel, inside the timed region
         # a4 on its own (SURVEY 8d "conv forward scan"): in L bytes of codes per read, out 2*c*M*4 bytes of dense codes
         a4_ms = cdl.model.time_filter_scan(tdev.data_ptr(), Gt, reps=10)
         c_rows = L - args.filter_len + 1
         a4_bytes = St * (L + 2 * c_rows * args.filters * 4)
+        # ... and on a launch large enough to show what the kernel can do (code retrieval runs it over all reads): 683 mini-batches = 4 098 reads
+        Gbig = 683
+        big_codes = sy.gen_codes(Gbig * hp.batch_size, L, seed + 78, n_plant=5, k=args.filter_len)
+        braw = torch.from_numpy(big_codes).to(dev)
+        bdev = torch.zeros(lib.Context.codes_bytes(Gbig * hp.batch_size, L), dtype=torch.uint8, device=dev)
+        ctx.encode_dev(braw.data_ptr(), lib.DATA_CODES_U8, Gbig * hp.batch_size, L, bdev.data_ptr())
+        a4_big_ms = cdl.model.time_filter_scan(bdev.data_ptr(), Gbig, reps=10)
+        a4_big_bytes = Gbig * hp.batch_size * (L + 2 * c_rows * args.filters * 4)
+        del braw, bdev
+        # a16 code retrieval (_1_code_retrieval.jl:33-56) as discover_motifs calls it: host codes in, host records out, mini-batches in file order
+        n_ret = min(N, 30_000)
+        cdl.model.retrieve_codes(codes[:n_ret], lib.DATA_CODES_U8, n_ret)
+        t0 = time.perf_counter()
+        ret_rec = cdl.model.retrieve_codes(codes[:n_ret], lib.DATA_CODES_U8, n_ret)
+        ret_dt = time.perf_counter() - t0
         # a7's dense contraction on its own ("MFMA fraction is computed on the syntax-layer GEMM flops", f32 matrix peak)
         a7_ms = cdl.model.time_syntax_conv(tdev.data_ptr(), Gt, reps=10)
         l_rows = c_rows - hp.h + 1
@@ -647,7 +671,9 @@ def main():
                         "note": "counter bytes of one step (2 x FETCH_SIZE + WRITE_SIZE over every kernel of the step) / the step time measured here"}
         train = {
             "workload": f"unrolled-ADMM sparse coding, {Gt} mini-batches x {hp.batch_size} reads x {L} bp per GPU per "
-                        f"optimiser step, {args.filters} filters len {args.filter_len}, h=12 K=24 q=32, 6+3 passes, f32",
+                        f"optimiser step, {args.filters} filters len {args.filter_len}, h=12 K=24 q=32, 6+3 passes; f32 storage and elementwise "
+                        "arithmetic, the four GEMMs of a large step as f16x3 matrix products (each float32 operand split into two binary16 numbers, three "
+                        "v_mfma_f32_32x32x16_f16 per term, f32 accumulation: 22 mantissa bits)",
             "ms_per_step": tdt / args.train_steps * 1e3,
             "seqs_per_s": St * world * args.train_steps / tdt,
             "bases_per_s": St * world * L * args.train_steps / tdt,
@@ -666,8 +692,14 @@ def main():
                 "bound": "hbm", "achieved": a4_bytes / (a4_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": a4_bytes / (a4_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_launch_ms": a4_ms, "algorithmic_bytes": a4_bytes,
                 "reads_per_launch": St, "bases_per_s": St * L / (a4_ms * 1e-3),
+                "at_4098_reads_per_launch": {"achieved": a4_big_bytes / (a4_big_ms * 1e-3) / 1e9, "frac": a4_big_bytes / (a4_big_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                             "avg_launch_ms": a4_big_ms, "algorithmic_bytes": a4_big_bytes, "reads_per_launch": Gbig * hp.batch_size},
             },
-            "roofline": (lambda f16x3: {
+            "code_retrieval": {"reads_per_s": n_ret / ret_dt, "reads": n_ret, "records": int(len(ret_rec)), "ms": ret_dt * 1e3,
+                               "entry": "motifs_model_retrieve_codes (a16, _1_code_retrieval.jl:33-56): host base codes in, host stored_code_component_t records out, "
+                                        "wall time of one call incl. upload, forward passes and download"},
+            "roofline": None,            # filled below: the kernel of the step that is largest by time
+            "syntax_gemm_a7": (lambda f16x3: {
                 "kernel": ("k_ana_f16x3 (a7: conv(ZY, F, flipped=true), model.jl:214,251, on v_mfma_f32_32x32x16_f16 with THREE products per term - every float32 operand "
                            "split into two binary16 numbers, 22 bits - + the pass that finds the image's largest magnitude; MOTIFS_ANA_F32=1: k_ana_lds on "
                            "v_mfma_f32_32x32x2_f32)") if f16x3 else
@@ -690,6 +722,27 @@ def main():
                       "bank) and ADMM_DF's residuals telescoped (R_1 = 0, R_t = -theta_{t-2}; identical values, "
                       "tests/test_model_gpu.py::test_df_telescoping_equals_literal_sequence); MOTIFS_DF_LITERAL=1 runs the literal "
                       "sequence"),
+        }
+        # the step's largest kernel by time (profiles/r04_train_kernels_pmc.json: 5 launches, 12 % of the step): the VJP of update_ZY's fused ISTA
+        # step.  Elementwise over the code images [reads][c][2M] f32: eight read (the two incoming gradients, the gradient of the combination formed
+        # after the step, the step's output, ZY, the D-layer gradient image, FX, the duals) and four written (gradients of ZY, g1, FX, duals); the first
+        # pass has no duals (ten streams), counted as twelve here, so `achieved` is an upper bound of at most 3 %
+        img_bytes = float(St) * c_rows * 2 * args.filters * 4
+        ista_launch_ms = ista_ms / max(ista_n, 1)
+        ista_traffic = None
+        if os.path.exists(TRAIN_PMC_FILE) and (Gt, L, args.filters, args.filter_len) == (64, 200, 200, 12):
+            with open(TRAIN_PMC_FILE) as fh:
+                for e in json.load(fh)["kernels"]:
+                    if e["kernel"].startswith("k_zy_step2_bwd"):
+                        ista_traffic = (e["hbm_read_bytes"] + e["hbm_write_bytes"]) / e["launches"]
+        train["roofline"] = {
+            "kernel": "k_zy_step2_bwd<8> (VJP of update_ZY's ISTA step relu(ZY - step (grad + penalty (ZY - FX - dual)) - step lambda), model.jl:237-245, with the "
+                      "VJP of the combination formed after it; elementwise over twelve image-sized streams, 32 bytes per lane and stream)",
+            "why_this_kernel": "largest kernel of the step by time", "share_of_step_time": ista_ms / args.train_steps / (tdt / args.train_steps * 1e3) if ista_n else None,
+            "bound": "hbm", "achieved": 12 * img_bytes / (ista_launch_ms * 1e-3) / 1e9 if ista_n else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": 12 * img_bytes / (ista_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ista_n else None,
+            "algorithmic_bytes_per_launch": 12 * img_bytes, "avg_launch_ms": ista_launch_ms, "launches_per_step": ista_n / max(args.train_steps, 1),
+            "traffic": ista_traffic, "timing": "HIP event pairs around each launch on the context's stream, inside the timed region (MOTIFS_KS_TRAIN_ISTA_BWD)",
         }
         cdl.model.close()
 
@@ -752,6 +805,10 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": strong["ms_per_step"] if world > 1 else dt / args.steps * 1e3,
+        "ms_per_step_default_mode": dt_default / args.steps * 1e3,
+        "ms_per_step_default_mode_note": "the same shard and step count with motifs_ctx_set_records_in_stream_order off (the library default: every call returns "
+                                         "with its records written); `ms_per_step` / `value` are measured with it on (config.records_in_stream_order); at N > 1 this "
+                                         "is the weak-scaling shard, not the configs[2] split",
         "cold_start_ms_per_step": sum(cold) / len(cold),
         "cold_start_ms_each": cold,
         "higher_is_better": True,
@@ -898,6 +955,7 @@ def main():
         out["train"] = tr
         out["train_ms_per_step"] = tr["ms_per_step"]
         out["train_ms_per_step_g1"] = tr["ms_per_step_g1"]
+        out["code_retrieval_reads_per_s"] = tr["code_retrieval"]["reads_per_s"]
     if "dense_kernel" in out:
         out["dense_frac"] = out["dense_kernel"]["frac"]
     out["cfg3_shard_ms"] = out.get("cfg3_shard", {}).get("ms_per_step_both_strands")

@@ -98,7 +98,9 @@ int motifs_ctx_set_workspace_limit(motifs_ctx* ctx, size_t bytes);
  * the row scans have run - while the kernel that writes the records may still be running: hits / scores are complete for
  * everything queued on the context's stream afterwards and after motifs_ctx_synchronize, as a hipMemcpyAsync's destination is.
  * A host loop over many shards then prepares its next call under the record writes instead of after them (the single-launch
- * plan only: a scan that needs several super-batches still returns when all of it is done). */
+ * plan only: a scan that needs several super-batches or runs in chunk groups still returns when all of it is done).
+ * MOTIFS_ERR_BUFFER_TOO_SMALL is returned only after the stream has drained (the first `cap` records of each strand are written,
+ * nothing past `cap` is touched), so the caller may release or re-allocate hits / scores at once. */
 int motifs_ctx_set_records_in_stream_order(motifs_ctx* ctx, int on);
 /* Per-kernel device time, measured with HIP events on the context stream
  * around every launch of that kernel (each timed launch synchronises, so leave
@@ -110,7 +112,9 @@ enum motifs_kernel_slot {
     MOTIFS_KS_SCAN_COUNT = 2,   /* scan_kernel<LEN,MASK>: all windows, `> 0` test, 128-bit hit masks */
     MOTIFS_KS_SCAN_OFFSETS = 3, /* fill_row_sums + fill_row_scan: record offsets                   */
     MOTIFS_KS_SCAN_FILL = 4,    /* fill_records: (m, n, l) + fp16 score per set mask bit           */
-    MOTIFS_KS_TRAIN_STEP = 5    /* the whole forward/backward graph of motifs_model_loss_grad_dev  */
+    MOTIFS_KS_TRAIN_STEP = 5,   /* the whole forward/backward graph of motifs_model_loss_grad_dev  */
+    MOTIFS_KS_TRAIN_ISTA_BWD = 6 /* k_zy_step2_bwd, the VJP of update_ZY's fused ISTA step (model.jl:237-245): the largest kernel
+                                  * by time of a many-mini-batch step; stamped only on steps that run outside a captured graph */
 };
 /* on = 0: off; 1: every slot; otherwise a set of slots, (1 << (slot + 1)) or-ed together (an event pair costs a few
  * microseconds of stream time per timed section: time only what is being reported). */

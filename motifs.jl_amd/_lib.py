@@ -16,7 +16,7 @@ OK, ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_BUFFER_TOO_SMALL, ERR_NOT_ONEHOT, E
 ABI_VERSION = 3
 COMM_ID_BYTES = 128
 DATA_CODES_U8, DATA_ONEHOT_F32, DATA_ONEHOT_F16 = 0, 1, 2
-KS_ENCODE, KS_SCAN_DENSE, KS_SCAN_COUNT, KS_SCAN_OFFSETS, KS_SCAN_FILL, KS_TRAIN_STEP = range(6)
+KS_ENCODE, KS_SCAN_DENSE, KS_SCAN_COUNT, KS_SCAN_OFFSETS, KS_SCAN_FILL, KS_TRAIN_STEP, KS_TRAIN_ISTA_BWD = range(7)
 SCAN_BATCH = 5000
 SCAN_MAX_LEN = 64
 

@@ -59,6 +59,7 @@ enum KernelSlot {
     KS_SCAN_OFFSETS = 3,
     KS_SCAN_FILL = 4,
     KS_TRAIN_STEP = 5,
+    KS_TRAIN_ISTA_BWD = 6,
     KS_COUNT_
 };
 

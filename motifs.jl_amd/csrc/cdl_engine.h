@@ -113,6 +113,13 @@ struct Engine {
     size_t zleft = 0;
     std::map<std::string, Tensor> named;
     bool keep_named = false;
+    // measurement hook (bench.py train.roofline): when set, an event pair is recorded around every launch of the step's largest kernel
+    // (k_zy_step2_bwd); the owner of the probe hands out the events and collects the pairs
+    struct Probe {
+        std::function<hipEvent_t()> get;
+        std::vector<std::pair<hipEvent_t, hipEvent_t>> pairs;
+    };
+    Probe* probe = nullptr;
 
     ~Engine() { reset(); }
     void reset();                  // drop every node and the tape, rewind the arena

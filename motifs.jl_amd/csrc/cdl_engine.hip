@@ -983,6 +983,11 @@ std::pair<Tensor, Tensor> Engine::zy_step2(Tensor ZY, Tensor g1, Tensor FX, Tens
             const bool v4 = (per & 3) == 0 && al16(out->g) && al16(abn->g) && al16(g3) && al16(out->v) && al16(ZY->v) && al16(g1->v) &&
                             al16(FX->v) && al16(abp ? abp->v : nullptr) && al16(d0) && al16(d1) && al16(d2) && al16(d3);
             // 32 bytes per lane and stream where the image allows it and the step is large (twelve streams per thread: 276 -> 267 us at 64 mini-batches)
+            hipEvent_t pe0 = nullptr, pe1 = nullptr;
+            if (probe) {
+                pe0 = probe->get(), pe1 = probe->get();
+                (void)hipEventRecord(pe0, st);
+            }
             if (v4 && (per & 7) == 0 && out->n >= ((size_t)8 << 20))
                 hipLaunchKernelGGL(k_zy_step2_bwd<8>, dim3(nblocks(per / 8, 256 * 4, std::max<size_t>(2048 / G, 1)), G), dim3(256), 0, st, out->g, abn->g,
                                    g3, out->fl_b, g3 ? out->fl_thr : nullptr, out->v, ZY->v, g1->v, FX->v, abp ? abp->v : nullptr, pen->v, lst->v,
@@ -995,6 +1000,10 @@ std::pair<Tensor, Tensor> Engine::zy_step2(Tensor ZY, Tensor g1, Tensor FX, Tens
                 hipLaunchKernelGGL(k_zy_step2_bwd<1>, dim3(nblocks(per, 256 * 16, std::max<size_t>(2048 / G, 1)), G), dim3(256), 0, st, out->g, abn->g, g3,
                                    out->fl_b, g3 ? out->fl_thr : nullptr, out->v, ZY->v, g1->v, FX->v, abp ? abp->v : nullptr, pen->v, lst->v,
                                    ls->v, per, d0, a0, d1, a1, d2, a2, d3, a3, dp, ds, dl);
+            if (probe) {
+                (void)hipEventRecord(pe1, st);
+                probe->pairs.push_back({pe0, pe1});
+            }
         });
     return {out, abn};
 }

@@ -576,8 +576,18 @@ int motifs_model_loss_grad_dev(motifs_model* m, const uint8_t* codes_dev, int n_
     // own stream later replays returned the loss of a half-updated buffer whenever the reads behind the same pointers had
     // changed, and on HIP's legacy null stream gradients of ~1e28 (tests/test_model_gpu.py::
     // test_replayed_steps_follow_the_reads, tests/test_round3_gpu.py::test_step_graph_on_the_null_stream).
-    if (!m->use_graphs || keep_intermediates || n_groups > m->graph_max_groups)
-        return enqueue_loss_grad(m, m->ctx->stream, codes_dev, n_groups, loss_dev, grad_flat_dev, keep_intermediates);
+    if (!m->use_graphs || keep_intermediates || n_groups > m->graph_max_groups) {
+        Engine::Probe probe;
+        if ((m->ctx->timing >> KS_TRAIN_ISTA_BWD) & 1u) {
+            motifs_ctx* c = m->ctx;
+            probe.get = [c]() { return KernelTimer::get(c); };
+            m->eng.probe = &probe;
+        }
+        const int rc = enqueue_loss_grad(m, m->ctx->stream, codes_dev, n_groups, loss_dev, grad_flat_dev, keep_intermediates);
+        m->eng.probe = nullptr;
+        for (auto& pr : probe.pairs) m->ctx->pending.push_back({KS_TRAIN_ISTA_BWD, pr.first, pr.second});
+        return rc;
+    }
     motifs_model::StepGraph* sg = nullptr;
     for (auto& g : m->step_graphs)
         if (g.n_groups == n_groups && g.codes == codes_dev && g.loss == loss_dev && g.grad == grad_flat_dev) sg = &g;

@@ -60,6 +60,7 @@ __global__ __launch_bounds__(256) void k_minmax_lds(const HitRec* hits, const ui
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const uint32_t m = m4[u], k = hkey(s4[u]);
+            if (m >= (uint32_t)K) continue;                         // a record of another bank: no counter in this block's LDS
             if (k < sb[m]) atomicMin(&sb[m], k);
             if (k > sb[K + m]) atomicMax(&sb[K + m], k);
         }
@@ -115,6 +116,7 @@ __global__ __launch_bounds__(1024) void k_thr_hist_lds(const HitRec* hits, const
             const int64_t i = i0 + u * stride;
             m4[u] = i < n ? hits[i].m - 1 : 0u;
             s4[u] = i < n ? scores[i] : (uint16_t)0xfc00u;        // -Inf: below every threshold, counted nowhere
+            if (m4[u] >= (uint32_t)K) m4[u] = 0u, s4[u] = (uint16_t)0xfc00u;    // a record of another bank: counted nowhere
         }
         // thresholds strictly below the score, by steps of falling powers of two: the same trips for every record, so the four searches
         // interleave (a while (lo < hi) per record ran them one after the other)
@@ -247,7 +249,7 @@ __global__ __launch_bounds__(256) void k_count_mats(const HitRec* hits, int64_t 
 // dword would have held lies past the window.  28 M records of a configs[1] strand: 0.84 ms with the byte loads, 0.24 now; by blocks
 // (one LDS copy of the matrices each, flushed with one global atomic per non-zero counter): 2 048: 0.27, 1 024: 0.24, 512: 0.34 ms.
 template <int NW>
-__global__ __launch_bounds__(1024) void k_count_mats_w(const HitRec* hits, int64_t n, const uint8_t* codes, int pitch, int64_t n0,
+__global__ __launch_bounds__(256) void k_count_mats_w(const HitRec* hits, int64_t n, const uint8_t* codes, int pitch, int64_t n0,
                                                       const int32_t* lens, int K, int maxlen, int comp, unsigned int* counts) {
     extern __shared__ unsigned int lh[];
     const int bins = K * maxlen * 4;
@@ -256,7 +258,9 @@ __global__ __launch_bounds__(1024) void k_count_mats_w(const HitRec* hits, int64
     const int dmax = pitch / 4 - 1;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const HitRec h = hits[i];
-        const int m = (int)h.m - 1, len = lens[m], off = (int)h.l - 1;
+        const int m = (int)h.m - 1, off = (int)h.l - 1;
+        if ((unsigned)m >= (unsigned)K) continue;                   // a record of another bank: no matrix in this block's LDS
+        const int len = lens[m];
         const uint32_t* rw = (const uint32_t*)(codes + ((int64_t)h.n - 1 - n0) * pitch);
         const int d0 = off >> 2;
         const uint32_t sh = (uint32_t)(off & 3) * 8u;
@@ -385,7 +389,7 @@ int motifs_hits_count_matrices_dev(motifs_ctx* c, const motifs_hit* hits_dev, in
     const size_t bins = (size_t)K * maxlen * 4;
     const int use_lds = bins * 4 <= 48 * 1024;
     if (use_lds && maxlen <= 28 && ((uintptr_t)codes_dev & 3) == 0) {
-        static const int nblk = getenv("MOTIFS_COUNT_MATS_BLOCKS") ? atoi(getenv("MOTIFS_COUNT_MATS_BLOCKS")) : 1024;
+        const int nblk = 1024;           // (2 048 blocks: 0.27 ms, 1 024: 0.24, 512: 0.34 per 28 M records)
         const int cbt = 256;             // (512- and 1 024-thread blocks, 256-768 of them: 0.21-0.26 ms - the pass is bound by its LDS atomics)
         const dim3 grid((unsigned)std::min<int64_t>((n + cbt - 1) / cbt, std::max(nblk, 1)));
         const int pitch = motifs_codes_pitch(L);

@@ -385,7 +385,10 @@ struct HitGeom {
     size_t per_batch, stage_per_batch;
     int64_t nb_max;            // ordering batches per launch
 };
-static HitGeom hit_geom(const motifs_ctx* c, const BankSlot& bank, int K, int Lout, int batch, bool emit, int64_t N, bool two_strands = false) {
+// two_strands: 0 = a launch serves one strand; 1 = one candidate launch writes both strands' cells / entries, the later stages run per
+// strand and share one set of staged words (scan_hits_mfma's cand_mode); 2 = every stage serves both strands (scan_hits_pair: staged words,
+// row counts and offsets twice as well)
+static HitGeom hit_geom(const motifs_ctx* c, const BankSlot& bank, int K, int Lout, int batch, bool emit, int64_t N, int two_strands = 0) {
     HitGeom g{};
     g.compact = c->compact_cells && bank.uniform_eps && bank.lenp <= 20;
     g.cgc = (g.compact && c->cg_chunks != 0) ? stage_cg_chunks(K, bank.nch, bank.lenp, bank.tabk_stride, c->cg_chunks > 0 ? c->cg_chunks : 0) : 0;
@@ -397,7 +400,8 @@ static HitGeom hit_geom(const motifs_ctx* c, const BankSlot& bank, int K, int Lo
     // (chunk groups: + the per-read hit counts in front of every (row, group)'s slots, 16 bits per read)
     g.stage_per_batch = emit ? (size_t)Lout * g.parts * g.ncg * (g.row_slots + (g.cgc ? 256 / g.cgc : 0)) * 4 : 0;
     const size_t cand_bytes = g.per_batch + (g.compact ? g.per_batch / 4 : 0);
-    const size_t all = (two_strands ? 2 : 1) * cand_bytes + g.stage_per_batch;
+    const size_t rows_bytes = (size_t)Lout * g.parts * g.ncg * 8;            // row counts + exclusive offsets
+    const size_t all = (two_strands ? 2 : 1) * cand_bytes + (two_strands == 2 ? 2 : 1) * (g.stage_per_batch + rows_bytes);
     int64_t nb_max = (int64_t)(c->ws_limit / all);
     // compact entries: the kernels keep 32-bit BYTE offsets into the entry array (2 bytes per half cell = per_batch / 4 bytes per
     // batch), so a launch holds fewer than 2^31 entries
@@ -414,10 +418,6 @@ static HitGeom hit_geom(const motifs_ctx* c, const BankSlot& bank, int K, int Lo
     }
     return g;
 }
-// reads one launch of the matrix-core path takes under the workspace bound (whole ordering batches)
-static int64_t reads_per_launch(const motifs_ctx* c, const BankSlot& bank, int K, int Lout, int batch, bool emit, int64_t N, bool two_strands = false) {
-    return hit_geom(c, bank, K, Lout, batch, emit, N, two_strands).nb_max * batch;
-}
 
 // Hit records through the matrix cores: candidates (scan_cand_kernel) -> exact verification, staged hits and
 // row counts (stage_hits) -> scan -> records (emit_records); no host round trip in between.  The bank has already been uploaded (tab, lim).
@@ -430,7 +430,7 @@ static int scan_hits_mfma(motifs_ctx* c, const BankSlot& bank, int K, const uint
     // slot: which pair of running totals in c->small this strand uses; finish = false: everything is enqueued, the
     // total stays on the device at totals_of(slot) and the caller reads it after its own synchronisation
     const bool emit = hits_dev != nullptr && cap > 0;
-    const HitGeom hg = hit_geom(c, bank, K, Lout, batch, emit, N, cand_mode != 0);
+    const HitGeom hg = hit_geom(c, bank, K, Lout, batch, emit, N, cand_mode != 0 ? 1 : 0);
     const int rpr = hg.rpr;                                          // reads per row of cells
     const int parts = hg.parts;
     const int row_slots = hg.row_slots;                              // staged hits per row (and chunk group) before the slow path
@@ -536,7 +536,7 @@ static int scan_hits_mfma(motifs_ctx* c, const BankSlot& bank, int K, const uint
 static int scan_hits_pair(motifs_ctx* c, BankSlot* const bs[2], int K, const uint8_t* codes_dev, int64_t N, int L, int Lout, int64_t n0, int batch,
                           motifs_hit* const hits[2], uint16_t* const scores[2], int64_t cap, int64_t* counts2_dev) {
     const bool emit = hits[0] != nullptr && cap > 0;
-    const HitGeom hg = hit_geom(c, *bs[0], K, Lout, batch, emit, N, true);
+    const HitGeom hg = hit_geom(c, *bs[0], K, Lout, batch, emit, N, 2);
     const int64_t nb = (N + batch - 1) / batch;
     const int64_t rows = nb * Lout * hg.parts, nblk = (rows + 1023) / 1024;
     const size_t stage_words = (size_t)nb * hg.stage_per_batch / 4;
@@ -1072,7 +1072,7 @@ int motifs_pwm_scan_hits_both_dev(motifs_ctx* c, const uint16_t* pwms_fp16, cons
     // One candidate launch for both strands when the four-reads kernel with compact entries serves both banks and the shard is one
     // super-batch: the reverse bank then goes over the reads the forward bank's waves have already staged (scan_mfma.hip).
     bool fuse = c->compact_cells && c->fuse_strands;
-    bool pair_ok = true;
+    bool pair_ok = true, pair_fits = false;
     {
         const int Lout0 = L - bs[0]->minlen + 1;
         CandArgs a0{}, a1{};
@@ -1081,12 +1081,13 @@ int motifs_pwm_scan_hits_both_dev(motifs_ctx* c, const uint16_t* pwms_fp16, cons
         scan_args(c, *bs[0], K, codes_dev, N, L, Lout0, batch, rpr0, a0, f0);
         scan_args(c, *bs[1], K, codes_dev, N, L, Lout0, batch, rpr0, a1, f0);
         const bool emit = hits[0] != nullptr && cap > 0;
-        const HitGeom hg0 = hit_geom(c, *bs[0], K, Lout0, batch, emit, N, true);
+        const HitGeom hg0 = hit_geom(c, *bs[0], K, Lout0, batch, emit, N, 1);
+        pair_fits = hit_geom(c, *bs[0], K, Lout0, batch, emit, N, 2).nb_max * batch >= N;   // the pair launches hold both strands' staged words
         fuse = fuse && cand_two_strands_ok(a0) && cand_two_strands_ok(a1) && bs[0]->lenp == bs[1]->lenp && bs[0]->nch == bs[1]->nch &&
                hg0.compact && hg0.nb_max * batch >= N;
         pair_ok = hg0.cgc == 0;           // (chunk groups keep their launches per strand)
     }
-    if (fuse && pair_ok && c->pair_launches && bs[0]->minlen == bs[1]->minlen) {
+    if (fuse && pair_ok && pair_fits && c->pair_launches && bs[0]->minlen == bs[1]->minlen) {
         const int rcode = scan_hits_pair(c, bs, K, codes_dev, N, L, L - bs[0]->minlen + 1, n0, batch, hits, scores, cap, per_pwm_counts2_dev);
         if (rcode) return rcode;
     } else
@@ -1108,6 +1109,9 @@ int motifs_pwm_scan_hits_both_dev(motifs_ctx* c, const uint16_t* pwms_fp16, cons
     for (int rc = 0; rc < 2; rc++) {
         n_out2[rc] = h_total[rc];
         if (h_total[rc] > cap && !(cap == 0 && hits[rc] == nullptr)) {
+            // records in stream order: the kernel that writes the first `cap` records may still be running, and a caller that gets this
+            // error frees or re-allocates its buffers next - the error path waits for it
+            if (c->records_async) MOTIFS_HIP_CHECK(hipStreamSynchronize(c->stream));
             set_error("hit buffer too small: strand %d needs %lld records, cap %lld", rc, (long long)h_total[rc], (long long)cap);
             return MOTIFS_ERR_BUFFER_TOO_SMALL;
         }

@@ -187,12 +187,27 @@ def warmup_ZY(S, D, lambda_stepsize_warmup, lambda_sparsity_warmup, projs):    #
     return torch.relu(zm * Z_update), torch.relu(zm * Y_update)
 
 
+# The reference computes in Float32 (float_type, _0_const.jl:1): its two data-dependent selections - the q-th largest code of a read
+# (partialsort, :183-184) and the median of the non-zero ZY entries (Statistics.median = middle(a, b) = a/2 + b/2 for an even count,
+# :198-199) - are taken on Float32 values.  A float64 run of this file takes them on float64 values, and that is a different FUNCTION
+# wherever the two middle values are less than one Float32 ulp apart: a/2 + b/2 then rounds to a (ties to even) and `ZY .>= med` keeps
+# one entry more.  At BASELINE configs[1] (453 600 non-zero codes of a mini-batch inside [0, 1.5e-2]: neighbours ~0.6 ulp apart at the
+# median) that happens in about one mini-batch of six.  DECISIONS_F32 = True rounds the operands of the two selections to float32 first
+# (everything else stays in the run's dtype): float64 arithmetic on the function the Float32 reference evaluates.
+DECISIONS_F32 = False
+
+
+def _dec(x):
+    return x.float() if DECISIONS_F32 else x
+
+
 def generate_bitmat(X, hp):                                                    # :181-187
     with torch.no_grad():
         B = X.shape[0]
-        Xr = X.reshape(B, -1)                                                  # (l*K, B) columns
+        Xd = _dec(X)
+        Xr = Xd.reshape(B, -1)                                                 # (l*K, B) columns
         vals = torch.topk(Xr, hp.q, dim=1).values[:, hp.q - 1]                # partialsort(col, q, rev=true)
-        return (X >= vals.reshape(B, 1, 1, 1)).to(X.dtype)
+        return (Xd >= vals.reshape(B, 1, 1, 1)).to(X.dtype)
 
 
 def project_X(X, hp):                                                          # :189-192
@@ -210,11 +225,12 @@ def julia_median(v):
 
 def create_ZY_mask(ZY):                                                        # :194-204
     with torch.no_grad():
-        Z_nz = ZY[ZY > 0]
+        ZYd = _dec(ZY)
+        Z_nz = ZYd[ZYd > 0]
         if Z_nz.numel() == 0:
             return None
         med = julia_median(Z_nz)
-        return (ZY >= med).to(ZY.dtype)
+        return (ZYd >= med).to(ZY.dtype)
 
 
 def cat_ZY(Z, Y, hp, ln):                                                      # :206-210

@@ -410,32 +410,52 @@ def test_step_sizes_take_different_kernels_and_agree(ctx, pkg, G):
         cdl.model.close()
 
 
-@pytest.mark.parametrize("G", [24, 64])
-def test_multi_mini_batch_launch_meets_the_float64_oracle(ctx, pkg, G):
-    """The launches bench.py's train leg times, against the float64 oracle DIRECTLY (tests/golden/make_model_cfg2_multi_golden.py:
-    384 reads = 64 mini-batches at the configs[1] shape on the state of model_cfg2.npz).  Default switches: at 24 mini-batches the
-    per-mini-batch sparse filter gradients (k_sp_wgrad_syn4 / _ana4 start at 21), at 64 the binary16 forms of the four GEMMs at their own
-    thresholds, k_zy_step2_bwd<8> and the large-step k_lin3.  Every mini-batch's loss and the summed gradient (train.jl:42-44, one
-    gradient per mini-batch; a launch returns their sum) at the tolerances of test_cfg2_golden."""
+def multi_golden_state():
+    """The state and reads of tests/golden/model_cfg2_multi.npz (model_cfg2.npz's state: every code alive)."""
     gm = np.load(os.path.join(HERE, "golden", "model_cfg2_multi.npz"))
     gold = np.load(os.path.join(HERE, "golden", "model_cfg2.npz"))
-    assert G in (int(gm["g_mid"]), len(gm["losses"]))
     hp = mo.Hyperparam(filter_len=12, M=200)
-    L = 200
     cdl_o = mo.UCDL(hp, np.random.default_rng(0)).to(torch.float64)
     for n in mo.PARAM_VECS + ["D", "F"]:
         setattr(cdl_o, n, torch.tensor(gold["init_" + n].astype(np.float64)))
     cdl_o.lambda_sparsity_warmup, cdl_o.lambda_stepsize_warmup, cdl_o.omega_stepsize_warmup = [float(x) for x in gold["warm"]]
-    cdl = to_model(pkg, ctx, hp, L, cdl_o, arena=int((0.3 * G + 2) * (1 << 30)))
+    return gm, hp, cdl_o
+
+
+F_TIE_ENTRIES = 64     # entries of the F gradient (of 115 200) a launch may have outside GRAD_INF: medians within rounding noise of a one-ulp gap
+F_TIE_INF = 5e-3       # ... and how far outside (|got - want|_inf / |want|_inf); one such median moved 1-9 entries by up to 1.7e-3
+
+
+@pytest.mark.parametrize("G", [24, 64])
+def test_multi_mini_batch_launch_meets_the_float64_oracle(ctx, pkg, G):
+    """The launches bench.py's train leg times, against the float64 oracle DIRECTLY (tests/golden/make_model_cfg2_multi_golden.py:
+    384 reads = 64 mini-batches at the configs[1] shape on the state of model_cfg2.npz).  Default switches: at 24 mini-batches the
+    four-column sparse filter gradients (k_sp_wgrad_syn4 / _ana4 start at 21), at 64 the binary16 forms of the four GEMMs at their own
+    thresholds, k_zy_step2_bwd<8> and the large-step k_lin3.  Every mini-batch's loss and the summed gradient (train.jl:42-44, one
+    gradient per mini-batch; a launch returns their sum) at the tolerances of test_cfg2_golden - with ONE allowance, for the F
+    gradient: the median of create_ZY_mask (model.jl:198-199) is a Float32 `a/2 + b/2` of two of 453 600 values that are less than
+    one ulp apart in a sixth of the mini-batches, and whether a float32 run sees them as the same, adjacent or two floats apart is
+    rounding noise (the golden takes the selections on float32-rounded float64 values; the generator's header has the mechanism).
+    A median decided the other way moves a handful of entries of one filter's F gradient by up to 1.7e-3 of the largest entry and
+    nothing else above 1e-6: at most F_TIE_ENTRIES entries of F may sit outside GRAD_INF, none further than F_TIE_INF."""
+    gm, hp, cdl_o = multi_golden_state()
+    assert G in (int(gm["g_mid"]), len(gm["losses"]))
+    cdl = to_model(pkg, ctx, hp, 200, cdl_o, arena=int((0.3 * G + 2) * (1 << 30)))
     try:
         codes = gm["codes"][: G * hp.batch_size]
         loss, flat = gpu_loss_grad(pkg, ctx, cdl, codes, G)
         want = gm["losses"][:G]
-        assert np.all(want < 190.0)
+        assert np.all(want < 190.0), "the codes died: this test would compare zeros"
         assert np.abs(loss.astype(np.float64) - want).max() <= LOSS_RTOL * want.max(), np.abs(loss - want).max() / want.max()
         got = split_grad(cdl, flat)
         for n in NAMES:
-            assert_grad(got[n], gm["grad%d_%s" % (G, n)].astype(np.float64), n)
+            w = gm["grad%d_%s" % (G, n)].astype(np.float64)
+            if n != "F":
+                assert_grad(got[n], w, n)
+                continue
+            e = np.abs(got[n].astype(np.float64) - w.ravel()) / np.abs(w).max()
+            assert int((e > GRAD_INF).sum()) <= F_TIE_ENTRIES and e.max() <= F_TIE_INF, (int((e > GRAD_INF).sum()), e.max())
+            assert np.quantile(e, 0.999) <= GRAD_INF / 2, np.quantile(e, 0.999)
     finally:
         cdl.model.close()
 

@@ -168,6 +168,31 @@ def test_median_and_topq_semantics():
     assert mo.generate_bitmat(X, hp).flatten().tolist() == [1, 0, 1, 1, 0]   # ties with the q-th value are kept (>=)
 
 
+def test_float32_decisions_mode():
+    """DECISIONS_F32: the median mask decided on float32-rounded values, as the Float32 reference decides it (model.jl:198-199,
+    Statistics.middle(a, b) = a/2 + b/2).  Two middle values one float32 ulp apart: in float32 their mean rounds to the lower one
+    (ties to even), which the mask then keeps; in float64 the mean lies strictly between.  Values well apart: both modes agree."""
+    a = np.float32(1.6663759e-4)
+    a = a if (a.view(np.uint32) & 1) == 0 else np.nextafter(a, np.float32(1))     # even mantissa: the tie rounds to a
+    b = np.nextafter(a, np.float32(1))
+    ZY = torch.tensor([[0.0, float(a) / 4, float(a), float(b), float(b) * 3]], dtype=torch.float64)
+    try:
+        mo.DECISIONS_F32 = False
+        assert mo.create_ZY_mask(ZY).tolist() == [[0.0, 0.0, 0.0, 1.0, 1.0]]
+        mo.DECISIONS_F32 = True
+        assert mo.create_ZY_mask(ZY).tolist() == [[0.0, 0.0, 1.0, 1.0, 1.0]]
+        far = torch.tensor([[0.0, 0.1, 0.2, 0.4, 0.8]], dtype=torch.float64)
+        m32 = mo.create_ZY_mask(far)
+        X = torch.rand((2, 4, 1, 9), dtype=torch.float64)
+        hp = mo.Hyperparam(filter_len=4, M=5, h=3, K=4, q=6, batch_size=2)
+        b32 = mo.generate_bitmat(X, hp)
+        mo.DECISIONS_F32 = False
+        assert torch.equal(m32, mo.create_ZY_mask(far)) and torch.equal(b32, mo.generate_bitmat(X, hp))
+        assert m32.dtype == torch.float64 and b32.dtype == torch.float64
+    finally:
+        mo.DECISIONS_F32 = False
+
+
 def test_gradients_against_finite_differences():
     hp, codes, cdl, ln, projs = tiny(7)
     val, grads = mo.loss_and_grads(codes, cdl, hp, DT)

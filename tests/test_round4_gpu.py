@@ -363,3 +363,85 @@ def test_records_in_stream_order(torch_cuda, pkg):
                 assert np.array_equal(scs[rc][:g[rc]].cpu().numpy().view(np.uint16), os_)
     finally:
         c.close()
+
+
+def test_stream_order_mode_with_a_short_buffer(torch_cuda, pkg):
+    """Records in stream order and a hit buffer that is too small: the call reports MOTIFS_ERR_BUFFER_TOO_SMALL with the needed counts only
+    after the stream has drained - the first `cap` records of each strand are the CPU port's, nothing past `cap` was written - so the
+    caller may free or re-allocate its buffers straight away (round-4 advisor)."""
+    sy, lib, torch = pkg.synth, pkg._lib, torch_cuda
+    c = lib.Context(0)
+    c.set_records_in_stream_order(True)
+    try:
+        N, L, K = 6000, 120, 200
+        pwms, lens = sy.gen_pwm_bank(K, 9300, len_lo=12, len_hi=12, alpha=0.3)
+        bank = sy.pad_bank(pwms, lens)
+        codes = sy.gen_codes(N, L, 9411, n_plant=4, k=12)
+        raw = torch.from_numpy(codes).cuda()
+        dcodes = torch.zeros(lib.Context.codes_bytes(N, L), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        c.encode_dev(raw.data_ptr(), lib.DATA_CODES_U8, N, L, dcodes.data_ptr())
+        need = c.pwm_scan_hits_both_dev(bank, lens, dcodes.data_ptr(), N, L, None, None, 0)
+        cap = min(need) // 3
+        hits = [torch.full((cap + 64, 3), -1, dtype=torch.int32, device="cuda") for _ in range(2)]
+        scs = [torch.full((cap + 64,), -1, dtype=torch.int16, device="cuda") for _ in range(2)]
+        torch.cuda.synchronize()
+        with pytest.raises(lib.MotifsError) as ei:
+            c.pwm_scan_hits_both_dev(bank, lens, dcodes.data_ptr(), N, L, [t.data_ptr() for t in hits], [t.data_ptr() for t in scs], cap)
+        assert ei.value.code == lib.ERR_BUFFER_TOO_SMALL
+        # no synchronize here: the error path has waited
+        for rc in (0, 1):
+            oh, os_ = fast_oracle_hits(bank, lens, codes, bool(rc), 5000)
+            h, s_ = hits[rc].cpu().numpy(), scs[rc].cpu().numpy()
+            assert np.array_equal(h[:cap].astype(np.uint32), oh[:cap]) and np.array_equal(s_[:cap].view(np.uint16), os_[:cap])
+            assert np.all(h[cap:] == -1) and np.all(s_[cap:] == -1)
+    finally:
+        c.close()
+
+
+
+def test_workspace_limit_bounds_what_a_both_strands_scan_holds(torch_cuda, pkg):
+    """motifs_ctx_set_workspace_limit: what a fresh context allocates for a both-strands scan stays under the bound (+ the small fixed
+    buffers: bank, totals), also when every stage serves both strands in one launch - the pair plan holds staged words, row counts and
+    offsets twice, which the geometry now counts (round-4 advisor: it sized the launch for one set).  The limit is chosen so that the pair
+    plan just fits one super-batch; records as in the default plan."""
+    sy, lib, torch = pkg.synth, pkg._lib, torch_cuda
+    N, L, K = 20000, 200, 200
+    pwms, lens = sy.gen_pwm_bank(K, 9500, len_lo=12, len_hi=12, alpha=0.3)
+    bank = sy.pad_bank(pwms, lens)
+    codes = sy.gen_codes(N, L, 9501, n_plant=4, k=12)
+    raw = torch.from_numpy(codes).cuda()
+    dcodes = torch.zeros(lib.Context.codes_bytes(N, L), dtype=torch.uint8, device="cuda")
+    Lout, nch, batch = L - 12 + 1, 2, 5000
+    cells = Lout * batch * nch * 16
+    staged = Lout * ((batch + 255) // 256) * (2 * 256 * nch) * 4
+    rows = Lout * ((batch + 255) // 256) * 8
+    pair_per_batch = 2 * (cells + cells // 4) + 2 * (staged + rows)
+    ref = None
+    for limit, want_launches in ((0, 1), (4 * pair_per_batch, 1), (4 * pair_per_batch - (1 << 20), None)):
+        c = lib.Context(0)
+        try:
+            c.set_workspace_limit(limit)
+            torch.cuda.synchronize()
+            c.encode_dev(raw.data_ptr(), lib.DATA_CODES_U8, N, L, dcodes.data_ptr())
+            need = c.pwm_scan_hits_both_dev(bank, lens, dcodes.data_ptr(), N, L, None, None, 0)
+            cap = max(need) + 8
+            hits = [torch.zeros((cap, 3), dtype=torch.int32, device="cuda") for _ in range(2)]
+            scs = [torch.zeros(cap, dtype=torch.int16, device="cuda") for _ in range(2)]
+            torch.cuda.synchronize()
+            free0 = torch.cuda.mem_get_info()[0]
+            got = c.pwm_scan_hits_both_dev(bank, lens, dcodes.data_ptr(), N, L, [t.data_ptr() for t in hits], [t.data_ptr() for t in scs], cap)
+            c.synchronize()
+            held = free0 - torch.cuda.mem_get_info()[0]
+            if limit:
+                assert held <= limit + (8 << 20), (held, limit)
+            if want_launches is not None:
+                assert c.scan_plan()["launches"] == want_launches
+            rec = [(hits[rc][:got[rc]].cpu().numpy().copy(), scs[rc][:got[rc]].cpu().numpy().copy()) for rc in (0, 1)]
+            if ref is None:
+                ref = rec
+            else:
+                for rc in (0, 1):
+                    assert np.array_equal(rec[rc][0], ref[rc][0]) and np.array_equal(rec[rc][1], ref[rc][1])
+        finally:
+            c.close()
