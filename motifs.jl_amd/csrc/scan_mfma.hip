@@ -473,14 +473,28 @@ constexpr int ROW_CELLS_MAX = 512;
 // scoring different PWMs hit different LDS banks.  One weight = v_bfe (the base) + v_lshl_add (the address) +
 // ds_read_u16 + v_add_f16.
 // sequential binary16 sum of a PWM's row over the window whose raw code words are W (reference order, one rounding per add)
-template <int LEN>
+template <int LEN, bool LDS = false>
 static __device__ __forceinline__ uint16_t exact_score(const _Float16* row, const uint32_t (&W)[LEN / 4 + 1], int l) {
-    uint32_t al[LEN / 4];
-#pragma unroll
-    for (int j = 0; j < LEN / 4; j++) al[j] = __builtin_amdgcn_alignbyte(W[j + 1], W[j], (uint32_t)(l & 3));
     _Float16 t[LEN];
+    if constexpr (LDS) {
+        // table in LDS: the window's bytes are doubled once (codes are 0..4: no carry between bytes; before the byte alignment, so that the
+        // shift cannot be folded back into the extraction), and a position's address is the row's LDS byte address plus one byte of a
+        // register - ONE v_add_u32 with a byte-select operand (SDWA) where the generic form spends a v_bfe and a v_lshl_add
+        typedef const __attribute__((address_space(3))) _Float16* lds_half;
+        uint32_t al[LEN / 4];
 #pragma unroll
-    for (int ind = 0; ind < LEN; ind++) t[ind] = row[ind * 5 + ((al[ind / 4] >> (8 * (ind % 4))) & 0xffu)];
+        for (int j = 0; j < LEN / 4; j++) al[j] = __builtin_amdgcn_alignbyte(W[j + 1] << 1, W[j] << 1, (uint32_t)(l & 3));
+        const uint32_t rb = (uint32_t)(uintptr_t)row;                 // a generic pointer into LDS: its low word is the LDS address
+#pragma unroll
+        for (int ind = 0; ind < LEN; ind++)
+            t[ind] = *(lds_half)(uintptr_t)(rb + ((al[ind / 4] >> (8 * (ind % 4))) & 0xffu) + (uint32_t)(ind * 10));
+    } else {
+        uint32_t al[LEN / 4];
+#pragma unroll
+        for (int j = 0; j < LEN / 4; j++) al[j] = __builtin_amdgcn_alignbyte(W[j + 1], W[j], (uint32_t)(l & 3));
+#pragma unroll
+        for (int ind = 0; ind < LEN; ind++) t[ind] = row[ind * 5 + ((al[ind / 4] >> (8 * (ind % 4))) & 0xffu)];
+    }
     __builtin_amdgcn_sched_barrier(0);        // all LEN reads in flight before the dependent chain of adds starts
     _Float16 acc = t[0];
 #pragma unroll
@@ -792,7 +806,7 @@ static __device__ __forceinline__ void for_row_candidates_c(const FillArgs& a, c
 }
 
 // exact score of one candidate word of row g; false if the candidate is not a hit
-template <int LEN>
+template <int LEN, bool LDS = false>
 static __device__ __forceinline__ bool score_candidate(const FillArgs& a, const RowGeom& g, const _Float16* tb, uint32_t cw, bool live,
                                                        uint32_t& k, uint32_t& nin, uint16_t& sc) {
     const uint32_t idx = cw >> 7, q = (cw >> 5) & 3u, i = cw & 31u;
@@ -809,7 +823,7 @@ static __device__ __forceinline__ bool score_candidate(const FillArgs& a, const 
         const uint32_t* sw = (const uint32_t*)(g.codes + __umul24(nin, (uint32_t)a.pitch));
 #pragma unroll
         for (int j = 0; j <= LEN / 4; j++) W[j] = sw[j];
-        sc = exact_score<LEN>(tb + __umul24(k, (uint32_t)a.tabk_stride), W, g.l);
+        sc = exact_score<LEN, LDS>(tb + __umul24(k, (uint32_t)a.tabk_stride), W, g.l);
     }
     return half_pos(sc);
 }
@@ -873,7 +887,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW == 1
         auto on_cand = [&](const uint32_t cw, const bool live) {
             uint32_t k, nin;
             uint16_t sc;
-            bool hit = score_candidate<LEN>(a, g, tb, cw, live, k, nin, sc);
+            bool hit = score_candidate<LEN, LDS_TAB>(a, g, tb, cw, live, k, nin, sc);
             const unsigned long long hb = __ballot(hit);
             if (hit) {
                 if (MODE == 1) {
@@ -936,7 +950,7 @@ static __device__ __forceinline__ bool score_candidate_cg(const FillArgs& a, con
     const uint32_t* sw = (const uint32_t*)(g.codes + __umul24(nin, (uint32_t)a.pitch));
 #pragma unroll
     for (int j = 0; j <= LEN / 4; j++) W[j] = sw[j];
-    sc = exact_score<LEN>(tbl + __umul24(kl, (uint32_t)a.tabk_stride), W, g.l);
+    sc = exact_score<LEN, true>(tbl + __umul24(kl, (uint32_t)a.tabk_stride), W, g.l);
     return half_pos(sc);
 }
 
