@@ -407,7 +407,7 @@ def main():
         extras["dense_kernel"] = {
             "kernel": "scan_dense_fused<3,7,8> (a17 greedy_search! drop-in in one kernel: MFMA tiles of 32 consecutive reads at one start, candidates re-scored from LDS, "
                       "the contiguous 32 x K span streamed out of an LDS window: (K,nb,L-len+1) fp16, zeros + exact scores of the hits, every byte once; "
-                      "MOTIFS_DENSE_FUSED=0: scan_cand_kernel_q + stage_hits<12,.,2>)",
+                      "banks past 256 PWMs or 20 positions: scan_cand_kernel_q + stage_hits<12,.,2>)",
             "checked": "positive entries == hit records of the same reads, score checksums equal",
             "bound": "hbm", "achieved": dense_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": dense_gbs / HBM_PEAK_GBS, "frac_of_measured_fill": dense_gbs / hbm_fill_gbs,
@@ -701,7 +701,7 @@ def main():
             "roofline": None,            # filled below: the kernel of the step that is largest by time
             "syntax_gemm_a7": (lambda f16x3: {
                 "kernel": ("k_ana_f16x3 (a7: conv(ZY, F, flipped=true), model.jl:214,251, on v_mfma_f32_32x32x16_f16 with THREE products per term - every float32 operand "
-                           "split into two binary16 numbers, 22 bits - + the pass that finds the image's largest magnitude; MOTIFS_ANA_F32=1: k_ana_lds on "
+                           "split into two binary16 numbers, 22 bits - + the pass that finds the image's largest magnitude; MOTIFS_GEMM_F32=1: k_ana_lds on "
                            "v_mfma_f32_32x32x2_f32)") if f16x3 else
                           "k_ana_lds (a7: conv(ZY, F, flipped=true), model.jl:214,251, on v_mfma_f32_32x32x2_f32; rows = reads x l, columns = K, reduction = h * 2M)",
                 "bound": "mfma", "achieved": a7_flops / (a7_ms * 1e-3) / 1e12, "peak": MFMA_F16_PEAK_TFLOPS / 3.0 if f16x3 else MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -711,7 +711,7 @@ def main():
                 "note": "algorithmic flops 2 * l * K * h * 2M per read (SURVEY 8d; the kernel pads K 24 -> 32 and l 178 -> 192).  f16x3: the peak is the dense f16 "
                         "peak over the three matrix instructions a term costs; the kernel is no longer bound by the matrix pipe but by the filter fragments it "
                         "pulls from L2 (437 MB per launch at three row tiles per fragment) and the 171 MB image from HBM",
-            })(os.environ.get("MOTIFS_ANA_F32") is None and St * ((l_rows + 31) // 32) >= 1024 and (2 * args.filters) % 16 == 0 and hp.h == 12),
+            })(os.environ.get("MOTIFS_GEMM_F32") is None and St * ((l_rows + 31) // 32) >= 1024 and (2 * args.filters) % 16 == 0 and hp.h == 12),
             "step_hbm": step_hbm,
             "arena_peak_bytes": cdl.model.arena_peak(),
             "arena_peak_GiB_per_mini_batch": cdl.model.arena_peak() / Gt / 2**30,

@@ -87,15 +87,15 @@ struct motifs_ctx {
     motifs::DevBuf staging, rowx;   // matrix-core scan: staged hit words, per-row offsets
     motifs::DevBuf dp_scratch;      // host-buffer data-parallel step: flat gradient + losses
     motifs::DevBuf centries;        // matrix-core scan: compact 16-bit entries of the candidate cells (scan_mfma.hip)
-    bool compact_cells = true;      // MOTIFS_DENSE_CELLS=1 turns them off (the round-2 round trip through the 128-bit cells)
+    bool compact_cells = true;      // compact entries where the bank allows them (uniform slack, PWMs of up to 20 positions); 128-bit cells otherwise
     motifs::DevBuf cnt2, centries2; // the reverse strand's cells / entries when one candidate launch serves both strands of gpu_scan
     motifs::DevBuf cm_lens;         // motifs_hits_count_matrices_dev: the PWM lengths of the last call (uploaded again only when they change)
     std::vector<int32_t> cm_lens_host;
     int cg_chunks = -1;             // chunk groups of the re-scoring (scan_mfma.hip): -1 = when the table does not fit the LDS; MOTIFS_CG_CHUNKS overrides
-    bool dense_fused = true;        // a17's tensor in one kernel (scan_dense.hip); MOTIFS_DENSE_FUSED=0: candidate kernel + stage_hits<.., 2>
+    bool dense_fused = true;        // a17's tensor in one kernel (scan_dense.hip) where the bank fits it; candidate kernel + stage_hits<.., 2> otherwise
     int32_t scan_plan[4] = {0, 0, 0, 0};   // motifs_ctx_scan_plan
-    bool pair_launches = true;      // both strands in one launch of stage_hits / row scans / emit_records too (MOTIFS_NO_PAIR_LAUNCHES=1: per strand)
-    bool fuse_strands = true;       // MOTIFS_NO_STRAND_FUSION=1: one candidate launch per strand
+    bool pair_launches = true;      // both strands in one launch of stage_hits / row scans / emit_records too (per strand: chunk groups, several super-batches)
+    bool fuse_strands = true;       // one candidate launch for both strands where both banks take the four-reads kernel with compact entries
     bool records_async = false;     // motifs_ctx_set_records_in_stream_order: the both-strands scan returns once the totals are on the host
     hipEvent_t ev_totals = nullptr; // ... recorded behind the row scans of that call
     bool ev_totals_set = false;     // (this call recorded it)

@@ -8,6 +8,20 @@
 
 namespace motifs {
 
+// The four GEMMs of a step (syntax-layer analysis, the D-layer's tall / row forms, their filter gradients) run on the binary16 matrix
+// instruction with three products per term once a launch has enough tiles; two switches, read once per process, move that choice for tests
+// and A/B runs: MOTIFS_GEMM_F32 (set: the float32 matrix instruction for every launch) and MOTIFS_GEMM_F16_MIN=<n> (the bar of all four, in
+// jobs / tiles; 1: every launch takes the binary16 forms; defaults 256 / 768 / 768 / 512).
+static bool gemm_f32_only() {
+    static const bool v = getenv("MOTIFS_GEMM_F32") != nullptr;
+    return v;
+}
+static long gemm_f16_min(long dflt) {
+    static const char* s = getenv("MOTIFS_GEMM_F16_MIN");
+    return s ? atol(s) : dflt;
+}
+
+
 static inline unsigned nblocks(size_t n, int per = 256, size_t cap = 256 * 32) {
     size_t b = (n + per - 1) / per;
     if (b < 1) b = 1;
@@ -803,8 +817,7 @@ Tensor Engine::lin3(Tensor x, float a, Tensor y, float b, Tensor z, float c, con
     const int G = ythr ? groups : 1;
     const size_t per = x->n / G;
     const dim3 grid(nblocks(per, 256, std::max<size_t>(256 * 32 / G, 1)), G);
-    static const bool no_amax = getenv("MOTIFS_NO_LIN3_AMAX") != nullptr;     // A/B: k_absmax passes instead
-    uint32_t* am = out->n >= AMAX_MIN_N && !no_amax ? (uint32_t*)zeros(1) : nullptr;   // (images of small steps never reach the binary16 GEMM)
+    uint32_t* am = out->n >= AMAX_MIN_N ? (uint32_t*)zeros(1) : nullptr;   // (images of small steps never reach the binary16 GEMM)
     if (failed) return out;
     if (am) absmax_of[out->v] = am;
     hipLaunchKernelGGL(k_lin3, grid, dim3(256), 0, st, x->v, a, y->v, ythr, b, z ? z->v : nullptr, c, per, out->v, am);
@@ -2065,14 +2078,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }
 template <int H, int CC>
 static bool launch_ana_f16x3(Engine& e, const float* A, const float* Bm, float* C, const ToepGeom& gm, int acc) {
-    static const bool off = getenv("MOTIFS_ANA_F32") != nullptr;        // A/B: the float32 matrix instruction for every launch
+    const bool off = gemm_f32_only();        // A/B: the float32 matrix instruction for every launch
     if (off) return false;
     if (gm.sa <= 0 || gm.Q != H * gm.sa || gm.sa % CC != 0 || gm.N < 9 || gm.N > 32) return false;
     if (gm.a0 < 0 || (int64_t)gm.a0 + (int64_t)(gm.P - 1) * gm.sa + gm.Q > gm.amax) return false;
     if ((gm.sa & 15) || (gm.a0 & 3) || (gm.lda & 3) || (((uintptr_t)A) & 15)) return false;
-    // steps of few reads keep the float32 form (its split over channel chunks); MOTIFS_ANA_F16_MIN_JOBS lowers the bar (tests: the
+    // steps of few reads keep the float32 form (its split over channel chunks); MOTIFS_GEMM_F16_MIN lowers the bar (tests: the
     // one-mini-batch goldens through this kernel)
-    static const long min_jobs = getenv("MOTIFS_ANA_F16_MIN_JOBS") ? atol(getenv("MOTIFS_ANA_F16_MIN_JOBS")) : 256;      // measured: pays from 8 mini-batches (288 row tiles), costs 4-7 % at 1-4
+    const long min_jobs = gemm_f16_min(256);      // measured: pays from 8 mini-batches (288 row tiles), costs 4-7 % at 1-4
     if ((long)gm.S * ((gm.P + 31) / 32) < min_jobs) return false;
     const int gB = gm.ldb == 0 ? 1 : gm.S / gm.B;
     const size_t perf = (size_t)(gm.Q / 16) * 128;                        // uint4 per bank
@@ -2110,12 +2123,9 @@ static bool launch_ana_f16x3(Engine& e, const float* A, const float* Bm, float* 
         hipLaunchKernelGGL(kern, dim3((unsigned)((long)gm.S * tps)), dim3(256), lds, e.st, A, (const uint4*)Bf, C, gm, acc, tps,
                            (int64_t)(gm.ldb == 0 ? 0 : perf), am, bm);
     };
-    static const int want_nt = getenv("MOTIFS_ANA_NT") ? atoi(getenv("MOTIFS_ANA_NT")) : 0;
     // row tiles per wave: the fewest padded rows, then the most rows per fragment
     const int pad2 = (gm.P + 63) / 64 * 64, pad3 = (gm.P + 95) / 96 * 96;
-    const int nt = want_nt ? want_nt : (pad3 <= pad2 ? 3 : 2);
-    if (nt == 3) go(std::integral_constant<int, 3>{});
-    else if (nt == 1) go(std::integral_constant<int, 1>{});
+    if (pad3 <= pad2) go(std::integral_constant<int, 3>{});
     else go(std::integral_constant<int, 2>{});
     return true;
 }
@@ -2970,8 +2980,8 @@ __global__ __launch_bounds__(512) void k_rowgemm16(const float* __restrict__ A, 
 extern "C" int motifs_debug_rg16_ts(void* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rg16_ts), sizeof(g_rg16_ts)); }
 #endif
 static bool launch_rowgemm16(Engine& e, const float* A, const float* Bm, float* C, const ToepGeom& rg, int acc, int groups, long rpg, int tpg) {
-    static const bool f32_only = getenv("MOTIFS_ROWGEMM_F32") != nullptr || getenv("MOTIFS_ANA_F32") != nullptr;     // A/B: the float32 matrix instruction
-    static const long min_tiles = getenv("MOTIFS_ROWGEMM_F16_MIN_TILES") ? atol(getenv("MOTIFS_ROWGEMM_F16_MIN_TILES")) : 768;       // measured: -1 % at 576 tiles, +1 % at 864
+    const bool f32_only = gemm_f32_only();     // A/B: the float32 matrix instruction
+    const long min_tiles = gemm_f16_min(768);       // measured: -1 % at 576 tiles, +1 % at 864
     const long ntiles = (long)groups * tpg;
     if (f32_only || ntiles < min_tiles || ntiles > (1l << 30) || rpg > (1l << 30)) return false;
     const int KT = rg.Q / 16, NCT = (rg.N + 31) / 32;
@@ -3102,8 +3112,8 @@ static bool launch_toep_wide(Engine& e, const float* A, const float* Bm, float* 
     if (!Bf) return true;
     if (fresh) hipLaunchKernelGGL(k_frag_bw, dim3(nblocks(perf * gB)), dim3(256), 0, e.st, Bm, gB, gm.Q, gm.N, Bf);
     const int tps = (gm.P + 31) / 32;
-    static const bool f32_only = getenv("MOTIFS_TOEP_F32") != nullptr || getenv("MOTIFS_ANA_F32") != nullptr;   // A/B: the float32 matrix instruction
-    static const long min_jobs16 = getenv("MOTIFS_TOEP_F16_MIN_JOBS") ? atol(getenv("MOTIFS_TOEP_F16_MIN_JOBS")) : 768;   // (tests: 1; measured: -2 % at 576 jobs, +2 % at 864)
+    const bool f32_only = gemm_f32_only();   // A/B: the float32 matrix instruction
+    const long min_jobs16 = gemm_f16_min(768);   // (tests: 1; measured: -2 % at 576 jobs, +2 % at 864)
     const bool want16 = !f32_only && (long)gm.S * tps >= min_jobs16 && gm.Q % 16 == 0 && gm.sa > 0;
     const int cs = !want16 && (long)gm.S * tps < 256 ? std::min(4, NCT) : 1;      // few reads: four blocks per row tile, a wave per column tile
     const dim3 grid((unsigned)((long)gm.S * tps * cs));
@@ -3174,9 +3184,8 @@ static void launch_toep(Engine& e, const float* A, const float* Bm, float* C, co
         }
         if (fresh) hipLaunchKernelGGL(k_tall_bt, dim3(nblocks(per * gB)), dim3(256), 0, st, Bm, gB, H, gm.sa, gm.N, Bt);
         const ToepGeom rg = tall_row_geom(gm);
-        static const bool legacy_rows = getenv("MOTIFS_TOEP_LEGACY") != nullptr;
-        if (!legacy_rows && launch_tall_fused(e, A, Bt, C, gm, rg, acc, y, yb)) return;
-        if (legacy_rows || !launch_rowgemm_lds(e, A, Bt, Wt, rg, 0)) {
+        if (launch_tall_fused(e, A, Bt, C, gm, rg, acc, y, yb)) return;
+        if (!launch_rowgemm_lds(e, A, Bt, Wt, rg, 0)) {
             const int grp_rows = rg.B * rg.P;
             hipLaunchKernelGGL(k_toep_mfma, dim3((unsigned)((grp_rows + 63) / 64), (unsigned)(rg.S / rg.B), (unsigned)((rg.N + 31) / 32)),
                                dim3(512), 0, st, A, Bt, Wt, rg, 0);
@@ -3185,9 +3194,7 @@ static void launch_toep(Engine& e, const float* A, const float* Bm, float* C, co
                            gm.a0 / gm.sa, gm.ldc, acc, y, yb);
         return;
     }
-    static const bool legacy = getenv("MOTIFS_TOEP_LEGACY") != nullptr;   // debugging aid: the pre-LDS kernels
-    if (legacy) {
-    } else if (launch_ana_f16x3<12, 80>(e, A, Bm, C, gm, acc) || launch_ana_f16x3<12, 64>(e, A, Bm, C, gm, acc) || launch_ana_lds<12, 80>(e, A, Bm, C, gm, acc) || launch_ana_lds<12, 64>(e, A, Bm, C, gm, acc) ||
+    if (launch_ana_f16x3<12, 80>(e, A, Bm, C, gm, acc) || launch_ana_f16x3<12, 64>(e, A, Bm, C, gm, acc) || launch_ana_lds<12, 80>(e, A, Bm, C, gm, acc) || launch_ana_lds<12, 64>(e, A, Bm, C, gm, acc) ||
                launch_ana_lds<12, 32>(e, A, Bm, C, gm, acc) || launch_ana_lds<8, 64>(e, A, Bm, C, gm, acc) ||
                launch_ana_lds<8, 32>(e, A, Bm, C, gm, acc)) {
         return;
@@ -3205,7 +3212,7 @@ static void launch_toep(Engine& e, const float* A, const float* Bm, float* C, co
                            gm, acc);
         return;
     }
-    if (!legacy && launch_toep_wide(e, A, Bm, C, gm, acc)) return;
+    if (launch_toep_wide(e, A, Bm, C, gm, acc)) return;
     if (gm.N <= 32) {
         dim3 grid((gm.N + 31) / 32, (gm.P + 63) / 64, gm.S);
         hipLaunchKernelGGL(k_toep<32>, grid, dim3(256), 0, st, A, Bm, C, gm, acc);
@@ -3644,8 +3651,8 @@ static bool launch_rowwgrad_lds(Engine& e, const float* A, const float* C, float
     const RowSrc cs = src ? *src : RowSrc{0, 0, 0, 0, 0, 0, 0, 0};
     if (nparts) *nparts = rg.B * rowwgrad_split(rg);
     {
-        static const bool f32_only = getenv("MOTIFS_ROWWGRAD_F32") != nullptr || getenv("MOTIFS_ANA_F32") != nullptr;   // A/B: the float32 matrix instruction
-        static const long min_tiles = getenv("MOTIFS_ROWWGRAD_F16_MIN_TILES") ? atol(getenv("MOTIFS_ROWWGRAD_F16_MIN_TILES")) : 512;       // measured: level at 288 tiles, +1 % at 576, +2 % at 864
+        const bool f32_only = gemm_f32_only();   // A/B: the float32 matrix instruction
+        const long min_tiles = gemm_f16_min(512);       // measured: level at 288 tiles, +1 % at 576, +2 % at 864
         const int tps = (rg.P + 31) / 32, G = rg.S / rg.B, T = rg.B * tps;
         const size_t lds16 = (size_t)2 * 2 * 32 * (rg.Q + 8) * 2 + (size_t)2 * 2 * 32 * 56 * 2;
         if (!f32_only && nparts && (long)G * T >= min_tiles && lds16 + 64 <= 160 * 1024) {
@@ -3782,11 +3789,10 @@ static void launch_wgrad(Engine& e, const float* A, const float* C, float* dB, c
         }
         const ToepGeom rg = tall_row_geom(gm);
         const int rtiles = ((rg.Q + 127) / 128) * ((rg.N + 31) / 32);
-        static const bool legacy_rows = getenv("MOTIFS_TOEP_LEGACY") != nullptr;
         static const bool no_src = getenv("MOTIFS_NO_ROW_SRC") != nullptr;
         // the row kernel forms the scattered rows itself, from C (one launch and a round trip of dW through memory less:
         // 13.78 -> 13.53 ms per 64-mini-batch step, 2.27 -> 2.23 at one)
-        const bool in_kernel = !legacy_rows && !no_src && rg.B > 1 && rtiles * G < 2048 && (gm.N & 3) == 0 && (gm.ldc & 3) == 0 &&
+        const bool in_kernel = !no_src && rg.B > 1 && rtiles * G < 2048 && (gm.N & 3) == 0 && (gm.ldc & 3) == 0 &&
                                gm.a0 % gm.sa == 0 && rowwgrad_lds_ok(A, rg) && (((uintptr_t)C) & 15) == 0;
         if (!in_kernel)
             hipLaunchKernelGGL(k_tall_scatter, dim3(nblocks((size_t)gm.S * R * H * gm.N)), dim3(256), 0, st, C, dW, gm.S, gm.P, H, gm.N, R,
@@ -3804,7 +3810,7 @@ static void launch_wgrad(Engine& e, const float* A, const float* C, float* dB, c
             const RowSrc scat{1, gm.N / 4, gm.a0 / gm.sa, gm.P, 0, 0, 0, gm.ldc};
             if (in_kernel) {
                 (void)launch_rowwgrad_lds(e, A, C, part, rg, &scat, &nparts);
-            } else if (legacy_rows || !launch_rowwgrad_lds(e, A, dW, part, rg, nullptr, &nparts)) {
+            } else if (!launch_rowwgrad_lds(e, A, dW, part, rg, nullptr, &nparts)) {
                 hipLaunchKernelGGL(k_wgrad_mfma, dim3((rg.Q + 127) / 128, gm.S, (rg.N + 31) / 32), dim3(256), 0, st, A, dW, part, r1, 0);
                 nparts = rg.B;
             }
@@ -3816,9 +3822,8 @@ static void launch_wgrad(Engine& e, const float* A, const float* C, float* dB, c
         return;
     }
     const size_t per = (size_t)gm.Q * gm.N;
-    static const bool legacy = getenv("MOTIFS_TOEP_LEGACY") != nullptr;
     // short windows, wide outputs (the D-layer analysis): the transposed row-GEMM gradient over the window matrix
-    if (!legacy && gm.Q <= 48 && gm.Q > 32 && gm.N >= 64 && gm.ldc == (int64_t)gm.P * gm.N) {
+    if (gm.Q <= 48 && gm.Q > 32 && gm.N >= 64 && gm.ldc == (int64_t)gm.P * gm.N) {
         ToepGeom rg;
         rg.S = gm.S, rg.P = gm.P, rg.Q = gm.N, rg.N = gm.Q, rg.sa = gm.N, rg.a0 = 0, rg.amax = gm.P * gm.N;
         rg.lda = (int64_t)gm.P * gm.N, rg.ldc = (int64_t)gm.P * gm.Q, rg.B = gm.B, rg.ldb = 0;
@@ -4730,7 +4735,7 @@ __global__ __launch_bounds__(1024) void k_sp_wgrad_ana_reads(const float* __rest
 // up to 24 mini-batches: the per-read form (5.51 against 5.70 ms per step at 16, 6.93 against 7.02 at 24, even at 32, 13.75 against
 // 13.34 at 64); more: a block per (columns, row, mini-batch) fills the chip by itself
 static bool sp_wgrad_by_reads(Engine& e, const SpDims& d, int G, size_t lds) {
-    static const int max_g = getenv("MOTIFS_WGRAD_READS_MAX_G") ? atoi(getenv("MOTIFS_WGRAD_READS_MAX_G")) : 20;      // (against the four-column form: +2 % at 16 mini-batches, -2 % at 24)
+    constexpr int max_g = 20;      // (against the four-column form: +2 % at 16 mini-batches, -2 % at 24)
     if (G > max_g || d.B < 2 || d.B > 8 || lds > (size_t)150 << 10) return false;
     if (!e.wgrad_reads_attr_set) {
         (void)hipFuncSetAttribute((const void*)k_sp_wgrad_syn_reads, hipFuncAttributeMaxDynamicSharedMemorySize, 150 << 10);
@@ -4854,8 +4859,7 @@ __global__ __launch_bounds__(64) void k_sp_wgrad_ana4(const float* __restrict__ 
     }
 }
 static bool sp_wgrad_four_columns(const SpDims& d, const float* a, const float* b) {
-    static const bool off = getenv("MOTIFS_SP_WGRAD_1COL") != nullptr;      // A/B: one column per lane
-    return !off && (d.W & 3) == 0 && (size_t)d.K * 64 * 16 <= 64 * 1024 && ((((uintptr_t)a) | ((uintptr_t)b)) & 15) == 0;
+    return (d.W & 3) == 0 && (size_t)d.K * 64 * 16 <= 64 * 1024 && ((((uintptr_t)a) | ((uintptr_t)b)) & 15) == 0;
 }
 static void launch_sp_wgrad_syn(Engine& e, NzView nz, const float* dOut, float* dF, const SpDims& d, int G) {
     const size_t lds = (size_t)d.B * d.K * 128 * 4;
@@ -5036,8 +5040,7 @@ __global__ __launch_bounds__(256) void k_sp_syn_rows(NzView nz, const float* __r
 }
 
 static void launch_sp_syn(hipStream_t st, const NzView& nz, const float* FAf, float* out, const SpDims& d, int acc) {
-    static const bool legacy = getenv("MOTIFS_TOEP_LEGACY") != nullptr;
-    if (!legacy && (d.W & 3) == 0 && d.W <= 1024 && (d.ldf & 3) == 0 && ((((uintptr_t)FAf) | ((uintptr_t)out)) & 15) == 0) {
+    if ((d.W & 3) == 0 && d.W <= 1024 && (d.ldf & 3) == 0 && ((((uintptr_t)FAf) | ((uintptr_t)out)) & 15) == 0) {
         if (d.S >= 192) hipLaunchKernelGGL(k_sp_syn_rows<32>, dim3((d.c + 31) / 32, d.S), dim3(256), 0, st, nz, FAf, out, d, acc);
         else hipLaunchKernelGGL(k_sp_syn_rows<2>, dim3((d.c + 1) / 2, d.S), dim3(256), 0, st, nz, FAf, out, d, acc);
         return;

@@ -632,15 +632,7 @@ int motifs_ctx_create(int device, motifs_ctx** out) {
     MOTIFS_HIP_CHECK(hipHostMalloc(&c->pinned, 256, hipHostMallocDefault));
     const char* ev = getenv("MOTIFS_SCAN_VALU");
     c->scan_valu = ev && ev[0] == '1';
-    if (const char* nc = getenv("MOTIFS_DENSE_CELLS")) c->compact_cells = !(nc[0] == '1');   // A/B: the round-2 cell round trip
-    if (const char* dfv = getenv("MOTIFS_DENSE_FUSED")) c->dense_fused = !(dfv[0] == '0');   // A/B: the two-kernel dense form
-    if (const char* pl = getenv("MOTIFS_NO_PAIR_LAUNCHES")) c->pair_launches = !(pl[0] == '1');   // A/B: one launch of every stage per strand
     if (const char* cgv = getenv("MOTIFS_CG_CHUNKS")) c->cg_chunks = atoi(cgv);      // chunk groups: 0 = never, 1 / 2 / 4 = that size for every bank that can take it (tests, A/B)
-    if (const char* nf = getenv("MOTIFS_NO_STRAND_FUSION")) c->fuse_strands = !(nf[0] == '1');  // A/B: one candidate launch per strand
-    if (const char* wl = getenv("MOTIFS_WS_LIMIT_MB")) {       // experiments: the default of motifs_ctx_set_workspace_limit
-        const long long mb = atoll(wl);
-        if (mb > 0) c->ws_limit = (size_t)mb << 20;
-    }
     *out = c;
     return MOTIFS_OK;
 }

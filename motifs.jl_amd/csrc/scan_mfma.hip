@@ -229,12 +229,8 @@ __global__ __launch_bounds__(512) void scan_cand_kernel(const uint4* __restrict_
                                                         const CandDims d) {
     scan_cand_body<T, PG, false, 4, 2>(afrag, cinit, codes, cells, d);
 }
-// uniform slack: the wave fits 168 VGPRs, so three 4-wave blocks (2 reads x 2 tile groups, or 4 reads x 1) share a CU
-template <int T, int PG, int TGB, bool COMPACT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((T * PG <= 16 && PG > 1) ? 3 : 2, 4))) void scan_cand_kernel_u(
-    const uint4* __restrict__ afrag, const uint8_t* __restrict__ codes, uint32_t* __restrict__ cells, uint16_t* __restrict__ centries, const CandDims d) {
-    scan_cand_body<T, PG, true, 4 / TGB, TGB, COMPACT>(afrag, nullptr, codes, cells, d, centries);
-}
+// (round 5: the one-read-per-wave kernel for uniform-slack banks, scan_cand_kernel_u, is gone - since the four-reads kernel takes segments
+// of a read's window tiles it serves reads of any length, and nothing reached the other form but an A/B switch)
 
 // Four reads per wave (uniform slack, short reads): the 32 columns of a tile are 8 consecutive windows of 4 consecutive
 // reads, lane (w, h) -> read w >> 3, window w & 7.  The cells of one start l and 4 reads x 2 chunks are one 128-byte line,
@@ -1390,7 +1386,7 @@ static size_t cand_q_lds_cap(int wpe) { return (size_t)(160 * 1024 / wpe) - 1024
 // kernel ran before, 11.9 ms of candidates per 25 000 reads against 10.1 with two segments), or (b) the launch does not fill the CU
 // slots once (1 024 reads: 28 -> 15 us; 4 096: 41 -> 38).  Past one round segments cost more than they balance (12 500 reads, 1 563
 // blocks on 1 024 slots: 96 us with one segment, 100 with four - a first round takes 61 us where a later one takes 45 because its
-// blocks stage and multiply in step, and segments do not change that).  MOTIFS_CAND_SEGS forces a count (A/B runs).
+// blocks stage and multiply in step, and segments do not change that).
 static int cand_q_segments(const CandDims& d, int lenp, int wpe, int64_t blocks) {
     const int nt = (d.Lout + 7) / 8;
     auto lds_of = [&](int ns) {
@@ -1399,8 +1395,6 @@ static int cand_q_segments(const CandDims& d, int lenp, int wpe, int64_t blocks)
     };
     int ns = 1;
     while (ns < nt && lds_of(ns) > cand_q_lds_cap(wpe)) ns++;
-    static const int want = getenv("MOTIFS_CAND_SEGS") ? atoi(getenv("MOTIFS_CAND_SEGS")) : 0;
-    if (want > 0) return std::min(nt, std::max(ns, want));
     const int64_t slots = (int64_t)256 * wpe;
     while (blocks * (ns + 1) <= slots && ns < 8 && (nt + ns) / (ns + 1) >= 4) ns++;
     return ns;
@@ -1411,8 +1405,7 @@ static hipError_t launch_cand_tp(const CandArgs& a, hipStream_t st, hipEvent_t e
     const int tgb = (a.uniform_eps && ntg == 1) ? 1 : 2;
     // four reads per wave, the LDS images leaving the CU as many blocks as the registers do (4, 3 or 2 per CU)
     constexpr int wpe = (T * PG <= 12) ? 4 : (T * PG <= CAND_Q_W3 && PG > 1) ? 3 : 2;
-    static const bool one_read = getenv("MOTIFS_CAND_ONE_READ") != nullptr;      // A/B: scan_cand_kernel_u (one strand per launch only)
-    if (a.uniform_eps && !(one_read && !a.afrag2)) {
+    if (a.uniform_eps) {
         CandDims d = a.d;
         const bool compact = PG == 4 && a.centries != nullptr;
         // quads per wave: many small blocks balance the CUs best (N = 100k: 1 or 2 per wave 0.337 ms, 3: 0.354, 8: 0.390)
@@ -1445,20 +1438,12 @@ static hipError_t launch_cand_tp(const CandArgs& a, hipStream_t st, hipEvent_t e
         else hipExtLaunchKernelGGL((scan_cand_kernel_q<T, PG, 2, false>), grid, dim3(256), (uint32_t)lds_q, st, ev0, ev1, 0, a.afrag, a.codes, a.cells, (uint16_t*)nullptr, d, (const uint4*)nullptr, (uint32_t*)nullptr, (uint16_t*)nullptr);
         return hipGetLastError();
     }
-    const int rpb = a.uniform_eps ? 4 / tgb : 4;
-    const int64_t per_block = (int64_t)rpb * a.d.spw;
+    // banks without a uniform slack: one read per wave, cells only
+    const int64_t per_block = (int64_t)4 * a.d.spw;
     dim3 grid((unsigned)((a.d.N + per_block - 1) / per_block), (unsigned)((ntg + tgb - 1) / tgb), 1);
-    const size_t lds = (size_t)tgb * rpb * ((a.d.ohlen + 3) & ~3) * 8;
-    if (a.afrag2) return hipErrorInvalidValue;                                       // two strands per launch: the four-reads kernel only (cand_two_strands_ok)
-    if (a.centries && !(a.uniform_eps && PG == 4)) return hipErrorInvalidValue;      // the caller asked cand_compact_ok() first
-    if (a.uniform_eps && a.centries) {
-        if constexpr (PG == 4) {
-            if (tgb == 1) hipExtLaunchKernelGGL((scan_cand_kernel_u<T, PG, 1, true>), grid, dim3(256), (uint32_t)lds, st, ev0, ev1, 0, a.afrag, a.codes, a.cells, a.centries, a.d);
-            else hipExtLaunchKernelGGL((scan_cand_kernel_u<T, PG, 2, true>), grid, dim3(256), (uint32_t)lds, st, ev0, ev1, 0, a.afrag, a.codes, a.cells, a.centries, a.d);
-        }
-    } else if (a.uniform_eps && tgb == 1) hipExtLaunchKernelGGL((scan_cand_kernel_u<T, PG, 1, false>), grid, dim3(256), (uint32_t)lds, st, ev0, ev1, 0, a.afrag, a.codes, a.cells, (uint16_t*)nullptr, a.d);
-    else if (a.uniform_eps) hipExtLaunchKernelGGL((scan_cand_kernel_u<T, PG, 2, false>), grid, dim3(256), (uint32_t)lds, st, ev0, ev1, 0, a.afrag, a.codes, a.cells, (uint16_t*)nullptr, a.d);
-    else hipExtLaunchKernelGGL((scan_cand_kernel<T, PG>), grid, dim3(512), (uint32_t)lds, st, ev0, ev1, 0, a.afrag, a.cinit, a.codes, a.cells, a.d);
+    const size_t lds = (size_t)tgb * 4 * ((a.d.ohlen + 3) & ~3) * 8;
+    if (a.afrag2 || a.centries) return hipErrorInvalidValue;       // two strands per launch / compact entries: the four-reads kernel only (cand_compact_ok)
+    hipExtLaunchKernelGGL((scan_cand_kernel<T, PG>), grid, dim3(512), (uint32_t)lds, st, ev0, ev1, 0, a.afrag, a.cinit, a.codes, a.cells, a.d);
     return hipGetLastError();
 }
 

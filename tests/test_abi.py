@@ -70,3 +70,18 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in src.replace("no CPU fallback", ""), f"{f} mentions the oracle"
+
+
+def test_every_switch_of_the_library_is_named_in_a_test():
+    """The MOTIFS_* environment switches csrc/ reads (debugging / A-B forms, read once per process) stay few and none of them guards a form that no
+    test runs: at most 20, each named in a tests/*.py file (round-4 verdict: 35 switches, a third of them covered by nothing)."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    names = set()
+    for f in glob.glob(os.path.join(root, "motifs.jl_amd", "csrc", "*.h*")):
+        names |= set(re.findall(r'getenv\("(MOTIFS_[A-Z0-9_]+)"\)', open(f).read()))
+    tests = "".join(open(f).read() for f in glob.glob(os.path.join(root, "tests", "*.py")) if not f.endswith("test_abi.py"))
+    assert 0 < len(names) <= 20, sorted(names)
+    missing = sorted(n for n in names if n not in tests)
+    assert not missing, missing

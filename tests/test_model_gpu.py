@@ -309,18 +309,15 @@ def test_fused_forms_equal_the_separate_launches(ctx, pkg, tmp_path):
 
 def test_f16x3_syntax_gemm_meets_the_oracle(ctx, pkg, tmp_path):
     """Steps of many mini-batches run the syntax-layer analysis GEMM on the binary16 matrix instruction with three products per term
-    (k_ana_f16x3: every float32 operand split into two binary16 numbers at a power-of-two scale).  MOTIFS_ANA_F16_MIN_JOBS=1 sends the
+    (k_ana_f16x3: every float32 operand split into two binary16 numbers at a power-of-two scale).  MOTIFS_GEMM_F16_MIN=1 sends the
     one-mini-batch configs[1] fixture through it (a fresh process: the switch is read once): loss and every gradient against the float64
     oracle's at the tolerances of test_cfg2_golden, i.e. the split form is as close to the oracle as the float32 instruction."""
     import subprocess
     import sys
     path = str(tmp_path / "f16x3.npz")
     e = dict(os.environ)
-    e.pop("MOTIFS_ANA_F32", None)
-    e["MOTIFS_ANA_F16_MIN_JOBS"] = "1"
-    e["MOTIFS_ROWGEMM_F16_MIN_TILES"] = "1"        # and the D-layer GEMMs in the same form (k_rowgemm16, k_toep_wide16)
-    e["MOTIFS_TOEP_F16_MIN_JOBS"] = "1"
-    e["MOTIFS_ROWWGRAD_F16_MIN_TILES"] = "1"       # and their filter gradients (k_rowwgrad16)
+    e.pop("MOTIFS_GEMM_F32", None)
+    e["MOTIFS_GEMM_F16_MIN"] = "1"        # all four: the syntax GEMM, the D-layer GEMMs (k_rowgemm16, k_toep_wide16) and their filter gradients (k_rowwgrad16)
     subprocess.run([sys.executable, os.path.join(HERE, "_df_literal_helper.py"), path], check=True, env=e, timeout=300)
     out = np.load(path)
     g = np.load(os.path.join(HERE, "golden", "model_cfg2.npz"))
@@ -344,10 +341,8 @@ def test_binary16_gemms_on_other_shapes(ctx, pkg, tmp_path):
     import sys
     path = str(tmp_path / "f16forms.npz")
     e = dict(os.environ)
-    for k in ("MOTIFS_ANA_F32", "MOTIFS_TOEP_F32", "MOTIFS_ROWGEMM_F32", "MOTIFS_ROWWGRAD_F32"):
-        e.pop(k, None)
-    for k in ("MOTIFS_ANA_F16_MIN_JOBS", "MOTIFS_TOEP_F16_MIN_JOBS", "MOTIFS_ROWGEMM_F16_MIN_TILES", "MOTIFS_ROWWGRAD_F16_MIN_TILES"):
-        e[k] = "1"
+    e.pop("MOTIFS_GEMM_F32", None)
+    e["MOTIFS_GEMM_F16_MIN"] = "1"
     subprocess.run([sys.executable, os.path.join(HERE, "_f16_forms_helper.py"), path], check=True, env=e, timeout=300)
     out = np.load(path)
 
@@ -422,6 +417,7 @@ def multi_golden_state():
     return gm, hp, cdl_o
 
 
+VEC_INF = 4.5e-6       # the scalar-vector gradients of a 24- / 64-mini-batch launch (see check_multi_launch)
 F_TIE_ENTRIES = 64     # entries of the F gradient (of 115 200) a launch may have outside GRAD_INF: medians within rounding noise of a one-ulp gap
 F_TIE_INF = 5e-3       # ... and how far outside (|got - want|_inf / |want|_inf); one such median moved 1-9 entries by up to 1.7e-3
 
@@ -442,22 +438,49 @@ def test_multi_mini_batch_launch_meets_the_float64_oracle(ctx, pkg, G):
     assert G in (int(gm["g_mid"]), len(gm["losses"]))
     cdl = to_model(pkg, ctx, hp, 200, cdl_o, arena=int((0.3 * G + 2) * (1 << 30)))
     try:
-        codes = gm["codes"][: G * hp.batch_size]
-        loss, flat = gpu_loss_grad(pkg, ctx, cdl, codes, G)
-        want = gm["losses"][:G]
-        assert np.all(want < 190.0), "the codes died: this test would compare zeros"
-        assert np.abs(loss.astype(np.float64) - want).max() <= LOSS_RTOL * want.max(), np.abs(loss - want).max() / want.max()
-        got = split_grad(cdl, flat)
-        for n in NAMES:
-            w = gm["grad%d_%s" % (G, n)].astype(np.float64)
-            if n != "F":
-                assert_grad(got[n], w, n)
-                continue
-            e = np.abs(got[n].astype(np.float64) - w.ravel()) / np.abs(w).max()
-            assert int((e > GRAD_INF).sum()) <= F_TIE_ENTRIES and e.max() <= F_TIE_INF, (int((e > GRAD_INF).sum()), e.max())
-            assert np.quantile(e, 0.999) <= GRAD_INF / 2, np.quantile(e, 0.999)
+        loss, flat = gpu_loss_grad(pkg, ctx, cdl, gm["codes"][: G * hp.batch_size], G)
+        check_multi_launch(gm, cdl.hp, G, loss, flat)
     finally:
         cdl.model.close()
+
+
+def check_multi_launch(gm, hp, G, loss, flat):
+    want = gm["losses"][:G]
+    assert np.all(want < 190.0), "the codes died: this test would compare zeros"
+    assert np.abs(loss.astype(np.float64) - want).max() <= LOSS_RTOL * want.max(), np.abs(loss - want).max() / want.max()
+    nD, nF = hp.M * 4 * hp.filter_len, hp.K * 2 * hp.M * hp.h
+    got = {"D": flat[:nD], "F": flat[nD:nD + nF]}
+    o = nD + nF
+    for name, n in zip(pkg_vec_fields(), pkg_vec_sizes(hp)):
+        got[name] = flat[o:o + n]
+        o += n
+    for n in NAMES:
+        w = gm["grad%d_%s" % (G, n)].astype(np.float64)
+        if n == "D":
+            assert_grad(got[n], w, n)
+            continue
+        if n != "F":         # the seven 3- / 6-entry vectors: each entry is a sum over G x 453 600 products whose block partials meet in float
+            # atomics - 1.1e-6 ... 2.2e-6 of the largest entry from run to run at 64 mini-batches (GRAD_INF there is marginal: VEC_INF = 2x achieved)
+            assert rel_inf(got[n], w) <= VEC_INF and rel_elem(got[n], w) <= GRAD_ELEM, (n, rel_inf(got[n], w), rel_elem(got[n], w))
+            continue
+        e = np.abs(got[n].astype(np.float64) - w.ravel()) / np.abs(w).max()
+        assert int((e > GRAD_INF).sum()) <= F_TIE_ENTRIES and e.max() <= F_TIE_INF, (int((e > GRAD_INF).sum()), e.max())
+        assert np.quantile(e, 0.999) <= GRAD_INF / 2, np.quantile(e, 0.999)
+
+
+def test_multi_mini_batch_launch_on_the_float32_matrix_instruction(pkg, tmp_path):
+    """MOTIFS_GEMM_F32=1 (read once per process: a fresh one) keeps the four GEMMs of the 64-mini-batch launch on v_mfma_f32_32x32x2_f32 /
+    16x16x4_f32 - the forms every launch took before round 4 and small launches still take: the same golden, the same bounds."""
+    import subprocess
+    import sys
+    path = str(tmp_path / "f32.npz")
+    e = dict(os.environ)
+    e.pop("MOTIFS_GEMM_F16_MIN", None)
+    e["MOTIFS_GEMM_F32"] = "1"
+    subprocess.run([sys.executable, os.path.join(HERE, "_multi_helper.py"), "64", path], check=True, env=e, timeout=600)
+    out = np.load(path)
+    gm, hp, _ = multi_golden_state()
+    check_multi_launch(gm, hp, 64, out["loss"], out["flat"])
 
 
 def test_train_step_matches_adabelief_oracle(ctx, pkg):

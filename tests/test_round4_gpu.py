@@ -6,6 +6,8 @@ slice of the table in LDS) and the record order (findall's: start l, read, PWM; 
 staged words.  `MOTIFS_CG_CHUNKS=c` forces that path on banks of any size, so every group size meets the oracle on the
 shapes the other scan tests use; the default (`auto`: chunk groups only when not even one 16-wave block per CU can hold the table) is
 checked at the BASELINE configs[3] / configs[4] bank shapes."""
+import os
+
 import numpy as np
 import pytest
 
@@ -445,3 +447,17 @@ def test_workspace_limit_bounds_what_a_both_strands_scan_holds(torch_cuda, pkg):
                     assert np.array_equal(rec[rc][0], ref[rc][0]) and np.array_equal(rec[rc][1], ref[rc][1])
         finally:
             c.close()
+
+
+def test_scans_on_poisoned_workspaces(torch_cuda, pkg):
+    """MOTIFS_POISON_WS=1 (read once per process: a fresh one): every workspace a context allocates starts as 0xFF bytes.  Four awkward
+    shapes - a short last ordering batch, reads not a multiple of 4 with an all-zero column and three chunks, a launch of one PWM tile on
+    1001-position reads, PWMs of 24-40 positions (128-bit cells, no entries) - both strands against the CPU port: a kernel that reads a cell,
+    an entry or a staging slot that nothing wrote would return a wrong record."""
+    import subprocess
+    import sys
+    e = dict(os.environ, MOTIFS_POISON_WS="1")
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "_poison_ws_helper.py")], env=e, timeout=600,
+                       capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
+
