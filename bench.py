@@ -123,7 +123,19 @@ def main():
     if rehearse:
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    watchdog = None
     if world > 1:
+        # a rank that cannot finish its rendezvous or its communicator (another rank died, RCCL hangs on a link) must not sit in the job for ever:
+        # past MOTIFS_BENCH_INIT_TIMEOUT seconds (default 240) without the set-up being complete the process leaves with status 5
+        import threading
+
+        def _give_up():
+            sys.stderr.write(f"bench.py rank {rank}: process group / communicator not ready after the init timeout; exiting\n")
+            sys.stderr.flush()
+            os._exit(5)
+        watchdog = threading.Timer(float(os.environ.get("MOTIFS_BENCH_INIT_TIMEOUT", "240")), _give_up)
+        watchdog.daemon = True
+        watchdog.start()
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearse:
             dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -156,6 +168,15 @@ def main():
     # ends with a device synchronize, so every record of every step is written inside it
     ctx.set_records_in_stream_order(True)
     reducer, reducer_note = par.make_reducer(ctx, prefer_rccl=not rehearse)
+    if watchdog is not None:
+        watchdog.cancel()
+    if world > 1 and not rehearse and not isinstance(reducer, par.RcclReducer) and os.environ.get("MOTIFS_BENCH_ALLOW_HOST_SUMS") != "1":
+        # make_reducer agreed on this over the process group (a MIN over the ranks): every rank takes this exit, none is left in a collective.
+        # A line measured with host-staged sums would not be the RCCL-over-xGMI path BASELINE configs[2] names.
+        sys.stderr.write(f"bench.py rank {rank}: {reducer_note}; refusing to report an N > 1 line without RCCL (MOTIFS_BENCH_ALLOW_HOST_SUMS=1 overrides)\n")
+        sys.stderr.flush()
+        dist.destroy_process_group()
+        sys.exit(4)
 
     # ---- synthetic inputs ------------------------------------------------------
     seed = sy.SEED_BASE + 2
@@ -183,7 +204,7 @@ def main():
             pc, ph, ps, pk = sh["ptrs"]
             tot = sum(ctx.pwm_scan_hits_both_dev(bank, lens, pc, sh["n"], L, ph, ps, sh["cap"], n0=sh["n0"], counts_ptr=pk))
         if world > 1:   # the one real exchange of the scan: the K int64 hit counts of both strands, queued on the
-            reducer.sum_i64_(sh["counts"])   # scan's stream behind the kernels that wrote them; the next scan queues behind it
+            reducer.hist_sum_(sh["counts"])  # behind the kernels that finished them, beside the record writes (motifs_hist_allreduce); the next scan queues behind it
         return tot
 
     # weak: one 100k shard per rank
@@ -295,7 +316,7 @@ def main():
                 pc, ph, ps, pk = shp["ptrs"]
                 tot_ = sum(ctx.pwm_scan_hits_both_dev(bank, lens, pc, shp["n"], L, ph, ps, shp["cap"], n0=0, counts_ptr=pk))
                 if red1 is not None:
-                    red1.sum_i64_(shp["counts"])
+                    red1.hist_sum_(shp["counts"])
                 return tot_
             for _ in range(PREHEAT):
                 pstep()

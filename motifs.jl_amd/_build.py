@@ -46,7 +46,7 @@ def build(verbose=True, force=False, defs=None, out=None):
 
 def _build(hipcc, OBJ, LIB, defs, verbose, force):
     os.makedirs(OBJ, exist_ok=True)
-    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h") or f.endswith(".inc")]   # (.inc: the parts of cdl_engine.hip)
     headers.append(os.path.join(HERE, "..", "include", "motifs_hip.h"))
     objs, cmds = [], []
     for f in sorted(os.listdir(CSRC)):

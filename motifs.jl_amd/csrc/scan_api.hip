@@ -587,6 +587,11 @@ static int scan_hits_pair(motifs_ctx* c, BankSlot* const bs[2], int K, const uin
             MOTIFS_HIP_CHECK(hipEventRecord(c->ev_totals, c->stream));
             c->ev_totals_set = true;
         }
+        if (counts2_dev && emit) {                       // ... and the hit counts are final: a sum over ranks may run beside emit_records
+            if (!c->ev_counts) MOTIFS_HIP_CHECK(hipEventCreateWithFlags(&c->ev_counts, hipEventDisableTiming));
+            MOTIFS_HIP_CHECK(hipEventRecord(c->ev_counts, c->stream));
+            c->ev_counts_buf = counts2_dev;
+        }
     }
     if (emit) {
         KernelTimer t(c, KS_SCAN_FILL);
@@ -652,6 +657,9 @@ void motifs_ctx_destroy(motifs_ctx* c) {
     resolve_timing(c);
     for (hipEvent_t e : c->free_events) (void)hipEventDestroy(e);
     if (c->ev_totals) (void)hipEventDestroy(c->ev_totals);
+    if (c->ev_counts) (void)hipEventDestroy(c->ev_counts);
+    if (c->ev_side) (void)hipEventDestroy(c->ev_side);
+    if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1060,6 +1068,7 @@ int motifs_pwm_scan_hits_both_dev(motifs_ctx* c, const uint16_t* pwms_fp16, cons
     }
     MOTIFS_HIP_CHECK(hipSetDevice(c->device));
     c->ev_totals_set = false;
+    c->ev_counts_buf = nullptr;
     if (per_pwm_counts2_dev) MOTIFS_HIP_CHECK(hipMemsetAsync(per_pwm_counts2_dev, 0, (size_t)2 * K * 8, c->stream));
     // One candidate launch for both strands when the four-reads kernel with compact entries serves both banks and the shard is one
     // super-batch: the reverse bank then goes over the reads the forward bank's waves have already staged (scan_mfma.hip).

@@ -62,6 +62,13 @@ class RcclReducer:
         self.comm.allreduce_sum_i64(t.data_ptr(), t.numel())
         return t
 
+    def hist_sum_(self, counts):
+        """The (2, K) per-PWM hit counts of the both-strands scan just made on this context (motifs_hist_allreduce: beside that scan's
+        record writes when the scan was one launch per stage)."""
+        self._order(counts)
+        self.comm.hist_allreduce(counts.data_ptr(), counts.shape[-1], counts.shape[0] if counts.dim() == 2 else 1)
+        return counts
+
 
 def host_all_reduce(t, op=None):
     """torch.distributed all-reduce of a small tensor wherever it lives: NCCL/RCCL groups only take device tensors, gloo
@@ -104,6 +111,7 @@ class HostReducer:
 
     sum_f32_ = _sum
     sum_i64_ = _sum
+    hist_sum_ = _sum
 
 
 def make_reducer(ctx, prefer_rccl=True):

@@ -461,3 +461,56 @@ def test_scans_on_poisoned_workspaces(torch_cuda, pkg):
                        capture_output=True, text=True)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
 
+
+
+def test_histogram_sum_beside_the_record_writes(torch_cuda, pkg):
+    """motifs_hist_allreduce straight after the both-strands scan that wrote the counts (one launch per stage): the sum runs on a stream of
+    the library's own behind the kernels that finished the counts, beside emit_records, and the context's stream waits for it.  Three scans
+    of different shards back to back on a private-stream context in stream-order mode, each followed by the sum (a one-rank RCCL communicator:
+    the values must come back unchanged) and by the next scan's zero fill of the SAME counts buffer, with a device-side copy of the counts queued
+    on the context's stream in between: every copy is the histogram of its own scan's records."""
+    sy, lib, torch = pkg.synth, pkg._lib, torch_cuda
+    c = lib.Context(0)
+    c.set_records_in_stream_order(True)
+    comm = None
+    try:
+        try:
+            comm = lib.Comm(c, lib.Comm.unique_id(), 1, 0)
+        except lib.MotifsError as e:
+            pytest.skip(f"no RCCL communicator on this box: {e}")
+        N, L, K = 7000, 120, 200
+        pwms, lens = sy.gen_pwm_bank(K, 9600, len_lo=12, len_hi=12, alpha=0.3)
+        bank = sy.pad_bank(pwms, lens)
+        st = torch.cuda.ExternalStream(c.get_stream())
+        counts = torch.zeros((2, K), dtype=torch.int64, device="cuda")
+        shards, copies = [], []
+        for i in range(3):
+            codes = sy.gen_codes(N, L, 9610 + i, n_plant=4, k=12)
+            raw = torch.from_numpy(codes).cuda()
+            dcodes = torch.zeros(lib.Context.codes_bytes(N, L), dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()
+            c.encode_dev(raw.data_ptr(), lib.DATA_CODES_U8, N, L, dcodes.data_ptr())
+            need = c.pwm_scan_hits_both_dev(bank, lens, dcodes.data_ptr(), N, L, None, None, 0)
+            cap = max(need) + 8
+            shards.append((dcodes, need, cap, [torch.zeros((cap, 3), dtype=torch.int32, device="cuda") for _ in range(2)],
+                           [torch.zeros(cap, dtype=torch.int16, device="cuda") for _ in range(2)]))
+            copies.append(torch.zeros_like(counts))
+        c.synchronize()
+        torch.cuda.synchronize()
+        for (dcodes, need, cap, hits, scs), cp in zip(shards, copies):
+            got = c.pwm_scan_hits_both_dev(bank, lens, dcodes.data_ptr(), N, L, [t.data_ptr() for t in hits], [t.data_ptr() for t in scs], cap,
+                                           counts_ptr=counts.data_ptr())
+            assert got == need and c.scan_plan()["launches"] == 1
+            comm.hist_allreduce(counts.data_ptr(), K, 2)
+            with torch.cuda.stream(st):
+                cp.copy_(counts)                      # on the context's stream: behind the sum, in front of the next scan's zero fill
+        c.synchronize()
+        for (dcodes, need, cap, hits, scs), cp in zip(shards, copies):
+            for rc in (0, 1):
+                want = torch.bincount(hits[rc][:need[rc], 0].to(torch.int64) - 1, minlength=K)
+                assert torch.equal(cp[rc], want)
+    finally:
+        if comm is not None:
+            c.synchronize()
+            comm.close()
+        c.close()
