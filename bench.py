@@ -35,8 +35,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 
 MFMA_F16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak (no sparsity)
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32-input matrix peak (= vector peak), v_mfma_f32_32x32x2_f32
 # PMC traffic per (kernel, launch shape), written by tools/summarize_traffic.py from the passes of tools/profile_round.sh
-TRAFFIC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r04_scan_hbm_traffic.json", "r03_scan_hbm_traffic.json", "r02_scan_hbm_traffic_by_shape.json")]
-TRAIN_PMC_FILE = os.path.join(ROOT, "profiles", "r04_train_kernels_pmc.json")   # tools/summarize_train_pmc.py
+TRAFFIC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r05_scan_hbm_traffic.json", "r04_scan_hbm_traffic.json", "r03_scan_hbm_traffic.json")]
+TRAIN_PMC_FILE = os.path.join(ROOT, "profiles", "r05_train_kernels_pmc.json")   # tools/summarize_train_pmc.py
 
 
 def parse():
@@ -563,26 +563,32 @@ def main():
             stage_ms = {"scan_cand": cms / reps_, "stage_hits_row_scan": oms / reps_, "emit_records": fms / reps_}
             hits_strand = sum(got_) / 2.0
             lenp_ = (int(ln.max()) + 3) // 4 * 4
-            # the other two stages against what bounds them.  Re-scoring (stage_hits / stage_hits_cg): VALU issue.  The counters of the
-            # chunk-group kernel at this bank shape (profiles/r04_cg_stage_counters.txt) show 65 % of its cycles issuing VALU instructions,
-            # 4.1 wave-instructions per hit, and LDS gathers at a few per cent of the LDS rate: the bound is the kernel's own instruction
-            # count against the chip's VALU issue rate (1024 SIMDs, one wave-instruction per 4 cycles, 2.4 GHz).
+            # the other two stages against what bounds them.  Re-scoring (stage_hits / stage_hits_cg): VALU issue (1024 SIMDs, one wave-instruction
+            # per 4 cycles, 2.4 GHz).  The ALGORITHMIC instruction count is the exact score alone, from the ISA of exact_score<LEN, true>: per 64
+            # candidates lenp/4 + 1 shifts (the window's dwords doubled), lenp/4 byte alignments, lenp address adds (SDWA) and lenp - 1 binary16
+            # adds - 30 wave-instructions at 12 positions, 50 at 20 - with the lenp LDS gathers beside them on the LDS pipe.  `frac` = hits x that /
+            # the issue rate; what the kernel really issues per hit (PMC, profiles/r05_cg_stage_valu.json: the walk over the candidate entries, the
+            # queue, validity tests, staging) is reported beside it as `issue_utilisation` - a kernel with twice the instructions would score the
+            # same there, which is why it is not the roofline figure.
             valu_peak = 1024 * 2.4e9 / 4.0
-            vf = os.path.join(ROOT, "profiles", "r04_cg_stage_valu.json")
-            ipw, vsrc = 4.1, None
+            vf = os.path.join(ROOT, "profiles", "r05_cg_stage_valu.json")
+            ipw, vsrc = 3.9, None
             if os.path.exists(vf):
                 with open(vf) as fh:
                     vj = json.load(fh)
                 ipw, vsrc = vj["valu_wave_insts_per_hit"], {"file": os.path.relpath(vf, ROOT), "commit": vj.get("commit"), "kernel": vj.get("kernel")}
             hits_per_s = hits_strand / (oms / (2 * reps_) * 1e-3)
+            alg_ipc = (lenp_ // 4 + 1 + lenp_ // 4 + lenp_ + lenp_ - 1) / 64.0       # wave-instructions per candidate, exact score only
             rescoring = {"kernel": ("stage_hits_cg (chunk groups: one group's table slice in LDS per block) + row scan" if plan_["cg_chunks"] else
                                     "stage_hits (whole table in the LDS of one 16-wave block per CU when it is past 64 KB) + row scan"),
-                         "bound": "valu-issue", "achieved": hits_per_s * ipw / 1e9, "peak": valu_peak / 1e9, "unit": "G wave-instructions/s",
-                         "frac": hits_per_s * ipw / valu_peak, "valu_wave_insts_per_hit": ipw, "insts_source": vsrc, "hits_per_s": hits_per_s,
+                         "bound": "valu-issue", "achieved": hits_per_s * alg_ipc / 1e9, "peak": valu_peak / 1e9, "unit": "G wave-instructions/s",
+                         "frac": hits_per_s * alg_ipc / valu_peak, "algorithmic_wave_insts_per_candidate": alg_ipc,
+                         "issue_utilisation": hits_per_s * ipw / valu_peak, "valu_wave_insts_per_hit_by_pmc": ipw, "insts_source": vsrc, "hits_per_s": hits_per_s,
                          "lds_gather_frac_of_lds_rate": hits_strand * lenp_ / (oms / (2 * reps_) * 1e-3) / (64.0 * 256 * 2.4e9),
                          "ms_per_strand": oms / (2 * reps_),
-                         "note": "instructions per hit from the PMC pass of the chunk-group kernel at the configs[4] bank shape (the 16-wave form of "
-                                 "configs[3] issues about the same per candidate but walks 15x more empty cells per hit: its fraction is a lower bound)"}
+                         "note": "frac: the exact scores alone against the VALU issue rate (hits stand for candidates: 95 % of them are hits); issue_utilisation: every "
+                                 "vector instruction the kernel issues (PMC pass of the chunk-group kernel at the configs[4] bank shape; the 16-wave form of configs[3] "
+                                 "issues about the same per candidate but walks 15x more empty cells per hit)"}
             rec_bytes = hits_strand * 18.0
             records = {"kernel": "emit_records_cg" if plan_["cg_chunks"] else "emit_records", "bound": "hbm",
                        "achieved": rec_bytes / (fms / (2 * reps_) * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -747,7 +753,7 @@ def main():
                       "tests/test_model_gpu.py::test_df_telescoping_equals_literal_sequence); MOTIFS_DF_LITERAL=1 runs the literal "
                       "sequence"),
         }
-        # the step's largest kernel by time (profiles/r04_train_kernels_pmc.json: 5 launches, 12 % of the step): the VJP of update_ZY's fused ISTA
+        # the step's largest kernel by time (profiles/r05_train_kernels_pmc.json: 5 launches, 12 % of the step): the VJP of update_ZY's fused ISTA
         # step.  Elementwise over the code images [reads][c][2M] f32: eight read (the two incoming gradients, the gradient of the combination formed
         # after the step, the step's output, ZY, the D-layer gradient image, FX, the duals) and four written (gradients of ZY, g1, FX, duals); the first
         # pass has no duals (ten streams), counted as twelve here, so `achieved` is an upper bound of at most 3 %
