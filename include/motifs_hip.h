@@ -318,10 +318,7 @@ int motifs_comm_allreduce_sum_u32_dev(motifs_comm* comm, uint32_t* buf_dev, int6
 int motifs_comm_allreduce_sum_f32_to_dev(motifs_comm* comm, const float* send_dev, float* recv_dev, int64_t n);
 /* Sum over ranks of the flat gradient motifs_model_loss_grad_dev wrote (nD + nF + nV floats). */
 int motifs_model_allreduce_grad(motifs_model* m, motifs_comm* comm, float* grad_flat_dev);
-/* Sum over ranks of the per-PWM hit counts of a scan (K int64 per strand, n_strands = 1 or 2).  Called straight after the
- * motifs_pwm_scan_hits_both_dev that wrote these counts (same buffer, single-launch plan) the sum does not queue behind the record
- * writes: it runs beside them on a stream of the library's own, behind the kernels that finished the counts, and the context's stream
- * waits for it - for everything queued afterwards the order is the same as for a sum on the context's stream. */
+/* Sum over ranks of the per-PWM hit counts of a scan (K int64 per strand, n_strands = 1 or 2), on the context's stream. */
 int motifs_hist_allreduce(motifs_comm* comm, int64_t* per_pwm_counts_dev, int K, int n_strands);
 /* One data-parallel optimiser step: gradient of this rank's n_groups_local mini-batches (0 is allowed: the rank
  * contributes zeros and still takes part in the exchange) -> sum over ranks -> AdaBelief with the mean over the

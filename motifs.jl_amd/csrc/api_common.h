@@ -98,12 +98,10 @@ struct motifs_ctx {
     bool fuse_strands = true;       // one candidate launch for both strands where both banks take the four-reads kernel with compact entries
     bool records_async = false;     // motifs_ctx_set_records_in_stream_order: the both-strands scan returns once the totals are on the host
     hipEvent_t ev_totals = nullptr; // ... recorded behind the row scans of that call
-    // The per-PWM hit counts of a both-strands pair scan are final once stage_hits has run; ev_counts is recorded there (behind the row
-    // scans, in front of emit_records) and motifs_hist_allreduce sums them on side_stream behind that event, beside the record writes
-    hipEvent_t ev_counts = nullptr, ev_side = nullptr;
-    const void* ev_counts_buf = nullptr;   // the counts buffer the recorded event stands for (nullptr: no event pending)
-    hipStream_t side_stream = nullptr;
+
     bool ev_totals_set = false;     // (this call recorded it)
+    int64_t ticket_seq = 0;         // records in stream order, one-launch plan: the row scan writes this call's ticket into pinned memory behind the
+    bool ticket_wait = false;       // totals and the host polls for it (this call asked for it)
     motifs::BankSlot bank_slot[2];  // [rc]
     void* pinned = nullptr;  // small pinned host block for totals / flags
     // pinned staging of the host-buffer entries (motifs_pwm_scan*): code rows on the way up, record chunks on the way down

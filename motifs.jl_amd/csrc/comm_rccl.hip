@@ -243,24 +243,8 @@ int motifs_hist_allreduce(motifs_comm* c, int64_t* per_pwm_counts_dev, int K, in
         set_error("motifs_hist_allreduce: bad argument (K=%d n_strands=%d)", K, n_strands);
         return MOTIFS_ERR_INVALID;
     }
-    // Straight after a both-strands scan of ONE launch per stage that wrote these counts: the sum runs on a side stream behind the event
-    // recorded in front of emit_records (the counts are final there), beside the record writes; the context's stream then waits for it, so
-    // everything queued afterwards - the next scan's zero fill of the counts included - is ordered behind the sum as before.
-    motifs_ctx* x = c ? c->ctx : nullptr;
-    if (x && x->ev_counts_buf == (const void*)per_pwm_counts_dev && x->ev_counts && n_strands == 2 && K > 0 && g_group_depth == 0) {
-        x->ev_counts_buf = nullptr;
-        int r = need_rccl("motifs_hist_allreduce");
-        if (r) return r;
-        MOTIFS_HIP_CHECK(hipSetDevice(x->device));
-        if (!x->side_stream) MOTIFS_HIP_CHECK(hipStreamCreateWithFlags(&x->side_stream, hipStreamNonBlocking));
-        if (!x->ev_side) MOTIFS_HIP_CHECK(hipEventCreateWithFlags(&x->ev_side, hipEventDisableTiming));
-        MOTIFS_HIP_CHECK(hipStreamWaitEvent(x->side_stream, x->ev_counts, 0));
-        r = nccl_check(g_rccl.AllReduce(per_pwm_counts_dev, per_pwm_counts_dev, (size_t)K * 2, ncclInt64, ncclSum, c->comm, x->side_stream), "motifs_hist_allreduce");
-        if (r) return r;
-        MOTIFS_HIP_CHECK(hipEventRecord(x->ev_side, x->side_stream));
-        MOTIFS_HIP_CHECK(hipStreamWaitEvent(x->stream, x->ev_side, 0));
-        return MOTIFS_OK;
-    }
+    // (Round 5 ran this sum on a side stream behind an event recorded in front of emit_records, beside the record writes.  The timeline of a step says
+    // no: an event record in the stream leaves a 15-20 us hole in front of the next kernel - as much as the sum's latency it was meant to hide.)
     return allreduce(c, per_pwm_counts_dev, per_pwm_counts_dev, (int64_t)K * n_strands, ncclInt64, "motifs_hist_allreduce");
 }
 

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cmath>
@@ -562,6 +563,9 @@ static int scan_hits_pair(motifs_ctx* c, BankSlot* const bs[2], int K, const uin
         f[rc].base_in = nullptr;
         f[rc].total = (int64_t*)c->small.p + 2 * rc + 1;
         f[rc].total_host = (int64_t*)c->pinned + rc;
+        // records in stream order: the host will poll pinned words 8 + rc for this call's ticket (written behind the totals by the row scan)
+        f[rc].ticket_host = c->records_async ? (int64_t*)c->pinned + 8 + rc : nullptr;
+        f[rc].ticket = c->ticket_seq + 1;
         f[rc].cap = cap;
         f[rc].hits = (HitRec*)hits[rc];
         f[rc].hit_scores = scores[rc];
@@ -570,6 +574,8 @@ static int scan_hits_pair(motifs_ctx* c, BankSlot* const bs[2], int K, const uin
         f[rc].hist_bins = (counts2_dev && 2 * bs[rc]->KP <= FILL_HIST_MAX) ? 2 * bs[rc]->KP : 0;
     }
     a[0].centries = (uint16_t*)c->centries.p;
+    a[0].d.zero_ptr = (unsigned long long*)counts2_dev;
+    a[0].d.zero_n = counts2_dev ? 2 * K : 0;
     a[0].afrag2 = (const uint4*)bs[1]->afrag.p;
     a[0].cells2 = (uint32_t*)c->cnt2.p;
     a[0].centries2 = (uint16_t*)c->centries2.p;
@@ -583,19 +589,14 @@ static int scan_hits_pair(motifs_ctx* c, BankSlot* const bs[2], int K, const uin
         KernelTimer t(c, KS_SCAN_OFFSETS);
         MOTIFS_HIP_CHECK(launch_stage_hits(f[0], emit ? 1 : 0, c->stream, &f[1]));
         MOTIFS_HIP_CHECK(launch_row_scan(f[0], c->stream, &f[1]));
-        if (c->records_async && c->ev_totals) {          // the totals are in pinned host memory once this is reached
-            MOTIFS_HIP_CHECK(hipEventRecord(c->ev_totals, c->stream));
-            c->ev_totals_set = true;
-        }
-        if (counts2_dev && emit) {                       // ... and the hit counts are final: a sum over ranks may run beside emit_records
-            if (!c->ev_counts) MOTIFS_HIP_CHECK(hipEventCreateWithFlags(&c->ev_counts, hipEventDisableTiming));
-            MOTIFS_HIP_CHECK(hipEventRecord(c->ev_counts, c->stream));
-            c->ev_counts_buf = counts2_dev;
-        }
     }
     if (emit) {
         KernelTimer t(c, KS_SCAN_FILL);
         MOTIFS_HIP_CHECK(launch_emit_records(f[0], c->stream, &f[1]));
+    }
+    if (c->records_async) {
+        c->ticket_seq++;
+        c->ticket_wait = true;
     }
     c->scan_plan[0] = 1, c->scan_plan[1] = 0, c->scan_plan[2] = 1, c->scan_plan[3] = 1;
     return MOTIFS_OK;
@@ -635,6 +636,7 @@ int motifs_ctx_create(int device, motifs_ctx** out) {
     MOTIFS_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     c->own_stream = true;
     MOTIFS_HIP_CHECK(hipHostMalloc(&c->pinned, 256, hipHostMallocDefault));
+    memset(c->pinned, 0, 256);        // (words 8, 9: the tickets the row scan writes in stream-order mode; they count up from 1)
     const char* ev = getenv("MOTIFS_SCAN_VALU");
     c->scan_valu = ev && ev[0] == '1';
     if (const char* cgv = getenv("MOTIFS_CG_CHUNKS")) c->cg_chunks = atoi(cgv);      // chunk groups: 0 = never, 1 / 2 / 4 = that size for every bank that can take it (tests, A/B)
@@ -657,9 +659,6 @@ void motifs_ctx_destroy(motifs_ctx* c) {
     resolve_timing(c);
     for (hipEvent_t e : c->free_events) (void)hipEventDestroy(e);
     if (c->ev_totals) (void)hipEventDestroy(c->ev_totals);
-    if (c->ev_counts) (void)hipEventDestroy(c->ev_counts);
-    if (c->ev_side) (void)hipEventDestroy(c->ev_side);
-    if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1068,8 +1067,7 @@ int motifs_pwm_scan_hits_both_dev(motifs_ctx* c, const uint16_t* pwms_fp16, cons
     }
     MOTIFS_HIP_CHECK(hipSetDevice(c->device));
     c->ev_totals_set = false;
-    c->ev_counts_buf = nullptr;
-    if (per_pwm_counts2_dev) MOTIFS_HIP_CHECK(hipMemsetAsync(per_pwm_counts2_dev, 0, (size_t)2 * K * 8, c->stream));
+    c->ticket_wait = false;
     // One candidate launch for both strands when the four-reads kernel with compact entries serves both banks and the shard is one
     // super-batch: the reverse bank then goes over the reads the forward bank's waves have already staged (scan_mfma.hip).
     bool fuse = c->compact_cells && c->fuse_strands;
@@ -1088,7 +1086,10 @@ int motifs_pwm_scan_hits_both_dev(motifs_ctx* c, const uint16_t* pwms_fp16, cons
                hg0.compact && hg0.nb_max * batch >= N;
         pair_ok = hg0.cgc == 0;           // (chunk groups keep their launches per strand)
     }
-    if (fuse && pair_ok && pair_fits && c->pair_launches && bs[0]->minlen == bs[1]->minlen) {
+    const bool pair_plan = fuse && pair_ok && pair_fits && c->pair_launches && bs[0]->minlen == bs[1]->minlen;
+    // the counts start at zero: the pair plan's candidate kernel does it itself (its first block: no fill in front of the step)
+    if (per_pwm_counts2_dev && !pair_plan) MOTIFS_HIP_CHECK(hipMemsetAsync(per_pwm_counts2_dev, 0, (size_t)2 * K * 8, c->stream));
+    if (pair_plan) {
         const int rcode = scan_hits_pair(c, bs, K, codes_dev, N, L, L - bs[0]->minlen + 1, n0, batch, hits, scores, cap, per_pwm_counts2_dev);
         if (rcode) return rcode;
     } else
@@ -1100,7 +1101,20 @@ int motifs_pwm_scan_hits_both_dev(motifs_ctx* c, const uint16_t* pwms_fp16, cons
                                          fuse ? rc + 1 : 0, fuse ? bs[1] : nullptr);
         if (rcode) return rcode;
     }
-    if (c->ev_totals_set) {        // records in stream order: wait for the row scans only (scan_hits_pair recorded the event behind them)
+    if (c->ticket_wait) {          // records in stream order: wait for the row scans only - they write this call's ticket into pinned memory behind
+        c->ticket_wait = false;    // the totals; polling it costs a core for the length of the scan and spares the stream an event (and the host its wake-up)
+        const volatile int64_t* tk = (const volatile int64_t*)c->pinned + 8;
+        const auto t0 = std::chrono::steady_clock::now();
+        bool ok = false;
+        for (uint64_t spin = 0;; spin++) {
+            if (__atomic_load_n(&tk[0], __ATOMIC_ACQUIRE) == c->ticket_seq && __atomic_load_n(&tk[1], __ATOMIC_ACQUIRE) == c->ticket_seq) {
+                ok = true;
+                break;
+            }
+            if ((spin & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) break;   // (a failed launch: fall through to the stream wait and its error)
+        }
+        if (!ok) MOTIFS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    } else if (c->ev_totals_set) {
         c->ev_totals_set = false;
         MOTIFS_HIP_CHECK(hipEventSynchronize(c->ev_totals));
     } else {

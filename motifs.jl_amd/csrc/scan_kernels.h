@@ -77,6 +77,8 @@ struct FillArgs {
     unsigned long long* blk_base; // [ceil(nrows / 1024)] block totals, then records before the block
     const int64_t* base_in;       // records emitted before this super-batch (nullptr: none, the first one)
     int64_t* total_host;          // optional pinned host copy of *total (the host reads it after its stream wait)
+    int64_t* ticket_host;         // optional: pinned word that takes `ticket` once *total_host is written (records in stream order: the host
+    int64_t ticket;               // polls it instead of waiting on an event - an event record leaves a 15-20 us hole in the stream)
     int64_t cap;                  // records the output arrays can hold
     // chunk-group mode (banks whose re-scoring table does not fit the LDS; scan_mfma.hip "chunk groups"): cgc = chunks of 128 PWMs
     // per group (1, 2 or 4; 0 = off), ncg = groups.  A row is then rpr = 512 / cgc reads x nch chunks, row_sum / staging are kept
@@ -105,6 +107,10 @@ struct CandDims {
     // `ohseg` positions of their images - long reads then leave the CU as many blocks as the registers do, and a small shard has
     // enough blocks to even out its last round.  nseg = 1: the whole read (seg_tiles = all tiles, ohseg = ohlen).
     int nseg, seg_tiles, ohseg;
+    // four-reads kernel only: `zero_n` 64-bit counters at `zero_ptr` set to zero by the launch's first block (the per-PWM hit counts of the call: the
+    // consumers that add to them run behind this kernel in stream order; a hipMemsetAsync in front of it cost ~16 us of stream time, 3.6 of them the fill)
+    unsigned long long* zero_ptr;
+    int zero_n;
 };
 struct CandArgs {
     const uint4* afrag;       // [tiles][T][64] PWM fragments (A operand)

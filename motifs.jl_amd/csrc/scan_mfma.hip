@@ -269,6 +269,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((T * PG <= 
     uint2* oh = oh_all + (size_t)wave * 4 * opitch;
     const int slot = wave % QPB;
     const int tg = blockIdx.y * TGB + wave / QPB;
+    if (d.zero_n && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
+        for (int i = threadIdx.x; i < d.zero_n; i += 256) d.zero_ptr[i] = 0ull;
     if (tg * PG >= d.used_tiles) return;
     // the block's segment of the reads: window tiles [wt0, wt0 + ntile), image positions [p0, p0 + ohs)
     const int wt0 = (int)blockIdx.z * d.seg_tiles;
@@ -1019,6 +1021,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(CGC == 
 // exclusive scan of the row counts in three small steps: per 1024 rows, over the block totals, (added back in emit_records)
 // (ncg > 1, chunk groups: a row's count is the sum of its groups')
 struct RowScan2 {                     // the row-scan arguments of one or two strands (blockIdx.y)
+    int64_t* ticket_host[2];
+    int64_t ticket[2];
     const uint32_t* row_sum[2];
     uint32_t* row_excl[2];
     unsigned long long* blk[2];
@@ -1082,6 +1086,10 @@ __global__ __launch_bounds__(1024) void row_scan_blocks(const RowScan2 rs, int64
     if (tid == 1023) {
         *total_out = (int64_t)(part[1023] + base);
         if (total_host) *total_host = (int64_t)(part[1023] + base);   // pinned host memory: no copy kernel behind this one
+        if (rs.ticket_host[blockIdx.x]) {                             // ... and the word the host polls, behind the total
+            __threadfence_system();
+            __hip_atomic_store(rs.ticket_host[blockIdx.x], rs.ticket[blockIdx.x], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
@@ -1399,6 +1407,12 @@ static int cand_q_segments(const CandDims& d, int lenp, int wpe, int64_t blocks)
     while (blocks * (ns + 1) <= slots && ns < 8 && (nt + ns) / (ns + 1) >= 4) ns++;
     return ns;
 }
+// a candidate launch: with events attached the extended launch (they take the kernel's own time stamps), otherwise a plain one
+#define CAND_LAUNCH(kern, grid, block, lds, ...)                                                                      \
+    do {                                                                                                               \
+        if (ev0 || ev1) hipExtLaunchKernelGGL(kern, grid, block, lds, st, ev0, ev1, 0, __VA_ARGS__);                  \
+        else hipLaunchKernelGGL(kern, grid, block, lds, st, __VA_ARGS__);                                             \
+    } while (0)
 template <int T, int PG>
 static hipError_t launch_cand_tp(const CandArgs& a, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
     const int ntg = (a.d.used_tiles + PG - 1) / PG;           // tile groups that hold PWMs
@@ -1431,11 +1445,11 @@ static hipError_t launch_cand_tp(const CandArgs& a, hipStream_t st, hipEvent_t e
         }
         if (compact) {
             if constexpr (PG == 4) {
-                if (tgb == 1) hipExtLaunchKernelGGL((scan_cand_kernel_q<T, PG, 1, true>), grid, dim3(256), (uint32_t)lds_q, st, ev0, ev1, 0, a.afrag, a.codes, a.cells, a.centries, d, a.afrag2, a.cells2, a.centries2);
-                else hipExtLaunchKernelGGL((scan_cand_kernel_q<T, PG, 2, true>), grid, dim3(256), (uint32_t)lds_q, st, ev0, ev1, 0, a.afrag, a.codes, a.cells, a.centries, d, a.afrag2, a.cells2, a.centries2);
+                if (tgb == 1) CAND_LAUNCH((scan_cand_kernel_q<T, PG, 1, true>), grid, dim3(256), (uint32_t)lds_q, a.afrag, a.codes, a.cells, a.centries, d, a.afrag2, a.cells2, a.centries2);
+                else CAND_LAUNCH((scan_cand_kernel_q<T, PG, 2, true>), grid, dim3(256), (uint32_t)lds_q, a.afrag, a.codes, a.cells, a.centries, d, a.afrag2, a.cells2, a.centries2);
             }
-        } else if (tgb == 1) hipExtLaunchKernelGGL((scan_cand_kernel_q<T, PG, 1, false>), grid, dim3(256), (uint32_t)lds_q, st, ev0, ev1, 0, a.afrag, a.codes, a.cells, (uint16_t*)nullptr, d, (const uint4*)nullptr, (uint32_t*)nullptr, (uint16_t*)nullptr);
-        else hipExtLaunchKernelGGL((scan_cand_kernel_q<T, PG, 2, false>), grid, dim3(256), (uint32_t)lds_q, st, ev0, ev1, 0, a.afrag, a.codes, a.cells, (uint16_t*)nullptr, d, (const uint4*)nullptr, (uint32_t*)nullptr, (uint16_t*)nullptr);
+        } else if (tgb == 1) CAND_LAUNCH((scan_cand_kernel_q<T, PG, 1, false>), grid, dim3(256), (uint32_t)lds_q, a.afrag, a.codes, a.cells, (uint16_t*)nullptr, d, (const uint4*)nullptr, (uint32_t*)nullptr, (uint16_t*)nullptr);
+        else CAND_LAUNCH((scan_cand_kernel_q<T, PG, 2, false>), grid, dim3(256), (uint32_t)lds_q, a.afrag, a.codes, a.cells, (uint16_t*)nullptr, d, (const uint4*)nullptr, (uint32_t*)nullptr, (uint16_t*)nullptr);
         return hipGetLastError();
     }
     // banks without a uniform slack: one read per wave, cells only
@@ -1443,7 +1457,7 @@ static hipError_t launch_cand_tp(const CandArgs& a, hipStream_t st, hipEvent_t e
     dim3 grid((unsigned)((a.d.N + per_block - 1) / per_block), (unsigned)((ntg + tgb - 1) / tgb), 1);
     const size_t lds = (size_t)tgb * 4 * ((a.d.ohlen + 3) & ~3) * 8;
     if (a.afrag2 || a.centries) return hipErrorInvalidValue;       // two strands per launch / compact entries: the four-reads kernel only (cand_compact_ok)
-    hipExtLaunchKernelGGL((scan_cand_kernel<T, PG>), grid, dim3(512), (uint32_t)lds, st, ev0, ev1, 0, a.afrag, a.cinit, a.codes, a.cells, a.d);
+    CAND_LAUNCH((scan_cand_kernel<T, PG>), grid, dim3(512), (uint32_t)lds, a.afrag, a.cinit, a.codes, a.cells, a.d);
     return hipGetLastError();
 }
 
@@ -1457,7 +1471,8 @@ bool cand_two_strands_ok(const CandArgs& a) {
     return cand_compact_ok(a);           // (reads of any length: the kernel's blocks take segments of them)
 }
 
-// ev0 / ev1 (optional): events that take the kernel's own start and stop time stamps (hipExtLaunchKernelGGL): timing the
+// ev0 / ev1 (optional): events that take the kernel's own start and stop time stamps (hipExtLaunchKernelGGL; without events a plain launch -
+// the extended launch leaves a ~9 us hole behind the kernel whether or not it stamps anything): timing the
 // dominant kernel then puts no extra packets on the stream (an event recorded before and after cost ~5 us each per launch)
 // run-time length: one tile per wave, as many waves per block as the one-hot images leave room for
 static hipError_t launch_cand_generic(const CandArgs& a, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
@@ -1472,7 +1487,7 @@ static hipError_t launch_cand_generic(const CandArgs& a, hipStream_t st, hipEven
     const size_t lds = per_wave * wpb;
     if (lds > 64 * 1024)
         (void)hipFuncSetAttribute((const void*)scan_cand_kernel_g, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipExtLaunchKernelGGL(scan_cand_kernel_g, grid, dim3(64 * wpb), (uint32_t)lds, st, ev0, ev1, 0, a.afrag, a.cinit, a.codes, a.cells, d, a.lenp / 4,
+    CAND_LAUNCH(scan_cand_kernel_g, grid, dim3(64 * wpb), (uint32_t)lds, a.afrag, a.cinit, a.codes, a.cells, d, a.lenp / 4,
                           a.uniform_eps);
     return hipGetLastError();
 }
@@ -1652,6 +1667,7 @@ hipError_t launch_row_scan(const FillArgs& a, hipStream_t st, const FillArgs* b)
     for (int i = 0; i < 2; i++) {
         rs.row_sum[i] = f[i]->row_sum, rs.row_excl[i] = f[i]->row_excl, rs.blk[i] = f[i]->blk_base;
         rs.base_in[i] = f[i]->base_in, rs.total_out[i] = f[i]->total, rs.total_host[i] = f[i]->total_host;
+        rs.ticket_host[i] = f[i]->ticket_host, rs.ticket[i] = f[i]->ticket;
     }
     hipLaunchKernelGGL(row_scan_local, dim3((unsigned)nblk, b ? 2 : 1, 1), dim3(1024), 0, st, rs, a.nrows, a.cgc ? a.ncg : 1);
     hipLaunchKernelGGL(row_scan_blocks, dim3(b ? 2 : 1), dim3(1024), 0, st, rs, nblk);

@@ -463,12 +463,12 @@ def test_scans_on_poisoned_workspaces(torch_cuda, pkg):
 
 
 
-def test_histogram_sum_beside_the_record_writes(torch_cuda, pkg):
-    """motifs_hist_allreduce straight after the both-strands scan that wrote the counts (one launch per stage): the sum runs on a stream of
-    the library's own behind the kernels that finished the counts, beside emit_records, and the context's stream waits for it.  Three scans
-    of different shards back to back on a private-stream context in stream-order mode, each followed by the sum (a one-rank RCCL communicator:
-    the values must come back unchanged) and by the next scan's zero fill of the SAME counts buffer, with a device-side copy of the counts queued
-    on the context's stream in between: every copy is the histogram of its own scan's records."""
+def test_histogram_sum_between_scans_in_stream_order_mode(torch_cuda, pkg):
+    """motifs_hist_allreduce straight after the both-strands scan that wrote the counts, in stream-order mode (the call has returned while the records
+    are still being written) and with the NEXT scan - whose candidate kernel zeroes the SAME counts buffer itself, no fill in front of it - queued
+    right behind: three scans of different shards back to back on a private-stream context, each followed by the sum (a one-rank RCCL
+    communicator: the values must come back unchanged) and by a device-side copy of the counts on the context's stream: every copy is the
+    histogram of its own scan's records."""
     sy, lib, torch = pkg.synth, pkg._lib, torch_cuda
     c = lib.Context(0)
     c.set_records_in_stream_order(True)
