@@ -99,6 +99,7 @@ int motifs_ctx_set_workspace_limit(motifs_ctx* ctx, size_t bytes);
  * everything queued on the context's stream afterwards and after motifs_ctx_synchronize, as a hipMemcpyAsync's destination is.
  * A host loop over many shards then prepares its next call under the record writes instead of after them (the single-launch
  * plan only: a scan that needs several super-batches or runs in chunk groups still returns when all of it is done).
+ * The wait for the totals is a poll of a pinned host word the row scan writes behind them (no event is recorded in the stream); a host core spins meanwhile.
  * MOTIFS_ERR_BUFFER_TOO_SMALL is returned only after the stream has drained (the first `cap` records of each strand are written,
  * nothing past `cap` is touched), so the caller may release or re-allocate hits / scores at once. */
 int motifs_ctx_set_records_in_stream_order(motifs_ctx* ctx, int on);
