@@ -204,7 +204,7 @@ def main():
             pc, ph, ps, pk = sh["ptrs"]
             tot = sum(ctx.pwm_scan_hits_both_dev(bank, lens, pc, sh["n"], L, ph, ps, sh["cap"], n0=sh["n0"], counts_ptr=pk))
         if world > 1:   # the one real exchange of the scan: the K int64 hit counts of both strands, queued on the
-            reducer.hist_sum_(sh["counts"])  # behind the kernels that finished them, beside the record writes (motifs_hist_allreduce); the next scan queues behind it
+            reducer.hist_sum_(sh["counts"])  # scan's stream behind the kernels that wrote them (motifs_hist_allreduce); the next scan queues behind it
         return tot
 
     # weak: one 100k shard per rank

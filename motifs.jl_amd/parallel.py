@@ -63,8 +63,7 @@ class RcclReducer:
         return t
 
     def hist_sum_(self, counts):
-        """The (2, K) per-PWM hit counts of the both-strands scan just made on this context (motifs_hist_allreduce: beside that scan's
-        record writes when the scan was one launch per stage)."""
+        """The (2, K) per-PWM hit counts of the both-strands scan just made on this context (motifs_hist_allreduce, on the context's stream)."""
         self._order(counts)
         self.comm.hist_allreduce(counts.data_ptr(), counts.shape[-1], counts.shape[0] if counts.dim() == 2 else 1)
         return counts
