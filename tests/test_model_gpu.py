@@ -399,8 +399,16 @@ def test_step_sizes_take_different_kernels_and_agree(ctx, pkg, G):
             l, gr = gpu_loss_grad(pkg, ctx, cdl, codes[g * hp.batch_size:(g + 1) * hp.batch_size], 1)
             l_one.append(l[0])
             g_sum += gr
-        assert np.all(np.isfinite(l_all)) and np.allclose(np.array(l_one), l_all, rtol=1e-5)
-        assert rel_inf(g_all, g_sum.astype(np.float32)) <= 2e-5
+        # achieved (round 5, tools-free run of this comparison at 16 / 32 / 40 / 64 mini-batches): losses 2e-7; the flat gradient 6.5e-7 of its largest
+        # entry (2e-5 was asked until round 4); per array: D 8.6e-7, the scalar vectors 6.5e-7, F 1e-6 at its 99.9 % quantile with 5-29 entries up to
+        # 1.9e-4 of F's own largest entry - the launch sizes take different kernels, their float32 values differ in the last bits, and a median whose
+        # middle values are an ulp apart then falls differently (the allowance of the multi-mini-batch golden test)
+        assert np.all(np.isfinite(l_all)) and np.allclose(np.array(l_one), l_all, rtol=1e-6)
+        assert rel_inf(g_all, g_sum.astype(np.float32)) <= 2e-6
+        m = cdl.model
+        assert rel_inf(g_all[: m.nD], g_sum[: m.nD]) <= GRAD_INF
+        eF = np.abs(g_all[m.nD: m.nD + m.nF] - g_sum[m.nD: m.nD + m.nF]) / np.abs(g_sum[m.nD: m.nD + m.nF]).max()
+        assert int((eF > GRAD_INF).sum()) <= F_TIE_ENTRIES and eF.max() <= F_TIE_INF and np.quantile(eF, 0.999) <= GRAD_INF, (int((eF > GRAD_INF).sum()), eF.max())
     finally:
         cdl.model.close()
 
